@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE on CPU in the build container.
+
+Run here only (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/gen_golden.py
+
+Outputs small .npz fixtures next to this script.  A fixture holds only numbers
+(scalars the reference logs, latent slices, gradient norms, parameter checksums);
+parameters, replay batches and noise are regenerated from RandomState seeds by
+oracle/fixtures.py and are not stored.
+
+The reference draws its noise from the global torch generator
+(torch.randn_like in models/rssm.py:49,61-63 and Normal.rsample ->
+torch.distributions.normal._standard_normal for the actor and the 100-sample
+entropy, models/utils.py:161).  Both entry points are patched below to serve the
+pre-drawn RandomState noise in the reference's own draw order, and every served
+shape is checked against the order documented in SURVEY.md section 8c.
+"""
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import fixtures as fx  # noqa: E402
+
+
+def import_reference():
+    for name in ("wandb", "wandb.data_types"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, REF)
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    import common.utils as cu
+
+    cu.set_gpu_mode(False)
+    from algorithms.repo import Dreamer, RePo
+
+    return Dreamer, RePo
+
+
+class FakeSpace:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class FakeEnv:
+    def __init__(self, A):
+        self.observation_space = FakeSpace((3, 64, 64))
+        self.action_space = FakeSpace((A,))
+
+
+class RecLogger:
+    dir = "/tmp"
+
+    def __init__(self):
+        self.kv = OrderedDict()
+
+    def record(self, k, v, exclude=None):
+        self.kv[k] = v
+
+
+class NoiseFeeder:
+    """Serves pre-drawn noise through the two RNG entry points the reference uses."""
+
+    def __init__(self):
+        self.queue = []
+        self.served = []
+
+    def load(self, noise, T, H):
+        q = []
+        for t in range(T):
+            q.append(noise["obs_prior"][t])
+            q.append(noise["obs_post"][t])
+        for t in range(H - 1):
+            q.append(noise["img_act"][t])
+            q.append(noise["img_prior"][t])
+        q.append(noise["entropy"])
+        self.queue = q
+
+    def pop(self, shape):
+        a = self.queue.pop(0)
+        assert tuple(a.shape) == tuple(shape), (a.shape, tuple(shape))
+        self.served.append(tuple(shape))
+        return torch.from_numpy(a.copy())
+
+
+def install_patches(feeder, record):
+    import torch.distributions.normal as tdn
+    import torch.nn as nn
+
+    def randn_like(x, **kw):
+        return feeder.pop(x.shape)
+
+    def std_normal(shape, dtype, device):
+        return feeder.pop(shape)
+
+    torch.randn_like = randn_like
+    tdn._standard_normal = std_normal
+
+    orig_clip = nn.utils.clip_grad_norm_
+
+    def clip(params, max_norm, *a, **k):
+        params = list(params) if not isinstance(params, torch.Tensor) else [params]
+        record["clip_calls"].append(
+            [None if p.grad is None else p.grad.detach().clone() for p in params]
+        )
+        tn = orig_clip(params, max_norm, *a, **k)
+        record["total_norms"].append(float(tn))
+        return tn
+
+    nn.utils.clip_grad_norm_ = clip
+
+
+def load_params(algo, params):
+    for mod in fx.MODULES:
+        m = getattr(algo, mod)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(params[mod].keys()), (mod, list(sd.keys()))
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params[mod].items()})
+
+
+def module_norms(algo, grads, which):
+    """L2 norm of pre-clip gradients per module for one clip_grad_norm_ call."""
+    if which == "model":
+        out, i = {}, 0
+        for mod in fx.MODEL_MODULES:
+            n = len(list(getattr(algo, mod).parameters()))
+            sq = sum(float((g.double() ** 2).sum()) for g in grads[i : i + n] if g is not None)
+            out[mod] = np.sqrt(sq)
+            i += n
+        return out
+    sq = sum(float((g.double() ** 2).sum()) for g in grads if g is not None)
+    return {which: np.sqrt(sq)}
+
+
+def run_case(Algo, algo_name, L, B, H, A, n_updates, full_latents, feeder, record, out_path):
+    cfg = fx.default_config(algo=algo_name, batch_size=B, chunk_size=L, horizon=H)
+    logger = RecLogger()
+    algo = Algo(cfg, FakeEnv(A), FakeEnv(A), logger)
+    load_params(algo, fx.make_params(A, seed=7))
+    T, N = L - 1, (L - 1) * B
+
+    g = OrderedDict()
+    g["meta"] = np.array([L, B, H, A, n_updates], dtype=np.int64)
+    scalar_keys = None
+    for u in range(n_updates):
+        obs_u8, actions, rewards, dones = fx.make_batch(L, B, A, seed=11 + u)
+        noise = fx.make_noise(L, B, H, A, seed=101 + u)
+        feeder.load(noise, T, H)
+        record["clip_calls"].clear()
+        record["total_norms"].clear()
+        logger.kv.clear()
+
+        obs = torch.from_numpy(fx.preprocess_u8(obs_u8))
+        acts = torch.from_numpy(actions)
+        rews = torch.from_numpy(rewards)
+        nonterms = torch.from_numpy(1 - dones)
+        beliefs, post = algo.train_dynamics(obs, acts, rews, nonterms)
+        algo.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
+        assert not feeder.queue, "noise left over: draw order differs from SURVEY 8c"
+
+        keys = sorted(logger.kv.keys())
+        if scalar_keys is None:
+            scalar_keys = keys
+        assert keys == scalar_keys
+        g[f"u{u}/scalars"] = np.array([logger.kv[k] for k in keys], dtype=np.float64)
+        if hasattr(algo, "log_beta"):
+            g[f"u{u}/log_beta"] = np.array(algo.log_beta.item(), dtype=np.float64)
+        g[f"u{u}/total_norms"] = np.array(record["total_norms"], dtype=np.float64)
+        mn = module_norms(algo, record["clip_calls"][0], "model")
+        mn.update(module_norms(algo, record["clip_calls"][1], "actor_model"))
+        mn.update(module_norms(algo, record["clip_calls"][2], "value_model"))
+        g[f"u{u}/module_grad_norms"] = np.array([mn[m] for m in fx.MODULES], dtype=np.float64)
+        if full_latents:
+            g[f"u{u}/beliefs"] = beliefs.numpy().copy()
+            g[f"u{u}/posterior_states"] = post.numpy().copy()
+        else:
+            g[f"u{u}/beliefs"] = beliefs.numpy()[::7, ::3, :8].copy()
+            g[f"u{u}/posterior_states"] = post.numpy()[::7, ::3, :8].copy()
+        print(
+            f"  [{os.path.basename(out_path)}] update {u}: "
+            + " ".join(f"{k.split('/')[-1]}={logger.kv[k]:.6g}" for k in keys),
+            flush=True,
+        )
+    g["scalar_keys"] = np.array(scalar_keys)
+    # per-tensor checksums after the last update
+    sums, abssums, names = [], [], []
+    for mod in fx.MODULES:
+        for k, v in getattr(algo, mod).state_dict().items():
+            names.append(f"{mod}.{k}")
+            sums.append(float(v.double().sum()))
+            abssums.append(float(v.double().abs().sum()))
+    g["param_names"] = np.array(names)
+    g["param_sums"] = np.array(sums, dtype=np.float64)
+    g["param_abssums"] = np.array(abssums, dtype=np.float64)
+    np.savez_compressed(out_path, **g)
+    print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    Dreamer, RePo = import_reference()
+    feeder = NoiseFeeder()
+    record = {"clip_calls": [], "total_norms": []}
+    install_patches(feeder, record)
+
+    # tiny unit-test size, full latents
+    run_case(RePo, "repo", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(HERE, "repo_tiny.npz"))
+    # config 5: Dreamer objective (free-nats KL, attached decoder)
+    run_case(Dreamer, "dreamer", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(HERE, "dreamer_tiny.npz"))
+    # ragged / odd sizes: B not a multiple of anything, A=7 (config 4's action size)
+    run_case(RePo, "repo", 6, 3, 3, 7, 2, True, feeder, record, os.path.join(HERE, "repo_odd.npz"))
+    # config 1 shapes, scalar + sliced latents only
+    run_case(RePo, "repo", 50, 16, 15, 6, 2, False, feeder, record, os.path.join(HERE, "repo_c1.npz"))
+
+
+if __name__ == "__main__":
+    main()
