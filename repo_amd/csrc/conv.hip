@@ -1,0 +1,486 @@
+// Stride-2 convolution family of the reference's encoder/decoder on the igemm tile engine.
+//
+// A layer is a (big, small) pair with big = 2*small + KS - 2 and one weight tensor
+// w[cs][cb][ky][kx] (nn.Conv2d (out,in,kh,kw) for the encoder, nn.ConvTranspose2d
+// (in,out,kh,kw) for the decoder -- the same indexing).  GEMM roles put channels on M and
+// pixels on N so the epilogue's lanes run along the contiguous pixel index of NCHW.
+//
+//   down : small[img][cs][sy][sx] = sum_{cb,ky,kx} big[img][cb][2sy+ky][2sx+kx] w[cs][cb][ky][kx]
+//          M = CS, N = nimg*HS*WS, K = CB*KS*KS                 (A = weights, k-contiguous)
+//   up   : for each output parity class (py,px):
+//          big[img][cb][2y+py][2x+px] = sum_{cs,jy,jx} small[img][cs][y-jy][x-jx] w[cs][cb][py+2jy][px+2jx]
+//          M = CB, N = nimg*ny*nx, K = CS*JY*JX  -- only the taps that exist, no zero-stuffing
+//   upm  : the four classes merged on M (M = 4*CB) for CB = 3, where a 32-row tile per class
+//          would waste 29 rows; the taps (3x3 for k=6) are shared by all four classes.
+//   wgrad: dw[cs][cb][ky][kx] = sum_{img,sy,sx} small[img][cs][sy][sx] big[img][cb][2sy+ky][2sx+kx]
+//          M = CS, N = CB*KS*KS (+1 column of ones = bias gradient of `small`), K = nimg*HS*WS
+//          split over images into slabs, reduced in fixed order.
+#include <type_traits>
+
+#include "igemm.h"
+
+namespace repo {
+
+template <int CB_, int CS_, int HB_, int KS_>
+struct Geo {
+  static constexpr int CB = CB_, CS = CS_, HB = HB_, WB = HB_, KS = KS_;
+  static constexpr int HS = (HB - KS) / 2 + 1, WS = HS;
+  static constexpr int PB = HB * WB, PS = HS * WS, KK = KS * KS;
+};
+using GEnc1 = Geo<3, 32, 64, 4>;
+using GEnc2 = Geo<32, 64, 31, 4>;
+using GEnc3 = Geo<64, 128, 14, 4>;
+using GEnc4 = Geo<128, 256, 6, 4>;
+using GDec2 = Geo<64, 128, 13, 5>;
+using GDec3 = Geo<32, 64, 30, 6>;
+using GDec4 = Geo<3, 32, 64, 6>;
+static_assert(GEnc1::HS == 31 && GEnc2::HS == 14 && GEnc3::HS == 6 && GEnc4::HS == 2, "encoder geometry");
+static_assert(GDec2::HS == 5 && GDec3::HS == 13 && GDec4::HS == 30, "decoder geometry");
+
+__device__ __forceinline__ float epi_apply(float v, int epi, const float* bias, int ch, const float* aux, int o) {
+  if (bias) v += bias[ch];
+  if (epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
+  else if (epi == REPO_EPI_MUL_DRELU) v = aux[o] > 0.f ? v : 0.f;
+  return v;
+}
+
+// ------------------------------------------------------------------------------- down
+template <class G, class BigT>
+struct ConvDownOp {
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
+  const BigT* big;
+  const float* w;
+  const float* bias;
+  const float* aux;
+  float* out;
+  int nimg, epi;
+  __device__ void init(int) {}
+  __device__ int M() const { return G::CS; }
+  __device__ int N() const { return nimg * G::PS; }
+  __device__ int kbeg() const { return 0; }
+  __device__ int kend() const { return G::CB * G::KK; }
+  __device__ float a(int m, int k) const { return w[m * (G::CB * G::KK) + k]; }
+  __device__ float b(int k, int n) const {
+    const int img = n / G::PS, p = n % G::PS;
+    const int sy = p / G::WS, sx = p % G::WS;
+    const int cb = k / G::KK, r = k % G::KK;
+    const int ky = r / G::KS, kx = r % G::KS;
+    return load_as_float(big, ((img * G::CB + cb) * G::HB + 2 * sy + ky) * G::WB + 2 * sx + kx);
+  }
+  __device__ void store(int m, int n, float v) {
+    const int img = n / G::PS, p = n % G::PS;
+    const int o = (img * G::CS + m) * G::PS + p;
+    out[o] = epi_apply(v, epi, bias, m, aux, o);
+  }
+  __device__ void finish() {}
+};
+
+// ------------------------------------------------------------------------------- up (one parity class)
+template <class G, int PY, int PX>
+struct ConvUpOp {
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
+  static constexpr int NY = (G::HB - PY + 1) / 2, NX = (G::WB - PX + 1) / 2;
+  static constexpr int JY = (G::KS - PY + 1) / 2, JX = (G::KS - PX + 1) / 2;
+  static constexpr int JJ = JY * JX;
+  const float* small;
+  const float* w;
+  const float* bias;
+  const float* aux;
+  float* out;
+  int nimg, epi;
+  __device__ void init(int) {}
+  __device__ int M() const { return G::CB; }
+  __device__ int N() const { return nimg * NY * NX; }
+  __device__ int kbeg() const { return 0; }
+  __device__ int kend() const { return G::CS * JJ; }
+  __device__ float a(int m, int k) const {
+    const int cs = k / JJ, r = k % JJ;
+    const int jy = r / JX, jx = r % JX;
+    return w[((cs * G::CB + m) * G::KS + PY + 2 * jy) * G::KS + PX + 2 * jx];
+  }
+  __device__ float b(int k, int n) const {
+    const int img = n / (NY * NX), q = n % (NY * NX);
+    const int y = q / NX, x = q % NX;
+    const int cs = k / JJ, r = k % JJ;
+    const int iy = y - r / JX, ix = x - r % JX;
+    if (iy < 0 || iy >= G::HS || ix < 0 || ix >= G::WS) return 0.f;
+    return small[((img * G::CS + cs) * G::HS + iy) * G::WS + ix];
+  }
+  __device__ void store(int m, int n, float v) {
+    const int img = n / (NY * NX), q = n % (NY * NX);
+    const int y = q / NX, x = q % NX;
+    const int o = ((img * G::CB + m) * G::HB + 2 * y + PY) * G::WB + 2 * x + PX;
+    out[o] = epi_apply(v, epi, bias, m, aux, o);
+  }
+  __device__ void finish() {}
+};
+
+// ------------------------------------------------------------------------------- up, classes merged on M
+// MODE 0: plain epilogue (bias / relu / mask).  MODE 1: pixel-likelihood epilogue.
+template <class G, class TgtT, int MODE>
+struct ConvUpMergedOp {
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
+  static constexpr int NY = (G::HB + 1) / 2, NX = (G::WB + 1) / 2;
+  static constexpr int J = (G::KS + 1) / 2, JJ = J * J;
+  const float* small;
+  const float* w;
+  const float* bias;
+  const float* aux;
+  float* out;  // MODE 0: output; MODE 1: recon (nullable)
+  int nimg, epi;
+  // MODE 1
+  const TgtT* target;
+  float* dpre;       // nullable
+  float* partials;   // one per workgroup
+  float grad_scale;
+  float lsum;
+
+  __device__ void init(int) { lsum = 0.f; }
+  __device__ int M() const { return 4 * G::CB; }
+  __device__ int N() const { return nimg * NY * NX; }
+  __device__ int kbeg() const { return 0; }
+  __device__ int kend() const { return G::CS * JJ; }
+  __device__ float a(int m, int k) const {
+    const int cls = m / G::CB, cb = m % G::CB;
+    const int cs = k / JJ, r = k % JJ;
+    const int ky = (cls >> 1) + 2 * (r / J), kx = (cls & 1) + 2 * (r % J);
+    if (ky >= G::KS || kx >= G::KS) return 0.f;
+    return w[((cs * G::CB + cb) * G::KS + ky) * G::KS + kx];
+  }
+  __device__ float b(int k, int n) const {
+    const int img = n / (NY * NX), q = n % (NY * NX);
+    const int y = q / NX, x = q % NX;
+    const int cs = k / JJ, r = k % JJ;
+    const int iy = y - r / J, ix = x - r % J;
+    if (iy < 0 || iy >= G::HS || ix < 0 || ix >= G::WS) return 0.f;
+    return small[((img * G::CS + cs) * G::HS + iy) * G::WS + ix];
+  }
+  __device__ void store(int m, int n, float v) {
+    const int cls = m / G::CB, cb = m % G::CB;
+    const int img = n / (NY * NX), q = n % (NY * NX);
+    const int by = 2 * (q / NX) + (cls >> 1), bx = 2 * (q % NX) + (cls & 1);
+    if (by >= G::HB || bx >= G::WB) return;
+    const int o = ((img * G::CB + cb) * G::HB + by) * G::WB + bx;
+    if (MODE == 0) {
+      out[o] = epi_apply(v, epi, bias, cb, aux, o);
+    } else {
+      if (bias) v += bias[cb];
+      const float d = v - load_as_float(target, o);
+      if (out) out[o] = v;
+      if (dpre) dpre[o] = d * grad_scale;
+      lsum += 0.5f * d * d;
+    }
+  }
+  __device__ void finish() {
+    if (MODE == 1) {
+      __shared__ float red[16];
+      const float s = block_sum(lsum, red);
+      if (threadIdx.x == 0)
+        partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------- wgrad
+template <class G, class BigT>
+struct ConvWgradOp {
+  static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
+  static constexpr int NW = G::CB * G::KK;
+  const float* small;
+  const BigT* big;
+  float* slab;  // [splits][CS][NW+1]
+  int nimg, imgs_per_split;
+  int z, kb, ke;
+  __device__ void init(int zz) {
+    z = zz;
+    kb = zz * imgs_per_split * G::PS;
+    ke = min(nimg * G::PS, kb + imgs_per_split * G::PS);
+  }
+  __device__ int M() const { return G::CS; }
+  __device__ int N() const { return NW + 1; }
+  __device__ int kbeg() const { return kb; }
+  __device__ int kend() const { return ke; }
+  __device__ float a(int m, int k) const {
+    const int img = k / G::PS, p = k % G::PS;
+    return small[(img * G::CS + m) * G::PS + p];
+  }
+  __device__ float b(int k, int n) const {
+    if (n == NW) return 1.f;
+    const int img = k / G::PS, p = k % G::PS;
+    const int sy = p / G::WS, sx = p % G::WS;
+    const int cb = n / G::KK, r = n % G::KK;
+    return load_as_float(big, ((img * G::CB + cb) * G::HB + 2 * sy + r / G::KS) * G::WB + 2 * sx + r % G::KS);
+  }
+  __device__ void store(int m, int n, float v) { slab[((size_t)z * G::CS + m) * (NW + 1) + n] = v; }
+  __device__ void finish() {}
+};
+
+__global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, int splits, int Mrows, int Ncols,
+                                        float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const int total = Mrows * (Ncols + 1);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int m = i / (Ncols + 1), n = i % (Ncols + 1);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
+    if (n < Ncols) {
+      float* p = dw + (size_t)m * Ncols + n;
+      *p = accumulate ? *p + s : s;
+    } else if (db) {
+      db[m] = accumulate ? db[m] + s : s;
+    }
+  }
+}
+
+__global__ void partial_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ out, int accumulate) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += parts[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *out = accumulate ? *out + s : s;
+}
+
+// x[n][c][p] -> partial[s][c] over image chunk s
+__global__ void channel_sum_kernel(const float* __restrict__ x, int nimg, int C, int P, int imgs_per_split,
+                                   float* __restrict__ parts) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int i0 = s * imgs_per_split, i1 = min(nimg, i0 + imgs_per_split);
+  float acc = 0.f;
+  for (int img = i0; img < i1; ++img) {
+    const float* px = x + ((size_t)img * C + c) * P;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) acc += px[p];
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[s * C + c] = acc;
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ parts, int splits, int C, float* __restrict__ out,
+                                         int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += parts[z * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ void relu_mask_kernel(int64_t n, const float* __restrict__ dy, const float* __restrict__ h,
+                                 float* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = h[i] > 0.f ? dy[i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------- host-side dispatch
+template <class G>
+struct TileFor {
+  // M = channels on the tile's M; pick BM to match, BN to keep ~>=512 workgroups
+  using Down = typename std::conditional<(G::CS <= 32), T32x256,
+                                         typename std::conditional<(G::CS <= 64), T64x128, T128x128>::type>::type;
+  using Up = typename std::conditional<(G::CB <= 32), T32x256,
+                                       typename std::conditional<(G::CB <= 64), T64x128, T128x128>::type>::type;
+  using Wgrad = typename std::conditional<(G::CS <= 32), T32x128, T64x64>::type;
+};
+
+template <class G, class BigT>
+static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
+                       const float* aux, hipStream_t s) {
+  if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  ConvDownOp<G, BigT> op{big, w, bias, aux, small, (int)nimg, epi};
+  return launch_igemm<typename TileFor<G>::Down>(op, G::CS, nimg * G::PS, 1, s);
+}
+
+template <class G, int PY, int PX>
+static int conv_up_class(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
+                         const float* aux, hipStream_t s) {
+  using Op = ConvUpOp<G, PY, PX>;
+  Op op{small, w, bias, aux, big, (int)nimg, epi};
+  return launch_igemm<typename TileFor<G>::Up>(op, G::CB, nimg * (int64_t)Op::NY * Op::NX, 1, s);
+}
+
+template <class G>
+static int conv_up_t(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
+                     const float* aux, hipStream_t s) {
+  if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  if (G::CB < 8) {
+    ConvUpMergedOp<G, float, 0> op{small, w, bias, aux, big, (int)nimg, epi, nullptr, nullptr, nullptr, 0.f, 0.f};
+    return launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
+  }
+  int rc;
+  if ((rc = conv_up_class<G, 0, 0>(nimg, small, w, bias, big, epi, aux, s))) return rc;
+  if ((rc = conv_up_class<G, 0, 1>(nimg, small, w, bias, big, epi, aux, s))) return rc;
+  if ((rc = conv_up_class<G, 1, 0>(nimg, small, w, bias, big, epi, aux, s))) return rc;
+  return conv_up_class<G, 1, 1>(nimg, small, w, bias, big, epi, aux, s);
+}
+
+template <class G>
+static int conv_wgrad_splits(int64_t nimg) {
+  using T = typename TileFor<G>::Wgrad;
+  const long tiles = ((G::CS + T::BM - 1) / T::BM) * ((G::CB * G::KK + 1 + T::BN - 1) / T::BN);
+  long want = (768 + tiles - 1) / tiles;
+  // keep >= ~256 reduction elements per split
+  long min_imgs = (256 + G::PS - 1) / G::PS;
+  long maxs = (nimg + min_imgs - 1) / min_imgs;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 2048) want = 2048;
+  // round so that splits * imgs_per_split covers nimg with no empty tail beyond one
+  long ips = (nimg + want - 1) / want;
+  return (int)((nimg + ips - 1) / ips);
+}
+
+template <class G, class BigT>
+static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float* dw, float* db, int accumulate,
+                        void* ws, size_t ws_bytes, hipStream_t s) {
+  if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  const int splits = conv_wgrad_splits<G>(nimg);
+  const size_t need = (size_t)splits * G::CS * (G::CB * G::KK + 1) * sizeof(float);
+  if (!ws || ws_bytes < need) return REPO_E_WS_TOO_SMALL;
+  const int ips = (int)((nimg + splits - 1) / splits);
+  ConvWgradOp<G, BigT> op{small, big, (float*)ws, (int)nimg, ips, 0, 0, 0};
+  int rc = launch_igemm<typename TileFor<G>::Wgrad>(op, G::CS, G::CB * G::KK + 1, splits, s);
+  if (rc) return rc;
+  const int total = G::CS * (G::CB * G::KK + 1);
+  const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
+  hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, splits, G::CS,
+                     G::CB * G::KK, dw, db, accumulate);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+}  // namespace repo
+
+using namespace repo;
+
+#define REPO_LAYER_SWITCH(layer, CALL)                 \
+  switch (layer) {                                     \
+    case 0: { using G = GEnc1; CALL; }                 \
+    case 1: { using G = GEnc2; CALL; }                 \
+    case 2: { using G = GEnc3; CALL; }                 \
+    case 3: { using G = GEnc4; CALL; }                 \
+    case 4: { using G = GDec2; CALL; }                 \
+    case 5: { using G = GDec3; CALL; }                 \
+    case 6: { using G = GDec4; CALL; }                 \
+    default: return REPO_E_BADARG;                     \
+  }
+
+extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
+                              const float* bias, float* small, int epi, const float* aux, hipStream_t stream) {
+  REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
+  if (nimg == 0) return REPO_OK;
+  REPO_REQUIRE(big && w && small, REPO_E_BADARG);
+  REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU || (epi == REPO_EPI_MUL_DRELU && aux), REPO_E_BADARG);
+  if (big_is_u8) {
+    REPO_REQUIRE(layer == 0, REPO_E_BADARG);
+    return conv_down_t<GEnc1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, stream);
+  }
+  REPO_LAYER_SWITCH(layer, return (conv_down_t<G, float>(nimg, (const float*)big, w, bias, small, epi, aux, stream)))
+}
+
+extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
+                            float* big, int epi, const float* aux, hipStream_t stream) {
+  REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
+  if (nimg == 0) return REPO_OK;
+  REPO_REQUIRE(small && w && big, REPO_E_BADARG);
+  REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU || (epi == REPO_EPI_MUL_DRELU && aux), REPO_E_BADARG);
+  REPO_LAYER_SWITCH(layer, return (conv_up_t<G>(nimg, small, w, bias, big, epi, aux, stream)))
+}
+
+extern "C" size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg) {
+  if (nimg <= 0) return 0;
+  REPO_LAYER_SWITCH(layer,
+                    return ((size_t)conv_wgrad_splits<G>(nimg) * G::CS * (G::CB * G::KK + 1) * sizeof(float)))
+}
+
+extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big, int big_is_u8,
+                               float* dw, float* dbias_small, int accumulate, void* ws, size_t ws_bytes,
+                               hipStream_t stream) {
+  REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
+  REPO_REQUIRE(small && big && dw, REPO_E_BADARG);
+  if (big_is_u8) {
+    REPO_REQUIRE(layer == 0, REPO_E_BADARG);
+    return conv_wgrad_t<GEnc1, uint8_t>(nimg, small, (const uint8_t*)big, dw, dbias_small, accumulate, ws, ws_bytes,
+                                        stream);
+  }
+  REPO_LAYER_SWITCH(layer, return (conv_wgrad_t<G, float>(nimg, small, (const float*)big, dw, dbias_small,
+                                                          accumulate, ws, ws_bytes, stream)))
+}
+
+static inline long nll_blocks(int64_t nimg) {
+  using Op = ConvUpMergedOp<GDec4, float, 1>;
+  const long N = nimg * (long)Op::NY * Op::NX;
+  return (N + T32x256::BN - 1) / T32x256::BN;
+}
+
+extern "C" size_t repo_decoder_out_nll_workspace_bytes(int64_t nimg) {
+  return nimg <= 0 ? 0 : (size_t)nll_blocks(nimg) * sizeof(float);
+}
+
+template <class TgtT>
+static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, const float* bias, const TgtT* target,
+                             float grad_scale, float* recon, float* dpre, float* loss_sum, void* ws,
+                             hipStream_t stream) {
+  using G = GDec4;
+  ConvUpMergedOp<G, TgtT, 1> op{h3, w, bias, nullptr, recon, (int)nimg, 0, target, dpre, (float*)ws, grad_scale, 0.f};
+  int rc = launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, stream);
+  if (rc) return rc;
+  if (loss_sum) {
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)ws, (int)nll_blocks(nimg),
+                       loss_sum, 0);
+    REPO_CHECK_LAUNCH();
+  }
+  return REPO_OK;
+}
+
+extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* w, const float* bias,
+                                    const void* target, int target_is_u8, float grad_scale, float* recon, float* dpre,
+                                    float* loss_sum, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
+  REPO_REQUIRE(h3 && w && target, REPO_E_BADARG);
+  REPO_REQUIRE(nimg * (int64_t)GDec4::CS * GDec4::PS < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(ws && ws_bytes >= repo_decoder_out_nll_workspace_bytes(nimg), REPO_E_WS_TOO_SMALL);
+  if (target_is_u8)
+    return decoder_out_nll_t<uint8_t>(nimg, h3, w, bias, (const uint8_t*)target, grad_scale, recon, dpre, loss_sum, ws,
+                                      stream);
+  return decoder_out_nll_t<float>(nimg, h3, w, bias, (const float*)target, grad_scale, recon, dpre, loss_sum, ws,
+                                  stream);
+}
+
+static inline int chansum_splits(int64_t nimg, int64_t C, int64_t P) {
+  long want = (1024 + C - 1) / C;
+  long min_imgs = (4096 + P - 1) / P;
+  long maxs = (nimg + min_imgs - 1) / min_imgs;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  long ips = (nimg + want - 1) / want;
+  return (int)((nimg + ips - 1) / ips);
+}
+
+extern "C" size_t repo_channel_sum_workspace_bytes(int64_t nimg, int64_t C, int64_t P) {
+  if (nimg <= 0 || C <= 0 || P <= 0) return 0;
+  return (size_t)chansum_splits(nimg, C, P) * C * sizeof(float);
+}
+
+extern "C" int repo_channel_sum(int64_t nimg, int64_t C, int64_t P, const float* x, float* out, int accumulate,
+                                void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(nimg > 0 && C > 0 && P > 0, REPO_E_SHAPE);
+  REPO_REQUIRE(x && out, REPO_E_BADARG);
+  REPO_REQUIRE(C <= 65535, REPO_E_SHAPE);
+  const int splits = chansum_splits(nimg, C, P);
+  REPO_REQUIRE(ws && ws_bytes >= (size_t)splits * C * sizeof(float), REPO_E_WS_TOO_SMALL);
+  const int ips = (int)((nimg + splits - 1) / splits);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C, (unsigned)splits), dim3(256), 0, stream, x, (int)nimg, (int)C,
+                     (int)P, ips, (float*)ws);
+  REPO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, splits,
+                     (int)C, out, accumulate);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStream_t stream) {
+  REPO_REQUIRE(n >= 0, REPO_E_SHAPE);
+  if (n == 0) return REPO_OK;
+  REPO_REQUIRE(dy && h && y, REPO_E_BADARG);
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, stream, n, dy, h, y);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}

@@ -1,0 +1,165 @@
+// Dense-layer GEMMs on the igemm tile engine: forward / backward-data (repo_gemm) and the
+// split-K weight gradient (repo_gemm_wgrad).
+#include "igemm.h"
+
+namespace repo {
+
+template <bool TA, bool TB>
+struct GemmOp {
+  static constexpr bool A_KMAJOR = !TA;  // A[m][k]: k contiguous
+  static constexpr bool B_KMAJOR = TB;   // B[n][k]: k contiguous
+  const float* A;
+  const float* B;
+  const float* bias;
+  const float* aux;
+  float* C;
+  int lda, ldb, ldc, ldaux, bias_div;
+  int M_, N_, K_;
+  int epi, accumulate;
+
+  __device__ void init(int) {}
+  __device__ int M() const { return M_; }
+  __device__ int N() const { return N_; }
+  __device__ int kbeg() const { return 0; }
+  __device__ int kend() const { return K_; }
+  __device__ float a(int m, int k) const { return TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]; }
+  __device__ float b(int k, int n) const { return TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]; }
+  __device__ void store(int m, int n, float v) {
+    if (bias) v += bias[n / bias_div];
+    switch (epi) {
+      case REPO_EPI_ELU: v = elu(v); break;
+      case REPO_EPI_RELU: v = fmaxf(v, 0.f); break;
+      case REPO_EPI_MUL_DELU: v *= elu_grad_from_out(aux[(size_t)m * ldaux + n]); break;
+      case REPO_EPI_MUL_DRELU: v = aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f; break;
+      default: break;
+    }
+    float* c = C + (size_t)m * ldc + n;
+    *c = accumulate ? *c + v : v;
+  }
+  __device__ void finish() {}
+};
+
+template <bool TA, bool TB>
+static int gemm_dispatch(const GemmOp<TA, TB>& op, long M, long N, hipStream_t s) {
+  // pick the tile by how many workgroups the problem yields (256 CUs to fill)
+  const long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  if (M >= 512 && N >= 512 && t128 >= 192) return launch_igemm<T128x128>(op, M, N, 1, s);
+  if (M <= 32) return launch_igemm<T32x128>(op, M, N, 1, s);
+  return launch_igemm<T64x64>(op, M, N, 1, s);
+}
+
+// dW[n][k] = sum_m dY[m][n] X[m][k]; column K of the product is the bias gradient.
+struct WgradOp {
+  static constexpr bool A_KMAJOR = false;  // A(m'=n, k'=m) = dY[m][n]: m' contiguous
+  static constexpr bool B_KMAJOR = false;  // B(k'=m, n'=k) = X[m][k]:  n' contiguous
+  const float* dY;
+  const float* X;
+  float* slab;  // [splits][N][K+1]
+  int lddy, ldx;
+  int rows, N_, K_, rows_per_split;
+  int z, kb, ke;
+
+  __device__ void init(int zz) {
+    z = zz;
+    kb = zz * rows_per_split;
+    ke = min(rows, kb + rows_per_split);
+  }
+  __device__ int M() const { return N_; }
+  __device__ int N() const { return K_ + 1; }
+  __device__ int kbeg() const { return kb; }
+  __device__ int kend() const { return ke; }
+  __device__ float a(int m, int k) const { return dY[(size_t)k * lddy + m]; }
+  __device__ float b(int k, int n) const { return n == K_ ? 1.f : X[(size_t)k * ldx + n]; }
+  __device__ void store(int m, int n, float v) { slab[((size_t)z * N_ + m) * (K_ + 1) + n] = v; }
+  __device__ void finish() {}
+};
+
+// out[m][n] (+)= sum_z slab[z][m][n] for n < K ; db[m] (+)= sum_z slab[z][m][K]
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, int Mrows, int Kcols,
+                                   float* __restrict__ dW, int lddw, float* __restrict__ db,
+                                   int accumulate) {
+  const int total = Mrows * (Kcols + 1);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int m = i / (Kcols + 1), n = i % (Kcols + 1);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
+    if (n < Kcols) {
+      float* p = dW + (size_t)m * lddw + n;
+      *p = accumulate ? *p + s : s;
+    } else if (db) {
+      db[m] = accumulate ? db[m] + s : s;
+    }
+  }
+}
+
+static int wgrad_splits(long rows, long N, long K) {
+  const long tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
+  long want = (768 + tiles - 1) / tiles;  // ~3 workgroups per CU
+  long maxs = (rows + 63) / 64;           // at least 64 rows per split
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+}  // namespace repo
+
+using namespace repo;
+
+extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K, const float* A,
+                         int64_t lda, const float* B, int64_t ldb, const float* bias, int64_t bias_div,
+                         float* C, int64_t ldc, int epi, const float* aux, int64_t ldaux, int accumulate,
+                         hipStream_t stream) {
+  REPO_REQUIRE(M >= 0 && N >= 0 && K >= 0, REPO_E_SHAPE);
+  if (M == 0 || N == 0) return REPO_OK;
+  REPO_REQUIRE(A && B && C, REPO_E_BADARG);
+  REPO_REQUIRE(epi >= REPO_EPI_NONE && epi <= REPO_EPI_MUL_DRELU, REPO_E_BADARG);
+  REPO_REQUIRE((epi != REPO_EPI_MUL_DELU && epi != REPO_EPI_MUL_DRELU) || aux, REPO_E_BADARG);
+  REPO_REQUIRE(M < kMaxIdx && N < kMaxIdx && K < kMaxIdx && lda < kMaxIdx && ldb < kMaxIdx && ldc < kMaxIdx,
+               REPO_E_SHAPE);
+  if (bias_div <= 0) bias_div = 1;
+#define REPO_GEMM_CASE(TA, TB)                                                                   \
+  {                                                                                              \
+    GemmOp<TA, TB> op{A,        B,        bias,           aux,    C,      (int)lda, (int)ldb, (int)ldc, \
+                      (int)ldaux, (int)bias_div, (int)M, (int)N, (int)K, epi,      accumulate};         \
+    return gemm_dispatch(op, M, N, stream);                                                      \
+  }
+  if (!transa && !transb) REPO_GEMM_CASE(false, false)
+  if (!transa && transb) REPO_GEMM_CASE(false, true)
+  if (transa && !transb) REPO_GEMM_CASE(true, false)
+  REPO_GEMM_CASE(true, true)
+#undef REPO_GEMM_CASE
+}
+
+extern "C" size_t repo_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)wgrad_splits(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float);
+}
+
+extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t lddy,
+                               const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                               int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(M >= 0 && N >= 0 && K >= 0, REPO_E_SHAPE);
+  if (N == 0 || K == 0) return REPO_OK;
+  REPO_REQUIRE(dY && X && dW, REPO_E_BADARG);
+  REPO_REQUIRE(M < kMaxIdx && N < kMaxIdx && K < kMaxIdx - 1, REPO_E_SHAPE);
+  if (M == 0) {
+    if (!accumulate) {
+      for (int64_t n = 0; n < N; ++n) (void)hipMemsetAsync(dW + n * lddw, 0, K * sizeof(float), stream);
+      if (db) (void)hipMemsetAsync(db, 0, N * sizeof(float), stream);
+    }
+    return REPO_OK;
+  }
+  const int splits = wgrad_splits(M, N, K);
+  REPO_REQUIRE(ws && ws_bytes >= repo_gemm_wgrad_workspace_bytes(M, N, K), REPO_E_WS_TOO_SMALL);
+  const int rps = (int)((M + splits - 1) / splits);
+  WgradOp op{dY, X, (float*)ws, (int)lddy, (int)ldx, (int)M, (int)N, (int)K, rps, 0, 0, 0};
+  int rc = launch_igemm<T64x64>(op, N, K + 1, splits, stream);
+  if (rc) return rc;
+  const int total = (int)(N * (K + 1));
+  const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, splits, (int)N,
+                     (int)K, dW, (int)lddw, db, accumulate);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}

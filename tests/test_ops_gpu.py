@@ -1,0 +1,215 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against fp64 PyTorch on CPU.
+
+fp32 tolerance: the kernels accumulate in fp32 (v_mfma_f32_32x32x2_f32 = chained fmaf),
+so the normwise error against an fp64 reference is bounded by ~K * 2^-24 * sum|a*b|;
+1e-5 relative to the largest output is used throughout (stated per assert).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import log, relerr, rnd
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from repo_amd import ops as o
+
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(50, 200, 36), (2450, 200, 230), (784, 1024, 230), (33, 60, 200), (700, 640, 130), (1, 1, 1), (65, 129, 17)])
+def test_gemm_layouts(ops, ta, tb, M, N, K):
+    rs = np.random.RandomState(M * 7 + N * 3 + K)
+    A = rnd(rs, K, M) if ta else rnd(rs, M, K)
+    B = rnd(rs, N, K) if tb else rnd(rs, K, N)
+    bias = rnd(rs, N)
+    want = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double()) + bias.double()
+    got = ops.gemm(dev(A), dev(B), ta, tb, bias=dev(bias))
+    e = relerr(got, want)
+    log(f"gemm ta={ta} tb={tb} {M}x{N}x{K}: relerr {e:.2e}")
+    assert e < TOL
+
+
+def test_gemm_strided_and_epilogues(ops):
+    rs = np.random.RandomState(5)
+    M, N, K = 300, 200, 230
+    feat = rnd(rs, M, 260)  # x is a column slice of a wider buffer
+    x = feat[:, 10:240]
+    W, b = rnd(rs, N, K, scale=0.1), rnd(rs, N)
+    pre = x.double() @ W.double().t() + b.double()
+    fd = dev(feat)
+    for epi, fn in [(ops.EPI_ELU, F.elu), (ops.EPI_RELU, F.relu), (ops.EPI_NONE, lambda v: v)]:
+        got = ops.gemm(fd[:, 10:240], dev(W), transb=True, bias=dev(b), epi=epi)
+        e = relerr(got, fn(pre))
+        log(f"gemm epi={epi}: relerr {e:.2e}")
+        assert e < TOL
+    # backward-data with the activation derivative fused + accumulate into a strided slice
+    h = F.elu(pre).float()
+    dy = rnd(rs, M, N)
+    want = (dy.double() * torch.where(h > 0, torch.ones_like(h), h + 1).double()) 
+    got = ops.gemm(dev(dy), dev(torch.eye(N)), epi=ops.EPI_MUL_DELU, aux=dev(h))
+    assert relerr(got, want) < TOL
+    dx_want = dy.double() @ W.double()
+    outbuf = torch.ones(M, 260).cuda()
+    ops.gemm(dev(dy), dev(W), out=outbuf[:, 10:240], accumulate=True)
+    assert relerr(outbuf[:, 10:240], dx_want + 1) < TOL
+    assert float((outbuf[:, :10] - 1).abs().max()) == 0 and float((outbuf[:, 240:] - 1).abs().max()) == 0
+    hr = F.relu(pre).float()
+    got = ops.gemm(dev(dy), dev(torch.eye(N)), epi=ops.EPI_MUL_DRELU, aux=dev(hr))
+    assert relerr(got, dy.double() * (hr > 0)) < TOL
+    # bias_div (channel bias over 25 pixels)
+    W2, b2 = rnd(rs, K, 75), rnd(rs, 3)
+    got = ops.gemm(fd[:, 10:240], dev(W2), bias=dev(b2), bias_div=25, epi=ops.EPI_RELU)
+    want = F.relu(x.double() @ W2.double() + b2.double().repeat_interleave(25))
+    assert relerr(got, want) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(2450, 200, 230), (50, 60, 200), (3000, 200, 1024), (7, 12, 200), (343, 1, 200)])
+def test_gemm_wgrad(ops, M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    dY, X = rnd(rs, M, N), rnd(rs, M, K)
+    dW, db = ops.gemm_wgrad(dev(dY), dev(X))
+    e1 = relerr(dW, dY.double().t() @ X.double())
+    e2 = relerr(db, dY.double().sum(0))
+    log(f"gemm_wgrad {M}x{N}x{K}: dW {e1:.2e} db {e2:.2e}")
+    assert e1 < TOL and e2 < TOL
+    # accumulate + strided destination (dW is a column block of a wider gradient)
+    wide = torch.full((N, K + 50), 2.0).cuda()
+    dbacc = torch.full((N,), 3.0).cuda()
+    ops.gemm_wgrad(dev(dY), dev(X), dW=wide[:, 20 : 20 + K], db=dbacc, accumulate=True)
+    assert relerr(wide[:, 20 : 20 + K], dY.double().t() @ X.double() + 2) < TOL
+    assert relerr(dbacc, dY.double().sum(0) + 3) < TOL
+    assert float((wide[:, :20] - 2).abs().max()) == 0
+
+
+def _layer_tensors(ops, layer, nimg, seed):
+    rs = np.random.RandomState(seed)
+    (cb, hb, _), (cs, hs, _) = ops.conv_shapes(layer)
+    ks = ops.CONV_GEO[layer][3]
+    big = rnd(rs, nimg, cb, hb, hb)
+    small = rnd(rs, nimg, cs, hs, hs)
+    w = rnd(rs, cs, cb, ks, ks, scale=0.1)
+    return big, small, w, rs
+
+
+@pytest.mark.parametrize("layer", range(7))
+@pytest.mark.parametrize("nimg", [1, 5])
+def test_conv_down(ops, layer, nimg):
+    big, small, w, rs = _layer_tensors(ops, layer, nimg, 100 + layer)
+    cs = small.shape[1]
+    bias = rnd(rs, cs)
+    want = F.conv2d(big.double(), w.double(), bias.double(), stride=2)
+    got = ops.conv_down(layer, dev(big), dev(w), dev(bias), epi=ops.EPI_RELU)
+    e = relerr(got, F.relu(want))
+    log(f"conv_down layer {layer} n={nimg}: {e:.2e}")
+    assert e < TOL
+    # backward-data form: no bias, masked by a saved activation
+    h = F.relu(rnd(rs, *small.shape))
+    got = ops.conv_down(layer, dev(big), dev(w), None, epi=ops.EPI_MUL_DRELU, aux=dev(h))
+    assert relerr(got, F.conv2d(big.double(), w.double(), None, stride=2) * (h > 0)) < TOL
+
+
+def test_conv_down_u8(ops):
+    rs = np.random.RandomState(3)
+    obs = torch.from_numpy(rs.randint(0, 256, size=(6, 3, 64, 64)).astype(np.uint8))
+    w, b = rnd(rs, 32, 3, 4, 4, scale=0.1), rnd(rs, 32)
+    x = ((obs.numpy().astype(np.float32) / 255) * 2) - 1.0
+    want = F.relu(F.conv2d(torch.from_numpy(x).double(), w.double(), b.double(), stride=2))
+    got = ops.conv_down(ops.ENC1, dev(obs), dev(w), dev(b), epi=ops.EPI_RELU)
+    assert relerr(got, want) < TOL
+
+
+@pytest.mark.parametrize("layer", range(7))
+@pytest.mark.parametrize("nimg", [1, 5])
+def test_conv_up(ops, layer, nimg):
+    big, small, w, rs = _layer_tensors(ops, layer, nimg, 200 + layer)
+    cb = big.shape[1]
+    bias = rnd(rs, cb)
+    hb = big.shape[2]
+
+    def up(bias_):
+        # encoder conv2 (31 -> 14) never reads the last input row/col, so its backward-data
+        # (the "up" form) leaves them at zero: pad torch's 30x30 result to the 31x31 buffer
+        r = F.conv_transpose2d(small.double(), w.double(), None, stride=2)
+        r = F.pad(r, (0, hb - r.shape[3], 0, hb - r.shape[2]))
+        return r if bias_ is None else r + bias_.double().view(1, -1, 1, 1)
+
+    want = up(bias)
+    got = ops.conv_up(layer, dev(small), dev(w), dev(bias), epi=ops.EPI_RELU)
+    e = relerr(got, F.relu(want))
+    log(f"conv_up layer {layer} n={nimg}: {e:.2e}")
+    assert e < TOL
+    h = F.relu(rnd(rs, *big.shape))
+    got = ops.conv_up(layer, dev(small), dev(w), None, epi=ops.EPI_MUL_DRELU, aux=dev(h))
+    assert relerr(got, up(None) * (h > 0)) < TOL
+    got = ops.conv_up(layer, dev(small), dev(w), dev(bias))
+    assert relerr(got, want) < TOL
+
+
+@pytest.mark.parametrize("layer", range(7))
+@pytest.mark.parametrize("nimg", [1, 9])
+def test_conv_wgrad(ops, layer, nimg):
+    big, small, w, rs = _layer_tensors(ops, layer, nimg, 300 + layer)
+    bigd = big.double().requires_grad_(False)
+    wd = w.double().requires_grad_(True)
+    out = F.conv2d(bigd, wd, None, stride=2)
+    (out * small.double()).sum().backward()
+    dw, db = ops.conv_wgrad(layer, dev(small), dev(big))
+    e1 = relerr(dw, wd.grad)
+    e2 = relerr(db, small.double().sum((0, 2, 3)))
+    log(f"conv_wgrad layer {layer} n={nimg}: dw {e1:.2e} db {e2:.2e}")
+    assert e1 < TOL and e2 < TOL
+    dw2 = torch.ones_like(dw)
+    ops.conv_wgrad(layer, dev(small), dev(big), dw=dw2, db=None, accumulate=True, want_bias=False)
+    assert relerr(dw2, wd.grad + 1) < TOL
+
+
+def test_conv_wgrad_u8(ops):
+    rs = np.random.RandomState(4)
+    obs = torch.from_numpy(rs.randint(0, 256, size=(7, 3, 64, 64)).astype(np.uint8))
+    x = torch.from_numpy(((obs.numpy().astype(np.float32) / 255) * 2) - 1.0).double()
+    small = rnd(rs, 7, 32, 31, 31)
+    wd = torch.zeros(32, 3, 4, 4, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, wd, None, stride=2) * small.double()).sum().backward()
+    dw, db = ops.conv_wgrad(ops.ENC1, dev(small), dev(obs))
+    assert relerr(dw, wd.grad) < TOL
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_decoder_out_nll(ops, u8):
+    rs = np.random.RandomState(9)
+    nimg = 6
+    h3 = F.relu(rnd(rs, nimg, 32, 30, 30))
+    w, b = rnd(rs, 32, 3, 6, 6, scale=0.05), rnd(rs, 3)
+    obs = torch.from_numpy(rs.randint(0, 256, size=(nimg, 3, 64, 64)).astype(np.uint8))
+    tgt = torch.from_numpy(((obs.numpy().astype(np.float32) / 255) * 2) - 1.0)
+    recon = F.conv_transpose2d(h3.double(), w.double(), b.double(), stride=2)
+    d = recon - tgt.double()
+    loss, dpre, rec = ops.decoder_out_nll(dev(h3), dev(w), dev(b), dev(obs if u8 else tgt), 0.25, want_recon=True)
+    e0, e1, e2 = relerr(rec, recon), relerr(dpre, d * 0.25), abs(loss.item() - (0.5 * d * d).sum().item()) / (0.5 * d * d).sum().item()
+    log(f"decoder_out_nll u8={u8}: recon {e0:.2e} dpre {e1:.2e} loss {e2:.2e}")
+    assert e0 < TOL and e1 < TOL and e2 < 1e-5
+
+
+def test_channel_sum_relu_mask(ops):
+    rs = np.random.RandomState(1)
+    x = rnd(rs, 37, 3, 64, 64)
+    assert relerr(ops.channel_sum(dev(x)), x.double().sum((0, 2, 3))) < TOL
+    x = rnd(rs, 50, 128, 25)
+    acc = torch.ones(128).cuda()
+    ops.channel_sum(dev(x), out=acc, accumulate=True)
+    assert relerr(acc, x.double().sum((0, 2)) + 1) < TOL
+    dy, h = rnd(rs, 1000, 33), F.relu(rnd(rs, 1000, 33))
+    assert float((ops.relu_mask(dev(dy), dev(h)).cpu() - dy * (h > 0)).abs().max()) == 0
