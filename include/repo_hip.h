@@ -120,6 +120,175 @@ int repo_channel_sum(int64_t nimg, int64_t C, int64_t P, const float* x, float* 
 /* y = dy * (h > 0)  (ReLU backward through a saved output), n elements */
 int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStream_t stream);
 
+/* ------------------------------------------------------------------ RSSM observe scan
+ * Fused per-timestep GRU + prior/posterior cell, persistent over the T steps
+ * (TransitionModel.observe with observations and nonterminals,
+ * models/rssm.py:76-146; cell = rssm.py:34-64).  rows are time-major: row = t*B + b.
+ *
+ * params: HOST array of 14 device pointers in the module's state_dict order:
+ *   0 fc_embed_state_action.weight (D,S+A)  1 .bias      2 rnn.weight_ih (3D,D)
+ *   3 rnn.weight_hh (3D,D)   4 rnn.bias_ih   5 rnn.bias_hh
+ *   6 fc_embed_belief_prior.weight (Hd,D)   7 .bias      8 fc_state_prior.weight (2S,Hd)  9 .bias
+ *  10 fc_embed_belief_posterior.weight (Hd,D+E)  11 .bias  12 fc_state_posterior.weight (2S,Hd)  13 .bias
+ * Inputs : prev_belief (B,D), prev_state (B,S), actions (T,B,A), nonterms (T,B),
+ *          embeds (T,B,E), eps_prior / eps_post (T,B,S) standard-normal noise in the
+ *          reference's draw order (rssm.py:49,61-63).
+ * Outputs: featx (T+1,B,D+S): slot 0 = [prev_belief|prev_state], slot t+1 = [belief_t|post_t]
+ *          (so beliefs = featx[1:,:,:D], posterior_states = featx[1:,:,D:]);
+ *          prior_state/mean/std, post_mean/std (T,B,S).
+ * Saved for backward: xsa (T,B,S+A), e (T,B,D), gates (T,B,4D) = r|z|n|W_hn h+b_hn,
+ *          hp, hq (T,B,Hd); eemb (T,B,Hd) is scratch for the hoisted embedding GEMM. */
+size_t repo_rssm_observe_fwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
+                                             int64_t S, int64_t E);
+int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
+                          const float* const* params, const float* prev_belief,
+                          const float* prev_state, const float* actions, const float* nonterms,
+                          const float* embeds, const float* eps_prior, const float* eps_post,
+                          float min_std, float* featx, float* prior_state, float* prior_mean,
+                          float* prior_std, float* post_mean, float* post_std, float* xsa, float* e,
+                          float* gates, float* hp, float* hq, float* eemb, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
+
+/* Reverse scan (BPTT) + deferred weight gradients.  Upstream gradients (each nullable):
+ * dfeat (T,B,D+S) w.r.t. featx[1:], dprior_state, dpm, dps, dqm, dqs (T,B,S) w.r.t. the
+ * prior sample and the four distribution parameters.  dparams: HOST array of 14 device
+ * pointers (same order/shapes as params) receiving the gradients ((+)= if accumulate);
+ * dembeds (T,B,E), dprev_belief (B,D), dprev_state (B,S) are nullable.
+ * Replaces autograd's traversal of the 49-step graph in model_loss.backward()
+ * (algorithms/repo/repo.py:88 / dreamer.py:287). */
+size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
+                                             int64_t S, int64_t E);
+int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
+                          const float* const* params, const float* nonterms, const float* embeds,
+                          const float* eps_prior, const float* eps_post, float min_std,
+                          const float* featx, const float* prior_std, const float* post_std,
+                          const float* xsa, const float* e, const float* gates, const float* hp,
+                          const float* hq, const float* dfeat, const float* dprior_state,
+                          const float* dpm, const float* dps, const float* dqm, const float* dqs,
+                          float* const* dparams, float* dembeds, float* dprev_belief,
+                          float* dprev_state, int accumulate, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
+
+/* ------------------------------------------------------------------ ELU-MLP heads
+ * n_layers nn.Linear layers, ELU between, last layer linear (RewardModel / ValueModel:
+ * 4 layers, out_dim 1, models/decoder.py:189-195, models/actor_critic.py:20-26; ActorModel
+ * trunk: 5 layers, out_dim 2A, models/actor_critic.py:76-82).  Input rows are [belief|state]
+ * (the torch.cat of the reference is a row of the caller's feature buffer, ld = ldx).
+ * params / dparams: HOST arrays of 2*n_layers device pointers (fc1.weight, fc1.bias, ...).
+ * hidden_out / hidden_acts: HOST arrays of n_layers-1 device pointers to (rows, hidden). */
+int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
+                 const float* x, int64_t ldx, const float* const* params, float* const* hidden_out,
+                 float* out, int64_t ldo, hipStream_t stream);
+/* dparams NULL: frozen weights (FreezeParameters, dreamer.py:306-317); dx NULL: detached input. */
+size_t repo_mlp_bwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
+                                    int n_layers);
+int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
+                 const float* x, int64_t ldx, const float* const* params,
+                 const float* const* hidden_acts, const float* dout, int64_t lddout,
+                 float* const* dparams, int accumulate_w, float* dx, int64_t lddx, int accumulate_dx,
+                 void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* Actor distribution head (models/actor_critic.py:84-87,89-102): raw (rows,2A) ->
+ * mean = mean_scale*tanh(raw_m/mean_scale), std = softplus(raw_s+init_std)+min_std.
+ * With eps (rows,A): also action = tanh(mean+std*eps) (TanhBijector rsample) and
+ * xsa[row] = [state(row) (S, ld ldstate) | action] -- the torch.cat([state, action]) input of
+ * fc_embed_state_action.  Backward maps (dmean,dstd) and/or d action to d raw. */
+int repo_actor_head_fwd(int64_t rows, int64_t A, int64_t S, const float* raw, const float* eps,
+                        const float* state, int64_t ldstate, float min_std, float init_std,
+                        float mean_scale, float* mean, float* std, float* xsa, hipStream_t stream);
+int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, const float* dstd,
+                        const float* daction, int64_t ldda, const float* action, int64_t ldact,
+                        const float* eps, const float* mean, const float* std, float min_std,
+                        float mean_scale, float* draw, hipStream_t stream);
+
+/* ------------------------------------------------------------------ imagination rollout
+ * TransitionModel.imagine(prev_belief, prev_state, actor, horizon) (models/rssm.py:148-184)
+ * with policy.get_action = rsample of the tanh-Normal on DETACHED inputs (rssm.py:170,
+ * actor_critic.py:97-102).  Hm = horizon-1 steps over N independent rows.
+ * rssm_params: 14 pointers as in repo_rssm_observe_fwd; actor_params: 2*n_actor_layers.
+ * eps_act (Hm,N,A) then eps_prior (Hm,N,S) per step, in the reference's draw order.
+ * Outputs: featx (Hm+1,N,D+S), slot 0 = start, slot t+1 = [belief|prior sample];
+ *          prior_mean/std (Hm,N,S).
+ * Saved  : a_hidden (n_actor_layers-1, Hm*N, Hd), a_raw (Hm*N,2A), a_mean/a_std (Hm*N,A),
+ *          xsa (Hm*N,S+A), e (Hm*N,D), gates (Hm*N,4D), hp (Hm*N,Hd). */
+size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
+                                             int64_t S);
+int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
+                          int n_actor_layers, const float* const* rssm_params,
+                          const float* const* actor_params, const float* belief0, const float* state0,
+                          const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
+                          float a_init_std, float a_mean_scale, float* featx, float* prior_mean,
+                          float* prior_std, float* a_hidden, float* a_raw, float* a_mean, float* a_std,
+                          float* xsa, float* e, float* gates, float* hp, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
+/* Reverse pass with frozen world-model weights: dfeat (Hm,N,D+S) is the gradient w.r.t.
+ * featx[1:] (from the heads and the entropy term), dprior_mean/std nullable.  Emits
+ * d_araw (Hm*N,2A), the gradient at the actor trunk's output of every step (the caller
+ * finishes with repo_mlp_bwd over all Hm*N rows), and optionally dfeat0 (N,D+S). */
+size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
+                                             int64_t S);
+int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
+                          const float* const* rssm_params, const float* eps_act,
+                          const float* eps_prior, float min_std, float a_min_std, float a_mean_scale,
+                          const float* featx, const float* prior_std, const float* a_mean,
+                          const float* a_std, const float* xsa, const float* e, const float* gates,
+                          const float* hp, const float* dfeat, const float* dprior_mean,
+                          const float* dprior_std, float* d_araw, float* dfeat0, void* ws,
+                          size_t ws_bytes, hipStream_t stream);
+
+/* ------------------------------------------------------------------ losses and regularisers
+ * All reductions use repo_reduce_workspace_bytes() of scratch and write device scalars
+ * (no host synchronisation; the caller batches its .item() reads). */
+size_t repo_reduce_workspace_bytes(void);
+
+/* KL(q||p) of diagonal Gaussians over rows x S.
+ * mode 0 (RePo, algorithms/repo/repo.py:64-83): *kl_sum = sum_rows KL; gradients of
+ *   exp(*log_beta) * (alpha*KL(sg q||p) + (1-alpha)*KL(q||sg p)) * scale.
+ * mode 1 (Dreamer, algorithms/repo/dreamer.py:278-282): *kl_sum = sum_rows max(KL, free_nats);
+ *   gradients of that * scale.   Gradient outputs are nullable. */
+int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const float* ps, const float* qm,
+                    const float* qs, int mode, float alpha, const float* log_beta, float free_nats,
+                    float scale, float* dpm, float* dps, float* dqm, float* dqs, float* kl_sum,
+                    void* ws, size_t ws_bytes, hipStream_t stream);
+/* Lagrangian dual ascent on log_beta (repo.py:83,93-105): grad = -(kl_sum/rows - target_kl),
+ * one Adam step (state exp_avg/exp_avg_sq on device, `step` = 1-based count) if apply.
+ * scalars_out[4] = {kl_div, kl_loss = beta_old*viol, beta_loss = -log_beta_old*viol, beta_new}. */
+int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const float* kl_sum,
+                   int64_t rows, float target_kl, float lr, float beta1, float beta2, float eps,
+                   int64_t step, int apply, float* scalars_out, hipStream_t stream);
+/* Unit-variance Gaussian NLL of a scalar head (reward repo.py:58-61, value dreamer.py:365-368):
+ * sums2[0] = sum 0.5*(pred-target)^2*mask, sums2[1] = sum mask (mask NULL = ones);
+ * dpred = (pred-target)*mask*scale (nullable). */
+int repo_scalar_nll(int64_t n, const float* pred, const float* target, const float* mask, float scale,
+                    float* dpred, float* sums2, void* ws, size_t ws_bytes, hipStream_t stream);
+/* SampleDist.entropy of the tanh-Normal policy (models/utils.py:126-134,160-163):
+ * eps (samples, rows, A).  *ent_sum = sum_rows entropy_row; dmean/dstd (rows,A) =
+ * gscale * d ent_sum / d(mean,std) (nullable). */
+int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean,
+                             const float* std, const float* eps, float gscale, float* dmean,
+                             float* dstd, float* ent_sum, void* ws, size_t ws_bytes, hipStream_t stream);
+/* Independent(Normal).entropy summed over n elements (dreamer.py:327-328): dstd = gscale/std. */
+int repo_normal_entropy(int64_t n, const float* std, float gscale, float* dstd, float* ent_sum,
+                        void* ws, size_t ws_bytes, hipStream_t stream);
+/* lambda_return (common/utils.py:61-71) as called at dreamer.py:342-349: rewards, values
+ * (Hm,N); returns (Hm-1,N); *ret_sum = sum(returns); drewards/dvalues (Hm,N) = gradient of
+ * gret*sum(returns) (both or neither). */
+int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, const float* values, float gamma,
+                       float lambda_, float gret, float* returns, float* drewards, float* dvalues,
+                       float* ret_sum, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * *sqnorm = sum g^2 over a flat, 16-byte aligned buffer (global norm of
+ * nn.utils.clip_grad_norm_, repo.py:89).  Fixed-order two-level sum. */
+size_t repo_grad_sqnorm_workspace_bytes(void);
+int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* ws, size_t ws_bytes,
+                     hipStream_t stream);
+/* g *= min(1, max_norm/(sqrt(*sqnorm)+1e-6)) fused with torch.optim.Adam's update
+ * (betas, eps, no weight decay; `step` = 1-based count).  sqnorm NULL = no clipping. */
+int repo_clip_adam(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   const float* sqnorm, float max_norm, float lr, float beta1, float beta2, float eps,
+                   int64_t step, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,318 @@
+// Loss / regulariser reductions of the update: KL balance + Lagrangian dual, masked
+// Gaussian NLL of the scalar heads, Monte-Carlo tanh-Normal entropy, Normal entropy,
+// lambda-returns.  All are HBM-bound streaming kernels: coalesced loads, wave64 shuffle
+// reductions, one partial per workgroup and a fixed-order final sum (bitwise reproducible;
+// no float atomics).
+#include "common.h"
+
+namespace repo {
+
+constexpr int kRedBlocks = 1024;  // max partials per reduction
+
+__global__ void final_sum_kernel(const float* __restrict__ parts, int n, int nvals, float* __restrict__ out) {
+  // parts is [nvals][n]; out[v] = sum_i parts[v][i]
+  __shared__ float red[16];
+  for (int v = 0; v < nvals; ++v) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += parts[v * n + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[v] = s;
+  }
+}
+
+static int final_sum(const float* parts, int n, int nvals, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, parts, n, nvals, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+// ------------------------------------------------------------------ KL(q || p) of diagonal Gaussians
+// mode 0 (RePo, repo.py:64-83): out = sum_rows KL_row; gradients of
+//   beta * (alpha * KL(sg q || p) + (1-alpha) * KL(q || sg p)) * scale
+// mode 1 (Dreamer, dreamer.py:278-282): out = sum_rows max(KL_row, free_nats); gradients of
+//   max(KL_row, free_nats) * scale on both sides.
+// One wave per row (S <= 64 lanes active).
+__global__ __launch_bounds__(256) void kl_kernel(int rows, int S, const float* __restrict__ pm,
+                                                 const float* __restrict__ ps, const float* __restrict__ qm,
+                                                 const float* __restrict__ qs, int mode, float alpha,
+                                                 const float* __restrict__ log_beta, float free_nats, float scale,
+                                                 float* __restrict__ dpm, float* __restrict__ dps,
+                                                 float* __restrict__ dqm, float* __restrict__ dqs,
+                                                 float* __restrict__ parts) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const float beta = (mode == 0 && log_beta) ? expf(*log_beta) : 1.f;
+  float acc = 0.f;
+  for (int row = blockIdx.x * nw + wid; row < rows; row += gridDim.x * nw) {
+    float kl = 0.f, gpm = 0.f, gps = 0.f, gqm = 0.f, gqs = 0.f;
+    const size_t o = (size_t)row * S + lane;
+    if (lane < S) {
+      const float mp = pm[o], sp = ps[o], mq = qm[o], sq = qs[o];
+      const float ratio = sq / sp, vr = ratio * ratio;
+      const float dm = (mq - mp) / sp, t1 = dm * dm;
+      kl = 0.5f * (vr + t1 - 1.f - logf(vr));
+      const float isp2 = 1.f / (sp * sp);
+      gqm = (mq - mp) * isp2;
+      gpm = -gqm;
+      gqs = -1.f / sq + sq * isp2;
+      gps = 1.f / sp - (sq * sq + (mq - mp) * (mq - mp)) * isp2 / sp;
+    }
+    const float klrow = wave_sum(kl);
+    float wp, wq;
+    if (mode == 0) {
+      wp = beta * alpha * scale;
+      wq = beta * (1.f - alpha) * scale;
+      if (lane == 0) acc += klrow;
+    } else {
+      const bool active = klrow > free_nats;
+      wp = wq = active ? scale : 0.f;
+      if (lane == 0) acc += active ? klrow : free_nats;
+    }
+    if (lane < S) {
+      if (dpm) dpm[o] = gpm * wp;
+      if (dps) dps[o] = gps * wp;
+      if (dqm) dqm[o] = gqm * wq;
+      if (dqs) dqs[o] = gqs * wq;
+    }
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------ dual variable (repo.py:83,93-105)
+// scalars_out: [kl_div, kl_loss, beta_loss, beta_after]
+__global__ void dual_step_kernel(float* __restrict__ log_beta, float* __restrict__ m, float* __restrict__ v,
+                                 const float* __restrict__ kl_sum, float inv_rows, float target_kl, float lr, float b1,
+                                 float b2, float eps, float bc1, float bc2_sqrt, int apply,
+                                 float* __restrict__ scalars_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float lb = *log_beta;
+  const float kl_div = *kl_sum * inv_rows;
+  const float viol = kl_div - target_kl;
+  const float g = -viol;  // d(-log_beta * viol)/d log_beta
+  scalars_out[0] = kl_div;
+  scalars_out[1] = expf(lb) * viol;
+  scalars_out[2] = -lb * viol;
+  float nlb = lb;
+  if (apply) {
+    const float mm = b1 * (*m) + (1.f - b1) * g;
+    const float vv = b2 * (*v) + (1.f - b2) * g * g;
+    *m = mm;
+    *v = vv;
+    nlb = lb - (lr / bc1) * mm / (sqrtf(vv) / bc2_sqrt + eps);
+    *log_beta = nlb;
+  }
+  scalars_out[3] = expf(nlb);
+}
+
+// ------------------------------------------------------------------ masked unit-variance NLL of a scalar head
+// parts[0][blk] = sum 0.5*(p-t)^2*mask ; parts[1][blk] = sum mask ; dpred = (p-t)*mask*scale
+__global__ __launch_bounds__(256) void scalar_nll_kernel(int n, const float* __restrict__ pred,
+                                                         const float* __restrict__ target,
+                                                         const float* __restrict__ mask, float scale,
+                                                         float* __restrict__ dpred, float* __restrict__ parts) {
+  __shared__ float red[16];
+  float a = 0.f, msum = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float mk = mask ? mask[i] : 1.f;
+    const float d = pred[i] - target[i];
+    a += 0.5f * d * d * mk;
+    msum += mk;
+    if (dpred) dpred[i] = d * mk * scale;
+  }
+  const float s0 = block_sum(a, red);
+  const float s1 = block_sum(msum, red);
+  if (threadIdx.x == 0) {
+    parts[blockIdx.x] = s0;
+    parts[gridDim.x + blockIdx.x] = s1;
+  }
+}
+
+// ------------------------------------------------------------------ Monte-Carlo entropy of tanh(Normal)
+// SampleDist.entropy (models/utils.py:160-163) over TanhBijector (models/utils.py:126-134):
+//   u = mean + std*eps ; y = tanh(u) ; x = atanh(clamp(y, +-0.99999994)) (inverse recomputed)
+//   logp = -0.5((x-mean)/std)^2 - log std - 0.5 log 2pi - 2(log2 - x - softplus(-2x))
+// element e = row*A + a; eps is (NS, n) with n = rows*A.  Writes
+//   parts[blk]   = sum_e ( -(1/NS) sum_s logp_{s,e} )         (sum over rows of the row entropy)
+//   dmean/dstd[e] = gscale * d(entropy_sum)/d(mean,std)[e]
+__global__ __launch_bounds__(256) void tanh_normal_entropy_kernel(int n, int NS, const float* __restrict__ mean,
+                                                                  const float* __restrict__ stdv,
+                                                                  const float* __restrict__ eps, float gscale,
+                                                                  float* __restrict__ dmean, float* __restrict__ dstd,
+                                                                  float* __restrict__ parts) {
+  __shared__ float red[16];
+  const float kClamp = 0.99999994f;
+  const float kLog2 = 0.69314718055994531f;
+  float acc = 0.f;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const float mu = mean[e], sd = stdv[e];
+    const float isd = 1.f / sd, isd2 = isd * isd, lsd = logf(sd);
+    float slog = 0.f, gmu = 0.f, gsd = 0.f;
+    for (int s = 0; s < NS; ++s) {
+      const float ep = eps[(size_t)s * n + e];
+      const float u = fmaf(sd, ep, mu);
+      const float y = tanhf(u);
+      const bool pass = fabsf(y) <= kClamp;  // clamp passes gradient inside (inclusive) the bounds
+      const float yc = fminf(fmaxf(y, -kClamp), kClamp);
+      const float x = atanhf(yc);
+      const float dlt = x - mu;
+      slog += -0.5f * dlt * dlt * isd2 - lsd - 0.5f * kLog2Pi - 2.f * (kLog2 - x - softplus(-2.f * x));
+      // dlogp/dx (through the recomputed inverse) times dx/du (1 inside the clamp, else 0)
+      const float via_x = pass ? (-dlt * isd2 + 2.f * tanhf(x)) : 0.f;
+      gmu += dlt * isd2 + via_x;
+      gsd += dlt * dlt * isd2 * isd - isd + via_x * ep;
+    }
+    const float inv = 1.f / (float)NS;
+    acc += -slog * inv;
+    if (dmean) dmean[e] = -gmu * inv * gscale;
+    if (dstd) dstd[e] = -gsd * inv * gscale;
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[blockIdx.x] = s;
+}
+
+// sum over elements of (0.5 + 0.5 log 2pi + log std); dstd = gscale / std   (dreamer.py:327-328)
+__global__ __launch_bounds__(256) void normal_entropy_kernel(int n, const float* __restrict__ stdv, float gscale,
+                                                             float* __restrict__ dstd, float* __restrict__ parts) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float sd = stdv[i];
+    acc += 0.5f + 0.5f * kLog2Pi + logf(sd);
+    if (dstd) dstd[i] = gscale / sd;
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------ lambda-returns (common/utils.py:61-71)
+// r, v are (Hm, N) (reward / value predictions on the imagined steps); uses r[:-1], v[:-1],
+// bootstrap v[-1], constant discount gamma.  One thread per column, serial over the Hm-1 steps.
+//   returns (Hm-1, N);  parts[blk] = sum returns
+//   dr, dv (Hm, N): gradient of gret * sum(returns)      (gret = -1/((Hm-1)N) for -mean(returns))
+__global__ __launch_bounds__(256) void lambda_return_kernel(int Hm, int N, const float* __restrict__ r,
+                                                            const float* __restrict__ v, float gamma, float lam,
+                                                            float gret, float* __restrict__ returns,
+                                                            float* __restrict__ dr, float* __restrict__ dv,
+                                                            float* __restrict__ parts) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const int L = Hm - 1;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const float boot = v[(size_t)L * N + n];
+    float last = boot;
+    for (int t = L - 1; t >= 0; --t) {
+      const float nextv = (t == L - 1) ? boot : v[(size_t)(t + 1) * N + n];
+      const float inp = r[(size_t)t * N + n] + gamma * nextv * (1.f - lam);
+      last = inp + gamma * lam * last;
+      returns[(size_t)t * N + n] = last;
+      acc += last;
+    }
+    if (dr && dv) {
+      // G_t = gret + gamma*lam*G_{t-1}: total gradient reaching inputs_t
+      float G = 0.f;
+      dv[n] = 0.f;  // values[0] is never read
+      for (int t = 0; t < L; ++t) {
+        G = gret + gamma * lam * G;
+        dr[(size_t)t * N + n] = G;
+        const float gnext = gamma * (1.f - lam) * G;
+        if (t < L - 1) dv[(size_t)(t + 1) * N + n] = gnext;
+        else dv[(size_t)L * N + n] = gnext + gamma * lam * G;  // bootstrap: next_value and the scan seed
+      }
+      dr[(size_t)L * N + n] = 0.f;
+    }
+  }
+  const float s = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[blockIdx.x] = s;
+}
+
+static inline int red_blocks(long n, int per_block) {
+  long b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > kRedBlocks) b = kRedBlocks;
+  return (int)b;
+}
+
+}  // namespace repo
+
+using namespace repo;
+
+extern "C" size_t repo_reduce_workspace_bytes(void) { return 2 * kRedBlocks * sizeof(float); }
+
+extern "C" int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const float* ps, const float* qm,
+                               const float* qs, int mode, float alpha, const float* log_beta, float free_nats,
+                               float scale, float* dpm, float* dps, float* dqm, float* dqs, float* kl_sum, void* ws,
+                               size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(rows > 0 && S > 0 && S <= 64 && rows * S < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(pm && ps && qm && qs && kl_sum && (mode == 0 || mode == 1), REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
+  const int blocks = red_blocks(rows, 4);
+  hipLaunchKernelGGL(kl_kernel, dim3(blocks), dim3(256), 0, stream, (int)rows, (int)S, pm, ps, qm, qs, mode, alpha,
+                     log_beta, free_nats, scale, dpm, dps, dqm, dqs, (float*)ws);
+  REPO_CHECK_LAUNCH();
+  return final_sum((const float*)ws, blocks, 1, kl_sum, stream);
+}
+
+extern "C" int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const float* kl_sum, int64_t rows,
+                              float target_kl, float lr, float beta1, float beta2, float eps, int64_t step, int apply,
+                              float* scalars_out, hipStream_t stream) {
+  REPO_REQUIRE(log_beta && exp_avg && exp_avg_sq && kl_sum && scalars_out && rows > 0 && step >= 1, REPO_E_BADARG);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(dual_step_kernel, dim3(1), dim3(64), 0, stream, log_beta, exp_avg, exp_avg_sq, kl_sum,
+                     (float)(1.0 / (double)rows), target_kl, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), apply,
+                     scalars_out);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" int repo_scalar_nll(int64_t n, const float* pred, const float* target, const float* mask, float scale,
+                               float* dpred, float* sums2, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(n > 0 && n < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(pred && target && sums2, REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
+  const int blocks = red_blocks(n, 1024);
+  hipLaunchKernelGGL(scalar_nll_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, pred, target, mask, scale, dpred,
+                     (float*)ws);
+  REPO_CHECK_LAUNCH();
+  return final_sum((const float*)ws, blocks, 2, sums2, stream);
+}
+
+extern "C" int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,
+                                        const float* eps, float gscale, float* dmean, float* dstd, float* ent_sum,
+                                        void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(rows > 0 && A > 0 && samples > 0 && rows * A < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(mean && std && eps && ent_sum, REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
+  const long n = rows * A;
+  const int blocks = red_blocks(n, 256);
+  hipLaunchKernelGGL(tanh_normal_entropy_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, (int)samples, mean, std,
+                     eps, gscale, dmean, dstd, (float*)ws);
+  REPO_CHECK_LAUNCH();
+  return final_sum((const float*)ws, blocks, 1, ent_sum, stream);
+}
+
+extern "C" int repo_normal_entropy(int64_t n, const float* std, float gscale, float* dstd, float* ent_sum, void* ws,
+                                   size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(n > 0 && n < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(std && ent_sum, REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
+  const int blocks = red_blocks(n, 1024);
+  hipLaunchKernelGGL(normal_entropy_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, std, gscale, dstd, (float*)ws);
+  REPO_CHECK_LAUNCH();
+  return final_sum((const float*)ws, blocks, 1, ent_sum, stream);
+}
+
+extern "C" int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, const float* values, float gamma,
+                                  float lambda_, float gret, float* returns, float* drewards, float* dvalues,
+                                  float* ret_sum, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(Hm >= 2 && N > 0 && Hm * N < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(rewards && values && returns && ret_sum && ((drewards == nullptr) == (dvalues == nullptr)),
+               REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
+  const int blocks = red_blocks(N, 256);
+  hipLaunchKernelGGL(lambda_return_kernel, dim3(blocks), dim3(256), 0, stream, (int)Hm, (int)N, rewards, values, gamma,
+                     lambda_, gret, returns, drewards, dvalues, (float*)ws);
+  REPO_CHECK_LAUNCH();
+  return final_sum((const float*)ws, blocks, 1, ret_sum, stream);
+}

@@ -1,0 +1,625 @@
+// RSSM observe scan: fused per-timestep GRU + prior/posterior cell, persistent over T.
+//
+// Reference: TransitionModel.observe / compute_belief / compute_prior_state /
+// compute_posterior_state, /root/reference/algorithms/repo/models/rssm.py:34-64,76-146.
+//
+// Structure (MI355X-first, not a per-op translation):
+//  * The posterior's observation half, embed_t @ W_bq[:, D:]^T, does not depend on the
+//    recurrence and is hoisted out of the scan as ONE (T*B, E) x (E, Hd) MFMA GEMM.
+//  * The scan itself is a latency-bound chain of T dependent steps on B rows.  One
+//    persistent workgroup owns R batch rows for all T steps; the deterministic belief and
+//    the stochastic state stay in LDS between steps, and each thread owns one output
+//    feature of the current stage, so weights stream through coalesced, transposed copies
+//    ([k][feature]) that stay L2-resident, with the row vectors broadcast from LDS.
+//  * Everything the backward needs is written once per step; weight gradients are NOT
+//    formed inside the scan: the reverse scan emits per-step pre-activation deltas and the
+//    weight/bias gradients become seven (T*B)-row MFMA GEMMs afterwards.
+#include "common.h"
+
+namespace repo {
+
+constexpr int kMaxW = 256;   // max belief / hidden width (one thread per feature)
+constexpr int kMaxS2 = 128;  // max 2*state
+constexpr int kMaxX = 64;    // max state + action
+
+struct ObsDims {
+  int T, B, A, D, Hd, S;
+};
+
+// dst[c][r] = src[r*ld + c]   (rows x cols -> cols x rows)
+__global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, int ld, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[threadIdx.x][i];
+  }
+}
+
+static int transpose_to(const float* src, int rows, int cols, int ld, float* dst, hipStream_t s) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(32, 8);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, s, src, rows, cols, ld, dst);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+struct ObsFwdArgs {
+  ObsDims d;
+  // transposed weights [k][feature] and biases
+  const float *WsaT, *bsa, *WihT, *WhhT, *bih, *bhh, *WbpT, *bbp, *WspT, *bsp, *WbqT, *bbq, *WsqT, *bsq;
+  const float *prev_belief, *prev_state;  // (B,D), (B,S)
+  const float *actions, *nonterms;        // (T,B,A), (T,B)
+  const float* eemb;                      // (T,B,Hd) hoisted embed contribution (no bias)
+  const float *eps_prior, *eps_post;      // (T,B,S)
+  float* featx;                           // (T+1,B,D+S): slot 0 = [prev_belief|prev_state], slot t+1 = [belief_t|post_t]
+  float *prior_state, *prior_mean, *prior_std, *post_mean, *post_std;  // (T,B,S)
+  float *xsa, *e, *gates, *hp, *hq;       // saved for backward: (T,B,S+A) (T,B,D) (T,B,4D) (T,B,Hd) (T,B,Hd)
+  float min_std;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
+  const int T = p.d.T, B = p.d.B, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
+  const int X = S + A, F = D + S;
+  __shared__ float xs[R][kMaxX];
+  __shared__ float es[R][kMaxW];
+  __shared__ float hs[2][R][kMaxW];
+  __shared__ float hps[R][kMaxW];
+  __shared__ float hqs[R][kMaxW];
+  __shared__ float outs[R][2 * kMaxS2];  // [0,2S) prior raw, [2S,4S) posterior raw
+  __shared__ float st[R][kMaxS2];
+
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * R;
+  int nr = B - b0;
+  if (nr > R) nr = R;
+
+  // slot 0 of featx and the carried state
+  for (int i = tid; i < R * D; i += blockDim.x) {
+    const int r = i / D, j = i % D;
+    const float v = r < nr ? p.prev_belief[(size_t)(b0 + r) * D + j] : 0.f;
+    hs[0][r][j] = v;
+    if (r < nr) p.featx[(size_t)(b0 + r) * F + j] = v;
+  }
+  for (int i = tid; i < R * S; i += blockDim.x) {
+    const int r = i / S, j = i % S;
+    const float v = r < nr ? p.prev_state[(size_t)(b0 + r) * S + j] : 0.f;
+    st[r][j] = v;
+    if (r < nr) p.featx[(size_t)(b0 + r) * F + D + j] = v;
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    const size_t row0 = (size_t)t * B + b0;  // flattened (t, b0)
+    // ---- x = [state * nonterm, action]
+    for (int i = tid; i < R * X; i += blockDim.x) {
+      const int r = i / X, k = i % X;
+      float v = 0.f;
+      if (r < nr) {
+        v = k < S ? st[r][k] * p.nonterms[row0 + r] : p.actions[(row0 + r) * A + (k - S)];
+        p.xsa[(row0 + r) * X + k] = v;
+      }
+      xs[r][k] = v;
+    }
+    __syncthreads();
+    // ---- e = elu(W_sa x + b)
+    if (tid < D) {
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = p.bsa[tid];
+      for (int k = 0; k < X; ++k) {
+        const float w = p.WsaT[k * D + tid];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, xs[r][k], acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float v = elu(acc[r]);
+        es[r][tid] = v;
+        if (r < nr) p.e[(row0 + r) * D + tid] = v;
+      }
+    }
+    __syncthreads();
+    // ---- GRU cell (gate order r,z,n)
+    if (tid < D) {
+      float gi[3][R], gh[3][R];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          gi[g][r] = p.bih[g * D + tid];
+          gh[g][r] = p.bhh[g * D + tid];
+        }
+      const float* hc = &hs[cur][0][0];
+#pragma unroll 4
+      for (int k = 0; k < D; ++k) {
+        const float* wi = p.WihT + (size_t)k * 3 * D + tid;
+        const float* wh = p.WhhT + (size_t)k * 3 * D + tid;
+        const float wi0 = wi[0], wi1 = wi[D], wi2 = wi[2 * D];
+        const float wh0 = wh[0], wh1 = wh[D], wh2 = wh[2 * D];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float ev = es[r][k], hv = hc[r * kMaxW + k];
+          gi[0][r] = fmaf(wi0, ev, gi[0][r]);
+          gi[1][r] = fmaf(wi1, ev, gi[1][r]);
+          gi[2][r] = fmaf(wi2, ev, gi[2][r]);
+          gh[0][r] = fmaf(wh0, hv, gh[0][r]);
+          gh[1][r] = fmaf(wh1, hv, gh[1][r]);
+          gh[2][r] = fmaf(wh2, hv, gh[2][r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float rg = sigmoidf(gi[0][r] + gh[0][r]);
+        const float zg = sigmoidf(gi[1][r] + gh[1][r]);
+        const float ng = tanhf(gi[2][r] + rg * gh[2][r]);
+        const float hprev = hc[r * kMaxW + tid];
+        const float hn = (1.f - zg) * ng + zg * hprev;
+        hs[cur ^ 1][r][tid] = hn;
+        if (r < nr) {
+          float* g = p.gates + (row0 + r) * 4 * D;
+          g[tid] = rg;
+          g[D + tid] = zg;
+          g[2 * D + tid] = ng;
+          g[3 * D + tid] = gh[2][r];
+          p.featx[((size_t)(t + 1) * B + b0 + r) * F + tid] = hn;
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+    // ---- hidden layers of the prior and the posterior heads
+    if (tid < Hd) {
+      float ap[R], aq[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        ap[r] = p.bbp[tid];
+        aq[r] = p.bbq[tid] + (r < nr ? p.eemb[(row0 + r) * Hd + tid] : 0.f);
+      }
+      const float* hc = &hs[cur][0][0];
+#pragma unroll 4
+      for (int k = 0; k < D; ++k) {
+        const float wp = p.WbpT[(size_t)k * Hd + tid];
+        const float wq = p.WbqT[(size_t)k * Hd + tid];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float hv = hc[r * kMaxW + k];
+          ap[r] = fmaf(wp, hv, ap[r]);
+          aq[r] = fmaf(wq, hv, aq[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float vp = elu(ap[r]), vq = elu(aq[r]);
+        hps[r][tid] = vp;
+        hqs[r][tid] = vq;
+        if (r < nr) {
+          p.hp[(row0 + r) * Hd + tid] = vp;
+          p.hq[(row0 + r) * Hd + tid] = vq;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- output layers: threads [0,2S) prior, [2S,4S) posterior
+    if (tid < 4 * S) {
+      const bool post = tid >= 2 * S;
+      const int o = post ? tid - 2 * S : tid;
+      const float* Wt = post ? p.WsqT : p.WspT;
+      const float* hsrc = post ? &hqs[0][0] : &hps[0][0];
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = post ? p.bsq[o] : p.bsp[o];
+#pragma unroll 4
+      for (int k = 0; k < Hd; ++k) {
+        const float w = Wt[(size_t)k * 2 * S + o];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, hsrc[r * kMaxW + k], acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) outs[r][tid] = acc[r];
+    }
+    __syncthreads();
+    // ---- softplus + reparameterised samples
+    for (int i = tid; i < R * 2 * S; i += blockDim.x) {
+      const int r = i / (2 * S), q = i % (2 * S);
+      const bool post = q >= S;
+      const int s = post ? q - S : q;
+      const int base = post ? 2 * S : 0;
+      const float mean = outs[r][base + s];
+      const float sd = softplus(outs[r][base + S + s]) + p.min_std;
+      if (r < nr) {
+        const size_t o = (row0 + r) * S + s;
+        const float eps = post ? p.eps_post[o] : p.eps_prior[o];
+        const float smp = fmaf(sd, eps, mean);
+        if (post) {
+          p.post_mean[o] = mean;
+          p.post_std[o] = sd;
+          p.featx[((size_t)(t + 1) * B + b0 + r) * F + D + s] = smp;
+          st[r][s] = smp;
+        } else {
+          p.prior_mean[o] = mean;
+          p.prior_std[o] = sd;
+          p.prior_state[o] = smp;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct ObsBwdArgs {
+  ObsDims d;
+  int ldbq;  // row stride of W_bq (= D + E)
+  // weights in their native [out][in] layout
+  const float *Wsa, *Wih, *Whh, *Wbp, *Wsp, *Wbq, *Wsq;
+  // saved by forward
+  const float *featx, *nonterms, *e, *gates, *hp, *hq, *prior_std, *post_std, *eps_prior, *eps_post;
+  // upstream gradients, each nullable: d featx[1:] (T,B,D+S); prior_state, and the four (mean,std) (T,B,S)
+  const float *dfeat, *dprior_state, *dpm, *dps, *dqm, *dqs;
+  // per-step deltas (outputs)
+  float *doutp, *doutq;  // (T,B,2S)
+  float *dhp, *dhq;      // (T,B,Hd)   d pre-activation of the hidden layers
+  float *dgi, *dgh;      // (T,B,3D)
+  float* de;             // (T,B,D)    d pre-activation of fc_embed_state_action
+  float *dprev_belief, *dprev_state;  // (B,D) (B,S), nullable
+  float min_std;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void observe_bwd_kernel(ObsBwdArgs p) {
+  const int T = p.d.T, B = p.d.B, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
+  const int X = S + A, F = D + S;
+  __shared__ float dh[R][kMaxW];      // carried d belief
+  __shared__ float dst[R][kMaxS2];    // carried d posterior state
+  __shared__ float dbel[R][kMaxW];
+  __shared__ float douts[R][2 * kMaxS2];
+  __shared__ float dhps[R][kMaxW];
+  __shared__ float dhqs[R][kMaxW];
+  __shared__ float dgis[R][3 * kMaxW];
+  __shared__ float dghs[R][3 * kMaxW];
+  __shared__ float des[R][kMaxW];
+
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * R;
+  int nr = B - b0;
+  if (nr > R) nr = R;
+  for (int i = tid; i < R * kMaxW; i += blockDim.x) (&dh[0][0])[i] = 0.f;
+  for (int i = tid; i < R * kMaxS2; i += blockDim.x) (&dst[0][0])[i] = 0.f;
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t row0 = (size_t)t * B + b0;
+    // ---- total gradient on belief_t; heads' output-layer deltas
+    if (tid < D) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float g = dh[r][tid];
+        if (p.dfeat && r < nr) g += p.dfeat[(row0 + r) * F + tid];
+        dbel[r][tid] = g;
+      }
+    }
+    for (int i = tid; i < R * 2 * S; i += blockDim.x) {
+      const int r = i / (2 * S), q = i % (2 * S);
+      const bool post = q >= S;
+      const int s = post ? q - S : q;
+      float dm = 0.f, draw = 0.f;
+      if (r < nr) {
+        const size_t o = (row0 + r) * S + s;
+        float dsmp, dsd, sd, eps;
+        if (post) {
+          dsmp = dst[r][s] + (p.dfeat ? p.dfeat[(row0 + r) * F + D + s] : 0.f);
+          dm = p.dqm ? p.dqm[o] : 0.f;
+          dsd = p.dqs ? p.dqs[o] : 0.f;
+          sd = p.post_std[o];
+          eps = p.eps_post[o];
+        } else {
+          dsmp = p.dprior_state ? p.dprior_state[o] : 0.f;
+          dm = p.dpm ? p.dpm[o] : 0.f;
+          dsd = p.dps ? p.dps[o] : 0.f;
+          sd = p.prior_std[o];
+          eps = p.eps_prior[o];
+        }
+        dm += dsmp;
+        dsd = fmaf(dsmp, eps, dsd);
+        // d softplus(raw)/d raw = sigmoid(raw) = 1 - exp(-softplus(raw))
+        draw = dsd * (-expm1f(-(sd - p.min_std)));
+        float* dst_out = post ? p.doutq : p.doutp;
+        dst_out[(row0 + r) * 2 * S + s] = dm;
+        dst_out[(row0 + r) * 2 * S + S + s] = draw;
+      }
+      const int base = post ? 2 * S : 0;
+      douts[r][base + s] = dm;
+      douts[r][base + S + s] = draw;
+    }
+    __syncthreads();
+    // ---- back through the output layers to the hidden pre-activations
+    if (tid < Hd) {
+      float ap[R], aq[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) ap[r] = aq[r] = 0.f;
+      for (int o = 0; o < 2 * S; ++o) {
+        const float wp = p.Wsp[(size_t)o * Hd + tid];
+        const float wq = p.Wsq[(size_t)o * Hd + tid];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          ap[r] = fmaf(wp, douts[r][o], ap[r]);
+          aq[r] = fmaf(wq, douts[r][2 * S + o], aq[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float vp = 0.f, vq = 0.f;
+        if (r < nr) {
+          vp = ap[r] * elu_grad_from_out(p.hp[(row0 + r) * Hd + tid]);
+          vq = aq[r] * elu_grad_from_out(p.hq[(row0 + r) * Hd + tid]);
+          p.dhp[(row0 + r) * Hd + tid] = vp;
+          p.dhq[(row0 + r) * Hd + tid] = vq;
+        }
+        dhps[r][tid] = vp;
+        dhqs[r][tid] = vq;
+      }
+    }
+    __syncthreads();
+    // ---- into belief_t, then through the GRU gates (pointwise in the feature index)
+    if (tid < D) {
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = dbel[r][tid];
+#pragma unroll 4
+      for (int j = 0; j < Hd; ++j) {
+        const float wp = p.Wbp[(size_t)j * D + tid];
+        const float wq = p.Wbq[(size_t)j * p.ldbq + tid];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fmaf(wp, dhps[r][j], fmaf(wq, dhqs[r][j], acc[r]));
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float g_r = 0.f, g_z = 0.f, g_n = 0.f, g_hn = 0.f, dhprev = 0.f;
+        if (r < nr) {
+          const float* g = p.gates + (row0 + r) * 4 * D;
+          const float rg = g[tid], zg = g[D + tid], ng = g[2 * D + tid], ghn = g[3 * D + tid];
+          const float hprev = p.featx[((size_t)t * B + b0 + r) * F + tid];
+          const float db_ = acc[r];
+          const float dn = db_ * (1.f - zg);
+          const float dz = db_ * (hprev - ng);
+          dhprev = db_ * zg;
+          g_n = dn * (1.f - ng * ng);
+          g_hn = g_n * rg;
+          g_r = g_n * ghn * rg * (1.f - rg);
+          g_z = dz * zg * (1.f - zg);
+          float* gi = p.dgi + (row0 + r) * 3 * D;
+          float* gh = p.dgh + (row0 + r) * 3 * D;
+          gi[tid] = g_r;
+          gi[D + tid] = g_z;
+          gi[2 * D + tid] = g_n;
+          gh[tid] = g_r;
+          gh[D + tid] = g_z;
+          gh[2 * D + tid] = g_hn;
+        }
+        dgis[r][tid] = g_r;
+        dgis[r][D + tid] = g_z;
+        dgis[r][2 * D + tid] = g_n;
+        dghs[r][tid] = g_r;
+        dghs[r][D + tid] = g_z;
+        dghs[r][2 * D + tid] = g_hn;
+        dh[r][tid] = dhprev;
+      }
+    }
+    __syncthreads();
+    // ---- through W_hh into belief_{t-1}, through W_ih into e
+    if (tid < D) {
+      float ah[R], ae[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        ah[r] = dh[r][tid];
+        ae[r] = 0.f;
+      }
+#pragma unroll 4
+      for (int j = 0; j < 3 * D; ++j) {
+        const float wh = p.Whh[(size_t)j * D + tid];
+        const float wi = p.Wih[(size_t)j * D + tid];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          ah[r] = fmaf(wh, dghs[r][j], ah[r]);
+          ae[r] = fmaf(wi, dgis[r][j], ae[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        dh[r][tid] = ah[r];
+        float v = 0.f;
+        if (r < nr) {
+          v = ae[r] * elu_grad_from_out(p.e[(row0 + r) * D + tid]);
+          p.de[(row0 + r) * D + tid] = v;
+        }
+        des[r][tid] = v;
+      }
+    }
+    __syncthreads();
+    // ---- through W_sa into the previous posterior state (masked by nonterminal)
+    if (tid < S) {
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < D; ++j) {
+        const float w = p.Wsa[(size_t)j * X + tid];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, des[r][j], acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) dst[r][tid] = r < nr ? acc[r] * p.nonterms[row0 + r] : 0.f;
+    }
+    __syncthreads();
+  }
+  if (p.dprev_belief)
+    for (int i = tid; i < nr * D; i += blockDim.x) p.dprev_belief[(size_t)(b0 + i / D) * D + i % D] = dh[i / D][i % D];
+  if (p.dprev_state)
+    for (int i = tid; i < nr * S; i += blockDim.x) p.dprev_state[(size_t)(b0 + i / S) * S + i % S] = dst[i / S][i % S];
+}
+
+static bool dims_ok(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  return T >= 0 && B > 0 && A >= 0 && D > 0 && Hd > 0 && S > 0 && D <= kMaxW && Hd <= kMaxW && 2 * S <= kMaxS2 &&
+         4 * S <= 256 && S + A <= kMaxX && T * B * 4 * D < kMaxIdx;
+}
+
+static size_t fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  return (size_t)((S + A) * D + 2 * D * 3 * D + 2 * D * Hd + 2 * Hd * 2 * S);
+}
+
+}  // namespace repo
+
+using namespace repo;
+
+extern "C" size_t repo_rssm_observe_fwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
+                                                        int64_t S, int64_t E) {
+  (void)T; (void)B; (void)E;
+  return fwd_ws_floats(A, D, Hd, S) * sizeof(float);
+}
+
+extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
+                                     const float* const* params, const float* prev_belief, const float* prev_state,
+                                     const float* actions, const float* nonterms, const float* embeds,
+                                     const float* eps_prior, const float* eps_post, float min_std, float* featx,
+                                     float* prior_state, float* prior_mean, float* prior_std, float* post_mean,
+                                     float* post_std, float* xsa, float* e, float* gates, float* hp, float* hq,
+                                     float* eemb, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0, REPO_E_SHAPE);
+  REPO_REQUIRE(params && prev_belief && prev_state && actions && nonterms && embeds && eps_prior && eps_post,
+               REPO_E_BADARG);
+  REPO_REQUIRE(featx && prior_state && prior_mean && prior_std && post_mean && post_std && xsa && e && gates && hp &&
+                   hq && eemb,
+               REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= fwd_ws_floats(A, D, Hd, S) * sizeof(float), REPO_E_WS_TOO_SMALL);
+  const float* const* P = params;
+  float* w = (float*)ws;
+  float* WsaT = w;  w += (S + A) * D;
+  float* WihT = w;  w += D * 3 * D;
+  float* WhhT = w;  w += D * 3 * D;
+  float* WbpT = w;  w += D * Hd;
+  float* WbqT = w;  w += D * Hd;
+  float* WspT = w;  w += Hd * 2 * S;
+  float* WsqT = w;
+  int rc;
+  if ((rc = transpose_to(P[0], (int)D, (int)(S + A), (int)(S + A), WsaT, stream))) return rc;
+  if ((rc = transpose_to(P[2], (int)(3 * D), (int)D, (int)D, WihT, stream))) return rc;
+  if ((rc = transpose_to(P[3], (int)(3 * D), (int)D, (int)D, WhhT, stream))) return rc;
+  if ((rc = transpose_to(P[6], (int)Hd, (int)D, (int)D, WbpT, stream))) return rc;
+  if ((rc = transpose_to(P[10], (int)Hd, (int)D, (int)(D + E), WbqT, stream))) return rc;
+  if ((rc = transpose_to(P[8], (int)(2 * S), (int)Hd, (int)Hd, WspT, stream))) return rc;
+  if ((rc = transpose_to(P[12], (int)(2 * S), (int)Hd, (int)Hd, WsqT, stream))) return rc;
+  if (T == 0) return REPO_OK;
+  // hoisted: eemb = embeds @ W_bq[:, D:]^T
+  if ((rc = repo_gemm(0, 1, T * B, Hd, E, embeds, E, P[10] + D, D + E, nullptr, 1, eemb, Hd, REPO_EPI_NONE, nullptr, 0,
+                      0, stream)))
+    return rc;
+  ObsFwdArgs a;
+  a.d = ObsDims{(int)T, (int)B, (int)A, (int)D, (int)Hd, (int)S};
+  a.WsaT = WsaT; a.bsa = P[1]; a.WihT = WihT; a.WhhT = WhhT; a.bih = P[4]; a.bhh = P[5];
+  a.WbpT = WbpT; a.bbp = P[7]; a.WspT = WspT; a.bsp = P[9]; a.WbqT = WbqT; a.bbq = P[11]; a.WsqT = WsqT; a.bsq = P[13];
+  a.prev_belief = prev_belief; a.prev_state = prev_state; a.actions = actions; a.nonterms = nonterms;
+  a.eemb = eemb; a.eps_prior = eps_prior; a.eps_post = eps_post;
+  a.featx = featx; a.prior_state = prior_state; a.prior_mean = prior_mean; a.prior_std = prior_std;
+  a.post_mean = post_mean; a.post_std = post_std; a.xsa = xsa; a.e = e; a.gates = gates; a.hp = hp; a.hq = hq;
+  a.min_std = min_std;
+  // rows per workgroup: spread B over as many CUs as possible (the scan is latency-bound)
+  if (B >= 512) {
+    hipLaunchKernelGGL(observe_fwd_kernel<4>, dim3(cdiv(B, 4)), dim3(256), 0, stream, a);
+  } else if (B >= 128) {
+    hipLaunchKernelGGL(observe_fwd_kernel<2>, dim3(cdiv(B, 2)), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(observe_fwd_kernel<1>, dim3((unsigned)B), dim3(256), 0, stream, a);
+  }
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
+                                                        int64_t S, int64_t E) {
+  // deltas + the largest wgrad slab
+  const size_t rows = (size_t)T * B;
+  size_t deltas = rows * (size_t)(4 * S + 2 * Hd + 6 * D + D);
+  size_t slab = 0;
+  const int64_t shapes[8][2] = {{2 * S, Hd}, {2 * S, Hd}, {Hd, D}, {Hd, D}, {Hd, E}, {3 * D, D}, {3 * D, D}, {D, S + A}};
+  for (auto& s : shapes) {
+    size_t b = repo_gemm_wgrad_workspace_bytes(T * B, s[0], s[1]);
+    if (b > slab) slab = b;
+  }
+  return deltas * sizeof(float) + slab + 256;
+}
+
+extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
+                                     const float* const* params, const float* nonterms, const float* embeds,
+                                     const float* eps_prior, const float* eps_post, float min_std, const float* featx,
+                                     const float* prior_std, const float* post_std, const float* xsa, const float* e,
+                                     const float* gates, const float* hp, const float* hq, const float* dfeat,
+                                     const float* dprior_state, const float* dpm, const float* dps, const float* dqm,
+                                     const float* dqs, float* const* dparams, float* dembeds, float* dprev_belief,
+                                     float* dprev_state, int accumulate, void* ws, size_t ws_bytes,
+                                     hipStream_t stream) {
+  REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0 && T > 0, REPO_E_SHAPE);
+  REPO_REQUIRE(params && nonterms && embeds && eps_prior && eps_post && featx && prior_std && post_std && xsa && e &&
+                   gates && hp && hq && dparams,
+               REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_rssm_observe_bwd_workspace_bytes(T, B, A, D, Hd, S, E), REPO_E_WS_TOO_SMALL);
+  const size_t rows = (size_t)T * B;
+  float* w = (float*)ws;
+  float* doutp = w;  w += rows * 2 * S;
+  float* doutq = w;  w += rows * 2 * S;
+  float* dhp = w;    w += rows * Hd;
+  float* dhq = w;    w += rows * Hd;
+  float* dgi = w;    w += rows * 3 * D;
+  float* dgh = w;    w += rows * 3 * D;
+  float* de = w;     w += rows * D;
+  // align the slab region to 256 B
+  uintptr_t sl = ((uintptr_t)w + 255) & ~(uintptr_t)255;
+  void* slab = (void*)sl;
+  const size_t slab_bytes = ws_bytes - (sl - (uintptr_t)ws);
+
+  const float* const* P = params;
+  ObsBwdArgs a;
+  a.d = ObsDims{(int)T, (int)B, (int)A, (int)D, (int)Hd, (int)S};
+  a.ldbq = (int)(D + E);
+  a.Wsa = P[0]; a.Wih = P[2]; a.Whh = P[3]; a.Wbp = P[6]; a.Wsp = P[8]; a.Wbq = P[10]; a.Wsq = P[12];
+  a.featx = featx; a.nonterms = nonterms; a.e = e; a.gates = gates; a.hp = hp; a.hq = hq;
+  a.prior_std = prior_std; a.post_std = post_std; a.eps_prior = eps_prior; a.eps_post = eps_post;
+  a.dfeat = dfeat; a.dprior_state = dprior_state; a.dpm = dpm; a.dps = dps; a.dqm = dqm; a.dqs = dqs;
+  a.doutp = doutp; a.doutq = doutq; a.dhp = dhp; a.dhq = dhq; a.dgi = dgi; a.dgh = dgh; a.de = de;
+  a.dprev_belief = dprev_belief; a.dprev_state = dprev_state; a.min_std = min_std;
+  if (B >= 512) {
+    hipLaunchKernelGGL(observe_bwd_kernel<4>, dim3(cdiv(B, 4)), dim3(256), 0, stream, a);
+  } else if (B >= 128) {
+    hipLaunchKernelGGL(observe_bwd_kernel<2>, dim3(cdiv(B, 2)), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(observe_bwd_kernel<1>, dim3((unsigned)B), dim3(256), 0, stream, a);
+  }
+  REPO_CHECK_LAUNCH();
+
+  // deferred weight/bias gradients: (T*B)-row MFMA GEMMs
+  float* const* G = dparams;
+  const int64_t F = D + S, X = S + A, R_ = (int64_t)rows;
+  int rc;
+  // fc_state_prior / fc_state_posterior
+  if ((rc = repo_gemm_wgrad(R_, 2 * S, Hd, doutp, 2 * S, hp, Hd, G[8], Hd, G[9], accumulate, slab, slab_bytes, stream))) return rc;
+  if ((rc = repo_gemm_wgrad(R_, 2 * S, Hd, doutq, 2 * S, hq, Hd, G[12], Hd, G[13], accumulate, slab, slab_bytes, stream))) return rc;
+  // fc_embed_belief_prior: input belief_t = featx[t+1][:, :D]
+  if ((rc = repo_gemm_wgrad(R_, Hd, D, dhp, Hd, featx + (size_t)B * F, F, G[6], D, G[7], accumulate, slab, slab_bytes, stream))) return rc;
+  // fc_embed_belief_posterior: columns [0,D) from the belief, [D,D+E) from the embedding
+  if ((rc = repo_gemm_wgrad(R_, Hd, D, dhq, Hd, featx + (size_t)B * F, F, G[10], D + E, G[11], accumulate, slab, slab_bytes, stream))) return rc;
+  if ((rc = repo_gemm_wgrad(R_, Hd, E, dhq, Hd, embeds, E, G[10] + D, D + E, nullptr, accumulate, slab, slab_bytes, stream))) return rc;
+  // GRU: weight_ih sees e, weight_hh sees belief_{t-1} = featx[t][:, :D]
+  if ((rc = repo_gemm_wgrad(R_, 3 * D, D, dgi, 3 * D, e, D, G[2], D, G[4], accumulate, slab, slab_bytes, stream))) return rc;
+  if ((rc = repo_gemm_wgrad(R_, 3 * D, D, dgh, 3 * D, featx, F, G[3], D, G[5], accumulate, slab, slab_bytes, stream))) return rc;
+  // fc_embed_state_action
+  if ((rc = repo_gemm_wgrad(R_, D, X, de, D, xsa, X, G[0], X, G[1], accumulate, slab, slab_bytes, stream))) return rc;
+  // gradient into the encoder embedding: d embeds = dhq @ W_bq[:, D:]
+  if (dembeds)
+    if ((rc = repo_gemm(0, 0, R_, E, Hd, dhq, Hd, P[10] + D, D + E, nullptr, 1, dembeds, E, REPO_EPI_NONE, nullptr, 0, 0, stream))) return rc;
+  return REPO_OK;
+}

@@ -200,3 +200,315 @@ def relu_mask(dy, h, out=None):
         out = torch.empty_like(dy)
     check(lib().repo_relu_mask(dy.numel(), _ptr(_f32c(dy)), _ptr(_f32c(h)), _ptr(out), _stream()), "repo_relu_mask")
     return out
+
+
+# ----------------------------------------------------------------------------- pointer arrays
+import ctypes  # noqa: E402
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (kept alive by the caller for the duration of the call)."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else _ptr(t)
+    return arr
+
+
+def reduce_ws(device):
+    nb = lib().repo_reduce_workspace_bytes()
+    return workspace(nb, device)
+
+
+# ----------------------------------------------------------------------------- RSSM observe
+class ObserveSaved:
+    __slots__ = ("T", "B", "A", "D", "Hd", "S", "E", "featx", "prior_state", "prior_mean", "prior_std", "post_mean",
+                 "post_std", "xsa", "e", "gates", "hp", "hq", "nonterms", "embeds", "eps_prior", "eps_post")
+
+
+def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds, eps_prior, eps_post, min_std=0.1):
+    """params: list of the 14 TransitionModel tensors in state_dict order.  Time-major inputs."""
+    T, B, A = actions.shape
+    D, S = prev_belief.shape[1], prev_state.shape[1]
+    Hd = params[6].shape[0]
+    E = embeds.shape[-1]
+    dev = actions.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    sv = ObserveSaved()
+    sv.T, sv.B, sv.A, sv.D, sv.Hd, sv.S, sv.E = T, B, A, D, Hd, S, E
+    sv.featx = f(T + 1, B, D + S)
+    sv.prior_state, sv.prior_mean, sv.prior_std = f(T, B, S), f(T, B, S), f(T, B, S)
+    sv.post_mean, sv.post_std = f(T, B, S), f(T, B, S)
+    sv.xsa, sv.e, sv.gates, sv.hp, sv.hq = f(T, B, S + A), f(T, B, D), f(T, B, 4 * D), f(T, B, Hd), f(T, B, Hd)
+    eemb = f(T, B, Hd)
+    sv.nonterms = _f32c(nonterms.reshape(T, B))
+    sv.embeds, sv.eps_prior, sv.eps_post = _f32c(embeds), _f32c(eps_prior), _f32c(eps_post)
+    nb = lib().repo_rssm_observe_fwd_workspace_bytes(T, B, A, D, Hd, S, E)
+    ws = workspace(nb, dev)
+    pa = ptr_array(params)
+    check(
+        lib().repo_rssm_observe_fwd(
+            T, B, A, D, Hd, S, E, pa, _ptr(_f32c(prev_belief)), _ptr(_f32c(prev_state)), _ptr(_f32c(actions)),
+            _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior), _ptr(sv.eps_post), float(min_std),
+            _ptr(sv.featx), _ptr(sv.prior_state), _ptr(sv.prior_mean), _ptr(sv.prior_std), _ptr(sv.post_mean),
+            _ptr(sv.post_std), _ptr(sv.xsa), _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(eemb),
+            _ptr(ws), ws.numel(), _stream(),
+        ),
+        "repo_rssm_observe_fwd",
+    )
+    return sv
+
+
+def rssm_observe_bwd(params, sv, dparams, dfeat=None, dprior_state=None, dpm=None, dps=None, dqm=None, dqs=None,
+                     dembeds=None, dprev_belief=None, dprev_state=None, accumulate=False, min_std=0.1):
+    dev = sv.featx.device
+    nb = lib().repo_rssm_observe_bwd_workspace_bytes(sv.T, sv.B, sv.A, sv.D, sv.Hd, sv.S, sv.E)
+    ws = workspace(nb, dev)
+    pa, ga = ptr_array(params), ptr_array(dparams)
+    check(
+        lib().repo_rssm_observe_bwd(
+            sv.T, sv.B, sv.A, sv.D, sv.Hd, sv.S, sv.E, pa, _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior),
+            _ptr(sv.eps_post), float(min_std), _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.post_std), _ptr(sv.xsa),
+            _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(dfeat), _ptr(dprior_state), _ptr(dpm),
+            _ptr(dps), _ptr(dqm), _ptr(dqs), ga, _ptr(dembeds), _ptr(dprev_belief), _ptr(dprev_state),
+            int(accumulate), _ptr(ws), ws.numel(), _stream(),
+        ),
+        "repo_rssm_observe_bwd",
+    )
+
+
+# ----------------------------------------------------------------------------- MLP heads
+def mlp_fwd(params, x, out=None):
+    """params: [w1,b1,...,wL,bL]; x (rows, in_dim) view with contiguous rows.  Returns (out, hidden list)."""
+    L = len(params) // 2
+    rows, in_dim = x.shape
+    hidden = params[0].shape[0] if L > 1 else 0
+    out_dim = params[-2].shape[0]
+    dev = x.device
+    hid = [torch.empty(rows, hidden, dtype=torch.float32, device=dev) for _ in range(L - 1)]
+    if out is None:
+        out = torch.empty(rows, out_dim, dtype=torch.float32, device=dev)
+    pa, ha = ptr_array(params), ptr_array(hid)
+    check(
+        lib().repo_mlp_fwd(rows, in_dim, max(hidden, 1), out_dim, L, _ptr(x), _ld(x), pa, ha, _ptr(out), _ld(out),
+                           _stream()),
+        "repo_mlp_fwd",
+    )
+    return out, hid
+
+
+def mlp_bwd(params, x, hid, dout, dparams=None, accumulate_w=False, dx=None, accumulate_dx=False):
+    L = len(params) // 2
+    rows, in_dim = x.shape
+    hidden = params[0].shape[0] if L > 1 else 1
+    out_dim = params[-2].shape[0]
+    nb = lib().repo_mlp_bwd_workspace_bytes(rows, in_dim, hidden, out_dim, L)
+    ws = workspace(nb, x.device)
+    pa, ha = ptr_array(params), ptr_array(hid)
+    ga = ptr_array(dparams) if dparams is not None else None
+    check(
+        lib().repo_mlp_bwd(rows, in_dim, hidden, out_dim, L, _ptr(x), _ld(x), pa, ha, _ptr(dout), _ld(dout), ga,
+                           int(accumulate_w), _ptr(dx), _ld(dx) if dx is not None else 0, int(accumulate_dx),
+                           _ptr(ws), ws.numel(), _stream()),
+        "repo_mlp_bwd",
+    )
+
+
+def actor_head_fwd(raw, min_std=0.1, init_std=0.0, mean_scale=5.0, eps=None, state=None):
+    rows, A2 = raw.shape
+    A = A2 // 2
+    dev = raw.device
+    mean = torch.empty(rows, A, dtype=torch.float32, device=dev)
+    std = torch.empty(rows, A, dtype=torch.float32, device=dev)
+    xsa = None
+    S = 0
+    if eps is not None:
+        S = state.shape[1]
+        xsa = torch.empty(rows, S + A, dtype=torch.float32, device=dev)
+    check(
+        lib().repo_actor_head_fwd(rows, A, S, _ptr(_f32c(raw)), _ptr(eps), _ptr(state),
+                                  _ld(state) if state is not None else 0, min_std, init_std, mean_scale, _ptr(mean),
+                                  _ptr(std), _ptr(xsa), _stream()),
+        "repo_actor_head_fwd",
+    )
+    return mean, std, xsa
+
+
+def actor_head_bwd(mean, std, dmean=None, dstd=None, daction=None, action=None, eps=None, min_std=0.1, mean_scale=5.0):
+    rows, A = mean.shape
+    draw = torch.empty(rows, 2 * A, dtype=torch.float32, device=mean.device)
+    check(
+        lib().repo_actor_head_bwd(rows, A, _ptr(dmean), _ptr(dstd), _ptr(daction),
+                                  _ld(daction) if daction is not None else 0, _ptr(action),
+                                  _ld(action) if action is not None else 0, _ptr(eps), _ptr(mean), _ptr(std), min_std,
+                                  mean_scale, _ptr(draw), _stream()),
+        "repo_actor_head_bwd",
+    )
+    return draw
+
+
+# ----------------------------------------------------------------------------- imagination
+class ImagineSaved:
+    __slots__ = ("Hm", "N", "A", "D", "Hd", "S", "featx", "prior_mean", "prior_std", "a_hidden", "a_raw", "a_mean",
+                 "a_std", "xsa", "e", "gates", "hp", "eps_act", "eps_prior")
+
+
+def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_prior, min_std=0.1, a_min_std=0.1,
+                     a_init_std=0.0, a_mean_scale=5.0):
+    Hm, N, A = eps_act.shape
+    D, S = belief0.shape[1], state0.shape[1]
+    Hd = rssm_params[6].shape[0]
+    La = len(actor_params) // 2
+    dev = belief0.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+    sv = ImagineSaved()
+    sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S = Hm, N, A, D, Hd, S
+    sv.featx = f(Hm + 1, N, D + S)
+    sv.prior_mean, sv.prior_std = f(Hm, N, S), f(Hm, N, S)
+    sv.a_hidden = f(La - 1, Hm * N, Hd)
+    sv.a_raw, sv.a_mean, sv.a_std = f(Hm * N, 2 * A), f(Hm * N, A), f(Hm * N, A)
+    sv.xsa, sv.e, sv.gates, sv.hp = f(Hm * N, S + A), f(Hm * N, D), f(Hm * N, 4 * D), f(Hm * N, Hd)
+    sv.eps_act, sv.eps_prior = _f32c(eps_act), _f32c(eps_prior)
+    nb = lib().repo_rssm_imagine_fwd_workspace_bytes(Hm, N, A, D, Hd, S)
+    ws = workspace(nb, dev)
+    ra, aa = ptr_array(rssm_params), ptr_array(actor_params)
+    check(
+        lib().repo_rssm_imagine_fwd(
+            Hm, N, A, D, Hd, S, La, ra, aa, _ptr(_f32c(belief0)), _ptr(_f32c(state0)), _ptr(sv.eps_act),
+            _ptr(sv.eps_prior), min_std, a_min_std, a_init_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_mean),
+            _ptr(sv.prior_std), _ptr(sv.a_hidden), _ptr(sv.a_raw), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
+            _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(ws), ws.numel(), _stream(),
+        ),
+        "repo_rssm_imagine_fwd",
+    )
+    return sv
+
+
+def rssm_imagine_bwd(rssm_params, sv, dfeat, dprior_mean=None, dprior_std=None, want_dfeat0=False, min_std=0.1,
+                     a_min_std=0.1, a_mean_scale=5.0):
+    dev = dfeat.device
+    d_araw = torch.empty(sv.Hm * sv.N, 2 * sv.A, dtype=torch.float32, device=dev)
+    dfeat0 = torch.empty(sv.N, sv.D + sv.S, dtype=torch.float32, device=dev) if want_dfeat0 else None
+    nb = lib().repo_rssm_imagine_bwd_workspace_bytes(sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S)
+    ws = workspace(nb, dev)
+    ra = ptr_array(rssm_params)
+    check(
+        lib().repo_rssm_imagine_bwd(
+            sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S, ra, _ptr(sv.eps_act), _ptr(sv.eps_prior), min_std, a_min_std,
+            a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
+            _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(_f32c(dfeat)), _ptr(dprior_mean), _ptr(dprior_std),
+            _ptr(d_araw), _ptr(dfeat0), _ptr(ws), ws.numel(), _stream(),
+        ),
+        "repo_rssm_imagine_bwd",
+    )
+    return d_araw, dfeat0
+
+
+# ----------------------------------------------------------------------------- losses
+def kl_balance(pm, ps, qm, qs, mode, alpha, log_beta, free_nats, scale, want_grads=True):
+    S = pm.shape[-1]
+    rows = pm.numel() // S
+    dev = pm.device
+    g = [torch.empty_like(pm) for _ in range(4)] if want_grads else [None] * 4
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = reduce_ws(dev)
+    check(
+        lib().repo_kl_balance(rows, S, _ptr(_f32c(pm)), _ptr(_f32c(ps)), _ptr(_f32c(qm)), _ptr(_f32c(qs)), mode,
+                              float(alpha), _ptr(log_beta), float(free_nats), float(scale), _ptr(g[0]), _ptr(g[1]),
+                              _ptr(g[2]), _ptr(g[3]), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+        "repo_kl_balance",
+    )
+    return out, g
+
+
+def dual_step(log_beta, exp_avg, exp_avg_sq, kl_sum, rows, target_kl, lr, step, apply=True, betas=(0.9, 0.999),
+              eps=1e-8, out=None):
+    if out is None:
+        out = torch.empty(4, dtype=torch.float32, device=log_beta.device)
+    check(
+        lib().repo_dual_step(_ptr(log_beta), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(kl_sum), rows, float(target_kl),
+                             float(lr), betas[0], betas[1], eps, step, int(apply), _ptr(out), _stream()),
+        "repo_dual_step",
+    )
+    return out
+
+
+def scalar_nll(pred, target, mask, scale, want_grad=True, out=None):
+    n = pred.numel()
+    dev = pred.device
+    dpred = torch.empty(n, dtype=torch.float32, device=dev) if want_grad else None
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = reduce_ws(dev)
+    check(
+        lib().repo_scalar_nll(n, _ptr(_f32c(pred)), _ptr(_f32c(target)), _ptr(mask), float(scale), _ptr(dpred),
+                              _ptr(out), _ptr(ws), ws.numel(), _stream()),
+        "repo_scalar_nll",
+    )
+    return out, dpred
+
+
+def tanh_normal_entropy(mean, std, eps, gscale=0.0, want_grads=True):
+    rows, A = mean.shape
+    NS = eps.shape[0]
+    assert eps.numel() == NS * rows * A
+    dev = mean.device
+    dmean = torch.empty_like(mean) if want_grads else None
+    dstd = torch.empty_like(std) if want_grads else None
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = reduce_ws(dev)
+    check(
+        lib().repo_tanh_normal_entropy(rows, A, NS, _ptr(_f32c(mean)), _ptr(_f32c(std)), _ptr(_f32c(eps)),
+                                       float(gscale), _ptr(dmean), _ptr(dstd), _ptr(out), _ptr(ws), ws.numel(),
+                                       _stream()),
+        "repo_tanh_normal_entropy",
+    )
+    return out, dmean, dstd
+
+
+def normal_entropy(std, gscale=0.0, want_grad=False):
+    dev = std.device
+    dstd = torch.empty_like(std) if want_grad else None
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = reduce_ws(dev)
+    check(
+        lib().repo_normal_entropy(std.numel(), _ptr(_f32c(std)), float(gscale), _ptr(dstd), _ptr(out), _ptr(ws),
+                                  ws.numel(), _stream()),
+        "repo_normal_entropy",
+    )
+    return out, dstd
+
+
+def lambda_return(rewards, values, gamma, lambda_, gret=0.0, want_grads=True):
+    Hm, N = rewards.shape
+    dev = rewards.device
+    returns = torch.empty(Hm - 1, N, dtype=torch.float32, device=dev)
+    dr = torch.empty(Hm, N, dtype=torch.float32, device=dev) if want_grads else None
+    dv = torch.empty(Hm, N, dtype=torch.float32, device=dev) if want_grads else None
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = reduce_ws(dev)
+    check(
+        lib().repo_lambda_return(Hm, N, _ptr(_f32c(rewards)), _ptr(_f32c(values)), float(gamma), float(lambda_),
+                                 float(gret), _ptr(returns), _ptr(dr), _ptr(dv), _ptr(out), _ptr(ws), ws.numel(),
+                                 _stream()),
+        "repo_lambda_return",
+    )
+    return returns, dr, dv, out
+
+
+# ----------------------------------------------------------------------------- optimiser
+def grad_sqnorm(g, out=None):
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=g.device)
+    nb = lib().repo_grad_sqnorm_workspace_bytes()
+    ws = workspace(nb, g.device)
+    check(lib().repo_grad_sqnorm(g.numel(), _ptr(_f32c(g)), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+          "repo_grad_sqnorm")
+    return out
+
+
+def clip_adam(p, g, m, v, sqnorm, max_norm, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    check(
+        lib().repo_clip_adam(p.numel(), _ptr(_f32c(p)), _ptr(_f32c(g)), _ptr(_f32c(m)), _ptr(_f32c(v)), _ptr(sqnorm),
+                             float(max_norm), float(lr), betas[0], betas[1], eps, step, _stream()),
+        "repo_clip_adam",
+    )

@@ -1,0 +1,246 @@
+"""Parity of the fused RSSM / head / loss / optimiser kernels against the CPU oracle
+(oracle/repo_oracle.py, itself pinned to the reference by tests/test_oracle_golden.py).
+
+Tolerances: forward values 1e-5 relative to the largest element (fp32 accumulation order
+differs); gradients 1e-4 normwise (49-step BPTT compounds rounding).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fixtures as fx
+from oracle import repo_oracle as ro
+from tests.util import l2err, log, relerr, rnd
+
+pytestmark = pytest.mark.gpu
+
+FTOL = 1e-5
+GTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from repo_amd import ops as o
+
+    return o
+
+
+def tparams(mod, A, seed=7, requires_grad=True):
+    p = fx.make_params(A, seed)[mod]
+    return {k: torch.tensor(v, requires_grad=requires_grad) for k, v in p.items()}
+
+
+def cu(d):
+    return [v.detach().cuda().contiguous() for v in d.values()]
+
+
+@pytest.mark.parametrize("T,B,A", [(7, 4, 6), (5, 3, 7), (49, 16, 6), (3, 130, 6)])
+def test_observe_fwd_bwd(ops, T, B, A):
+    rs = np.random.RandomState(T * 100 + B)
+    D, S, E = 200, 30, 1024
+    p = tparams("transition_model", A)
+    actions = rnd(rs, T, B, A)
+    nonterms = torch.from_numpy((rs.uniform(size=(T, B, 1)) > 0.2).astype(np.float32))
+    embeds = F.relu(rnd(rs, T, B, E)).requires_grad_(True)
+    e1, e2 = rnd(rs, T, B, S), rnd(rs, T, B, S)
+    b0, s0 = rnd(rs, B, D, scale=0.3), rnd(rs, B, S)
+    outs = ro.observe(p, b0, s0, actions, embeds, nonterms, e1, e2)
+    sv = ops.rssm_observe_fwd(cu(p), b0.cuda(), s0.cuda(), actions.cuda(), nonterms.cuda(), embeds.detach().cuda(),
+                              e1.cuda(), e2.cuda())
+    got = [sv.featx[1:, :, :D], sv.prior_state, sv.prior_mean, sv.prior_std, sv.featx[1:, :, D:], sv.post_mean,
+           sv.post_std]
+    names = ["beliefs", "prior_states", "prior_means", "prior_stds", "post_states", "post_means", "post_stds"]
+    for n, g, w in zip(names, got, outs):
+        e = relerr(g, w)
+        log(f"observe T={T} B={B} {n}: {e:.2e}")
+        assert e < FTOL, n
+    # backward: random upstream gradients on every output
+    ups = [rnd(rs, *o.shape, scale=0.1) for o in outs]
+    loss = sum((o * u).sum() for o, u in zip(outs, ups))
+    loss.backward()
+    dparams = [torch.zeros_like(v).cuda() for v in p.values()]
+    dfeat = torch.cat([ups[0], ups[4]], dim=2).cuda().contiguous()
+    dembeds = torch.empty(T, B, E).cuda()
+    ops.rssm_observe_bwd(cu(p), sv, dparams, dfeat=dfeat, dprior_state=ups[1].cuda(), dpm=ups[2].cuda(),
+                         dps=ups[3].cuda(), dqm=ups[5].cuda(), dqs=ups[6].cuda(), dembeds=dembeds)
+    for (k, v), g in zip(p.items(), dparams):
+        e = l2err(g, v.grad)
+        log(f"observe bwd T={T} B={B} d{k}: {e:.2e}")
+        assert e < GTOL, k
+    e = l2err(dembeds, embeds.grad)
+    log(f"observe bwd T={T} B={B} dembeds: {e:.2e}")
+    assert e < GTOL
+
+
+@pytest.mark.parametrize("mod,L,rows", [("reward_model", 4, 333), ("actor_model", 5, 1000), ("value_model", 4, 64)])
+def test_mlp_fwd_bwd(ops, mod, L, rows):
+    A = 6
+    rs = np.random.RandomState(rows)
+    p = tparams(mod, A)
+    feat = rnd(rs, rows, 230).requires_grad_(True)
+    want = ro.mlp_head(p, feat[:, :200], feat[:, 200:], L)
+    out, hid = ops.mlp_fwd(cu(p), feat.detach().cuda())
+    assert relerr(out, want) < FTOL
+    up = rnd(rs, *want.shape)
+    (want * up).sum().backward()
+    dparams = [torch.full_like(v, 7.0).cuda() for v in p.values()]
+    dx = torch.ones(rows, 230).cuda()
+    ops.mlp_bwd(cu(p), feat.detach().cuda(), hid, up.cuda(), dparams=dparams, dx=dx, accumulate_dx=True)
+    for (k, v), g in zip(p.items(), dparams):
+        e = l2err(g, v.grad)
+        log(f"mlp {mod} d{k}: {e:.2e}")
+        assert e < GTOL
+    assert l2err(dx, feat.grad + 1) < GTOL
+    # frozen weights / detached input variants run
+    ops.mlp_bwd(cu(p), feat.detach().cuda(), hid, up.cuda(), dparams=None, dx=dx)
+    assert l2err(dx, feat.grad) < GTOL
+
+
+@pytest.mark.parametrize("Hm,N,A", [(4, 28, 6), (14, 300, 6), (2, 15, 7)])
+def test_imagine_fwd_bwd(ops, Hm, N, A):
+    rs = np.random.RandomState(Hm * 10 + N)
+    D, S = 200, 30
+    rp = tparams("transition_model", A, requires_grad=False)
+    ap = tparams("actor_model", A)
+    b0 = rnd(rs, N, D, scale=0.3).requires_grad_(True)
+    s0 = rnd(rs, N, S).requires_grad_(True)
+    ea, ep = rnd(rs, Hm, N, A), rnd(rs, Hm, N, S)
+    ib, istate, im, isd = ro.imagine(rp, ap, b0, s0, Hm + 1, ea, ep)
+    sv = ops.rssm_imagine_fwd(cu(rp), cu(ap), b0.detach().cuda(), s0.detach().cuda(), ea.cuda(), ep.cuda())
+    for n, g, w in [("beliefs", sv.featx[1:, :, :D], ib), ("states", sv.featx[1:, :, D:], istate),
+                    ("means", sv.prior_mean, im), ("stds", sv.prior_std, isd)]:
+        e = relerr(g, w)
+        log(f"imagine Hm={Hm} N={N} {n}: {e:.2e}")
+        assert e < FTOL
+    ub, us, um, usd = (rnd(rs, *x.shape, scale=0.1) for x in (ib, istate, im, isd))
+    ((ib * ub).sum() + (istate * us).sum() + (im * um).sum() + (isd * usd).sum()).backward()
+    dfeat = torch.cat([ub, us], dim=2).cuda().contiguous()
+    d_araw, dfeat0 = ops.rssm_imagine_bwd(cu(rp), sv, dfeat, dprior_mean=um.cuda(), dprior_std=usd.cuda(),
+                                          want_dfeat0=True)
+    e1, e2 = l2err(dfeat0[:, :D], b0.grad), l2err(dfeat0[:, D:], s0.grad)
+    log(f"imagine bwd Hm={Hm} N={N}: dbelief0 {e1:.2e} dstate0 {e2:.2e}")
+    assert e1 < GTOL and e2 < GTOL
+    # deferred actor backward over all steps
+    dap = [torch.zeros_like(v).cuda() for v in ap.values()]
+    x = sv.featx[:Hm].reshape(Hm * N, D + S)
+    hid = [sv.a_hidden[l] for l in range(sv.a_hidden.shape[0])]
+    ops.mlp_bwd(cu(ap), x, hid, d_araw, dparams=dap, dx=None)
+    for (k, v), g in zip(ap.items(), dap):
+        e = l2err(g, v.grad)
+        log(f"imagine bwd Hm={Hm} N={N} actor d{k}: {e:.2e}")
+        assert e < GTOL
+
+
+def test_actor_head_and_entropy(ops):
+    rs = np.random.RandomState(2)
+    rows, A, NS = 500, 6, 100
+    raw = rnd(rs, rows, 2 * A, scale=2.0)
+    raw[0, :A] = 40.0  # saturate: tanh(u) == 1 -> clamp branch, zero gradient through x
+    raw[1, :A] = -40.0
+    rawt = raw.clone().requires_grad_(True)
+    mean = 5.0 * torch.tanh(rawt[:, :A] / 5.0)
+    std = F.softplus(rawt[:, A:]) + 0.1
+    eps = rnd(rs, NS, rows, A)
+    ent = ro.tanh_normal_entropy(mean, std, eps)
+    ent.sum().backward()
+    m, s, _ = ops.actor_head_fwd(raw.cuda())
+    assert relerr(m, mean) < FTOL and relerr(s, std) < FTOL
+    out, dm, ds = ops.tanh_normal_entropy(m, s, eps.cuda(), gscale=1.0)
+    e = abs(out.item() - ent.sum().item()) / abs(ent.sum().item())
+    log(f"tanh_normal_entropy sum: {e:.2e}")
+    assert e < 1e-4
+    draw = ops.actor_head_bwd(m, s, dmean=dm, dstd=ds)
+    e = l2err(draw, rawt.grad)
+    log(f"tanh_normal_entropy d raw: {e:.2e}")
+    assert e < 2e-3  # 100-sample sums of tanh/atanh round trips: libm differences at |u| > 5
+
+
+def test_losses(ops):
+    rs = np.random.RandomState(3)
+    rows, S = 343, 30
+    pm, qm = rnd(rs, rows, S).requires_grad_(True), rnd(rs, rows, S).requires_grad_(True)
+    ps = (rnd(rs, rows, S).abs() + 0.1).requires_grad_(True)
+    qs = (rnd(rs, rows, S).abs() + 0.1).requires_grad_(True)
+    lb = torch.tensor(math.log(0.3))
+    alpha = 5 / 6
+    klp = ro.normal_kl(qm.detach(), qs.detach(), pm, ps).sum(1).mean()
+    klq = ro.normal_kl(qm, qs, pm.detach(), ps.detach()).sum(1).mean()
+    (lb.exp() * (alpha * klp + (1 - alpha) * klq)).backward()
+    out, g = ops.kl_balance(pm.detach().cuda(), ps.detach().cuda(), qm.detach().cuda(), qs.detach().cuda(), 0, alpha,
+                            lb.cuda(), 3.0, 1.0 / rows)
+    assert abs(out.item() / rows - klp.item()) < 1e-5 * abs(klp.item())
+    for gg, t in zip(g, (pm, ps, qm, qs)):
+        assert l2err(gg, t.grad) < 1e-5
+    for t in (pm, ps, qm, qs):
+        t.grad = None
+    # Dreamer free-nats variant: make a third of the rows fall under the threshold
+    with torch.no_grad():
+        qm[::3] = pm[::3]
+        qs[::3] = ps[::3]
+    kl = ro.normal_kl(qm, qs, pm, ps).sum(1)
+    fn = 3.0
+    torch.max(kl, torch.full((1,), fn)).mean().backward()
+    out, g = ops.kl_balance(pm.detach().cuda(), ps.detach().cuda(), qm.detach().cuda(), qs.detach().cuda(), 1, 0.0,
+                            None, fn, 1.0 / rows)
+    assert abs(out.item() / rows - torch.max(kl, torch.full((1,), fn)).mean().item()) < 1e-5 * fn
+    for gg, t in zip(g, (pm, ps, qm, qs)):
+        assert l2err(gg, t.grad) < 1e-5
+    # scalar nll
+    pred, tgt = rnd(rs, 777), rnd(rs, 777)
+    mask = torch.from_numpy((rs.uniform(size=777) > 0.3).astype(np.float32))
+    sums, dp = ops.scalar_nll(pred.cuda(), tgt.cuda(), mask.cuda(), 0.5)
+    assert relerr(sums, torch.stack([(0.5 * (pred - tgt) ** 2 * mask).sum(), mask.sum()])) < 1e-5
+    assert relerr(dp, (pred - tgt) * mask * 0.5) < 1e-6
+    # normal entropy
+    sd = rnd(rs, 500, 30).abs() + 0.1
+    out, dsd = ops.normal_entropy(sd.cuda(), gscale=2.0, want_grad=True)
+    want = (0.5 + 0.5 * math.log(2 * math.pi) + sd.log()).sum()
+    assert abs(out.item() - want.item()) < 1e-5 * abs(want.item())
+    assert relerr(dsd, 2.0 / sd) < 1e-6
+    # lambda return
+    Hm, N = 14, 321
+    r, v = rnd(rs, Hm, N).requires_grad_(True), rnd(rs, Hm, N).requires_grad_(True)
+    disc = 0.99 * torch.ones(Hm, N)
+    ret = ro.lambda_return(r[:-1], v[:-1], disc[:-1], v[-1], 0.95)
+    gret = -1.0 / ret.numel()
+    (gret * ret.sum()).backward()
+    returns, dr, dv, rsum = ops.lambda_return(r.detach().cuda(), v.detach().cuda(), 0.99, 0.95, gret)
+    assert relerr(returns, ret) < 1e-5
+    assert relerr(dr, r.grad) < 1e-5 and relerr(dv, v.grad) < 1e-5
+    assert abs(rsum.item() - ret.sum().item()) < 1e-4 * abs(ret.sum().item()) + 1e-3
+    # dual step
+    lbp = torch.tensor([math.log(1e-5)]).cuda()
+    m, vv = torch.zeros(1).cuda(), torch.zeros(1).cuda()
+    klsum = torch.tensor([0.2 * 100]).cuda()
+    sc = ops.dual_step(lbp, m, vv, klsum, 100, 3.0, 1e-4, 1)
+    ref = torch.tensor(math.log(1e-5), requires_grad=True)
+    opt = ro.Adam([ref], 1e-4)
+    (-ref * (0.2 - 3.0)).backward()
+    opt.step()
+    assert abs(lbp.item() - ref.item()) < 1e-6
+    assert abs(sc[0].item() - 0.2) < 1e-6 and abs(sc[2].item() - (-math.log(1e-5) * (0.2 - 3.0))) < 1e-4
+
+
+def test_clip_adam(ops):
+    rs = np.random.RandomState(4)
+    n = 100003
+    p0 = rnd(rs, n)
+    ref = p0.clone().requires_grad_(True)
+    opt = ro.Adam([ref], 3e-4)
+    p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 4):
+        g = rnd(rs, n, scale=5.0 if step == 2 else 0.01)  # step 2 exceeds max_norm=100 -> clipped
+        ref.grad = g.clone()
+        total = ro.clip_grad_norm([ref], 100.0)
+        opt.step()
+        gc = g.cuda()
+        sq = ops.grad_sqnorm(gc)
+        assert abs(math.sqrt(sq.item()) - float(total)) < 1e-5 * float(total)
+        ops.clip_adam(p, gc, m, v, sq, 100.0, 3e-4, step)
+        e = (p.cpu() - ref.detach()).abs().max().item()
+        log(f"clip_adam step {step}: max abs diff {e:.2e}")
+        assert e < 2e-7
