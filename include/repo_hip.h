@@ -267,6 +267,10 @@ int repo_scalar_nll(int64_t n, const float* pred, const float* target, const flo
 int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean,
                              const float* std, const float* eps, float gscale, float* dmean,
                              float* dstd, float* ent_sum, void* ws, size_t ws_bytes, hipStream_t stream);
+/* SampleDist.mode (models/utils.py:149-158): per row, the tanh-Normal sample with the highest
+ * log-probability among `samples` draws (first maximum, like torch.argmax); eps (samples,rows,A). */
+int repo_tanh_normal_mode(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,
+                          const float* eps, float* action, hipStream_t stream);
 /* Independent(Normal).entropy summed over n elements (dreamer.py:327-328): dstd = gscale/std. */
 int repo_normal_entropy(int64_t n, const float* std, float gscale, float* dstd, float* ent_sum,
                         void* ws, size_t ws_bytes, hipStream_t stream);

@@ -65,6 +65,12 @@ def lib():
             f"{LIB_PATH} not found: build it with `python -m repo_amd.build` "
             "(the HIP path has no CPU fallback)"
         )
+    # PyTorch-ROCm ships its own HIP runtime; it must be in the process BEFORE this library is
+    # dlopen'ed so that both share one runtime (device pointers and streams come from torch).
+    # Loading librepo_hip.so first binds it to the system runtime and every launch then fails
+    # with hipErrorNoDevice.
+    import torch  # noqa: F401
+
     L = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (ret, params) in _protos.items():

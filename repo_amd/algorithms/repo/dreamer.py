@@ -1,0 +1,519 @@
+"""Dreamer agent on the MI355X kernels.
+
+Same surface as the reference's `Dreamer` (/root/reference/algorithms/repo/dreamer.py:32):
+constructor (config, env, eval_env, logger), build_models, train_dynamics, train_actor_critic,
+train_agent, train, eval_agent, save/load_checkpoint, get/load_param_dict, plus `update(batch)`
+= one train_dynamics + one train_actor_critic.
+
+What differs is HOW an update runs.  The reference builds an autograd graph of ~2000 small ATen
+ops per update; here forward and backward are scheduled by hand over the fused HIP passes
+(repo_amd.functional / repo_amd.ops), gradients land directly in one flat buffer per optimiser
+(FlatAdam), replay frames stay uint8 on the device (normalised inside conv1's loader), and
+every logged scalar of an update is read back with ONE device->host copy instead of 11
+.item() synchronisations (dreamer.py:292-295,376-379).
+
+Data parallelism: each rank owns a slice of the batch rows; losses are scaled by the GLOBAL
+row count so that a sum all-reduce of the flat gradient buffers (RCCL over xGMI) yields the
+global-batch gradient before the global-norm clip, and every rank applies the identical
+Adam step.
+"""
+import glob
+import math
+import os
+
+import numpy as np
+import torch
+
+from ... import functional as Fn
+from ... import ops
+from ...common.buffers import SequenceReplayBuffer
+from ...common.utils import get_device, postprocess, preprocess, to_np, to_torch
+from .models.actor_critic import ActorModel, ValueModel
+from .models.decoder import ObservationModel, RewardModel
+from .models.encoder import Encoder
+from .models.rssm import TransitionModel
+from .models.utils import FlatAdam
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+def _d(ts):
+    return [t.detach() for t in ts]
+
+
+class Dreamer:
+    def __init__(self, config, env, eval_env, logger):
+        self.c = config
+        self.env = env
+        self.eval_env = eval_env
+        self.logger = logger
+        self.device = get_device()
+        if self.device.type != "cuda":
+            raise RuntimeError(
+                "repo_amd agents run on a HIP device only (call set_gpu_mode(True)); there is no CPU path"
+            )
+        self.step = 0
+        self.dp = None  # set by repo_amd.parallel.attach() for multi-GPU runs
+        self.noise_source = None  # tests inject pre-drawn noise here
+        self.build_models(config, env)
+        self.buffer = SequenceReplayBuffer(
+            config.replay_size,
+            env.observation_space.shape,
+            env.action_space.shape,
+            obs_type=np.uint8 if config.pixel_obs else np.float32,
+        )
+        self.free_nats = torch.full((1,), float(config.free_nats), device=self.device)
+        self._scal = torch.zeros(32, dtype=torch.float32, device=self.device)
+        self.last_scalars = {}
+
+    # ------------------------------------------------------------------ construction
+    def build_models(self, config, env):
+        if not config.pixel_obs:
+            raise NotImplementedError("only pixel observations are on the MI355X hot path")
+        if getattr(config, "disag_model", False) or getattr(config, "inv_dynamics", False):
+            raise NotImplementedError("disagreement / inverse-dynamics auxiliaries are out of scope (SURVEY 2.1 #10)")
+        obs_size = env.observation_space.shape
+        action_size = int(np.prod(env.action_space.shape))
+        self.action_size = action_size
+        dev = self.device
+        # same construction order as the reference (dreamer.py:57-114) => same default init under a seed
+        self.encoder = Encoder(False, obs_size, config.embedding_size, config.cnn_activation_function).to(dev)
+        self.transition_model = TransitionModel(
+            config.belief_size, config.state_size, action_size, config.hidden_size, config.embedding_size,
+            config.dense_activation_function,
+        ).to(dev)
+        self.obs_model = ObservationModel(
+            False, obs_size, config.belief_size, config.state_size, config.embedding_size,
+            config.cnn_activation_function,
+        ).to(dev)
+        self.reward_model = RewardModel(
+            config.belief_size, config.state_size, config.hidden_size, config.dense_activation_function
+        ).to(dev)
+        self.model_params = (
+            list(self.encoder.parameters())
+            + list(self.transition_model.parameters())
+            + list(self.obs_model.parameters())
+            + list(self.reward_model.parameters())
+        )
+        self.model_optimizer = FlatAdam(self.model_params, lr=config.model_lr)
+        # quirk kept: dense_activation_function lands in ActorModel's `dist` slot (dreamer.py:99-105)
+        self.actor_model = ActorModel(
+            config.belief_size, config.state_size, config.hidden_size, action_size, config.dense_activation_function
+        ).to(dev)
+        self.actor_optimizer = FlatAdam(self.actor_model.parameters(), lr=config.actor_lr)
+        self.value_model = ValueModel(
+            config.belief_size, config.state_size, config.hidden_size, config.dense_activation_function
+        ).to(dev)
+        self.value_optimizer = FlatAdam(self.value_model.parameters(), lr=config.value_lr)
+
+    def _pg(self, module):
+        """(params, grads) of a module as detached tensors / flat-gradient views, state_dict order."""
+        ps = module.plist()
+        return _d(ps), [p.grad for p in ps]
+
+    def toggle_train(self, train=True):
+        for m in (self.encoder, self.transition_model, self.obs_model, self.reward_model, self.actor_model,
+                  self.value_model):
+            m.train(train)
+
+    # ------------------------------------------------------------------ helpers
+    def _noise(self, key, shape):
+        if self.noise_source is not None:
+            t = self.noise_source[key]
+            assert tuple(t.shape) == tuple(shape), (key, t.shape, shape)
+            return t
+        return torch.randn(*shape, device=self.device)
+
+    def _global_rows(self, local_rows):
+        """Row count of the global batch (sum over data-parallel ranks)."""
+        if self.dp is None:
+            return local_rows
+        return self.dp.global_count(local_rows)
+
+    def _allreduce(self, t):
+        if self.dp is not None:
+            self.dp.all_reduce(t)
+
+    # ------------------------------------------------------------------ world model
+    def _world_model_forward(self, obs, actions, rewards, nonterms):
+        """Shared by Dreamer and RePo: encoder, observe scan, decoder+NLL, reward head.
+        Returns a dict of everything the backward needs."""
+        c = self.c
+        L, B = obs.shape[:2]
+        T = L - 1
+        rows = T * B
+        grow = self._global_rows(rows)
+        dev = self.device
+        D, S = c.belief_size, c.state_size
+        st = {"T": T, "B": B, "rows": rows, "grow": grow}
+        # frame 0's embedding is never used (embeds[1:], repo.py:41): encode frames 1..L-1 only
+        frames = obs[1:].reshape(rows, *obs.shape[2:])
+        st["frames"] = frames
+        pe, _ = self._pg(self.encoder)
+        embeds, st["enc_saved"] = Fn.encoder_fwd(pe, frames)
+        pr, _ = self._pg(self.transition_model)
+        b0 = torch.zeros(B, D, device=dev)
+        s0 = torch.zeros(B, S, device=dev)
+        sv = ops.rssm_observe_fwd(
+            pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
+            self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev,
+        )
+        st["sv"] = sv
+        feat = sv.featx[1:].reshape(rows, D + S)
+        st["feat"] = feat
+        # decoder + pixel NLL (mean over (T,B) of the per-frame sums)
+        pd, _ = self._pg(self.obs_model)
+        st["nll_sum"], st["dec_saved"] = Fn.decoder_fwd_nll(pd, feat, frames, 1.0 / grow)
+        # reward head; predicted from the next state, masked by nonterminal (repo.py:58-61)
+        pw, _ = self._pg(self.reward_model)
+        r_pred, st["rew_hid"] = ops.mlp_fwd(pw, feat)
+        st["rew_sums"], st["drew"] = ops.scalar_nll(
+            r_pred.view(-1), rewards[:-1].reshape(-1).contiguous(), nonterms[:-1].reshape(-1).contiguous(), 1.0 / grow
+        )
+        return st
+
+    def _world_model_backward(self, st, kl_grads, decoder_attached):
+        """reward head -> (decoder) -> reverse scan -> encoder; gradients into the flat model buffer."""
+        rows = st["rows"]
+        sv = st["sv"]
+        feat = st["feat"]
+        dev = self.device
+        dfeat = torch.empty(rows, feat.shape[1], device=dev)
+        pw, gw = self._pg(self.reward_model)
+        ops.mlp_bwd(pw, feat, st["rew_hid"], st["drew"].view(rows, 1), dparams=gw, dx=dfeat)
+        pd, gd = self._pg(self.obs_model)
+        Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, dfeat=dfeat if decoder_attached else None,
+                       accumulate_dfeat=True)
+        pr, gr = self._pg(self.transition_model)
+        dembeds = torch.empty(rows, self.c.embedding_size, device=dev)
+        dpm, dps, dqm, dqs = kl_grads
+        ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
+                             min_std=self.transition_model.min_std_dev)
+        pe, ge = self._pg(self.encoder)
+        Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge)
+
+    def _model_step(self):
+        self._allreduce(self.model_optimizer.grad)
+        self.model_optimizer.clip_and_step(self.c.grad_clip_norm)
+
+    def _prep_batch(self, obs, actions, rewards, nonterms):
+        obs = obs.contiguous()
+        assert obs.dtype in (torch.uint8, torch.float32), obs.dtype
+        return obs, actions.float().contiguous(), rewards.float().contiguous(), nonterms.float().contiguous()
+
+    def train_dynamics(self, obs, actions, rewards, nonterms):
+        """Dreamer world-model step (reference dreamer.py:241-302).  obs (L,B,3,64,64) float32 in
+        [-1,1] (reference convention) or uint8; returns detached (beliefs, posterior_states)."""
+        c = self.c
+        obs, actions, rewards, nonterms = self._prep_batch(obs, actions, rewards, nonterms)
+        st = self._world_model_forward(obs, actions, rewards, nonterms)
+        sv, grow = st["sv"], st["grow"]
+        kl_sum, kl_grads = ops.kl_balance(sv.prior_mean, sv.prior_std, sv.post_mean, sv.post_std, 1, 0.0, None,
+                                          float(c.free_nats), 1.0 / grow)
+        self._world_model_backward(st, kl_grads, decoder_attached=True)
+        self._model_step()
+        self._pending_model = (st["nll_sum"], st["rew_sums"], kl_sum, None, grow)
+        D = c.belief_size
+        return sv.featx[1:, :, :D], sv.featx[1:, :, D:]
+
+    # ------------------------------------------------------------------ actor critic
+    def train_actor_critic(self, beliefs, posterior_states):
+        """Imagination + actor and critic steps (reference dreamer.py:304-381).
+        beliefs (N, D), posterior_states (N, S): detached start states."""
+        c = self.c
+        dev = self.device
+        N = beliefs.shape[0]
+        Hm = c.horizon - 1
+        D, S, A = c.belief_size, c.state_size, self.action_size
+        F_ = D + S
+        gN = self._global_rows(N)
+        pr, _ = self._pg(self.transition_model)
+        pa, ga = self._pg(self.actor_model)
+        pv, gv = self._pg(self.value_model)
+        pw, _ = self._pg(self.reward_model)
+        am = self.actor_model
+        a_consts = (am._min_std, am._init_std, float(am._mean_scale))
+        # -- imagine (world model frozen, actor inputs detached)
+        sv = ops.rssm_imagine_fwd(
+            pr, pa, beliefs.contiguous(), posterior_states.contiguous(), self._noise("img_act", (Hm, N, A)),
+            self._noise("img_prior", (Hm, N, S)), self.transition_model.min_std_dev, *a_consts,
+        )
+        feats = sv.featx[1:].reshape(Hm * N, F_)
+        r_pred, r_hid = ops.mlp_fwd(pw, feats)
+        v_pred, v_hid = ops.mlp_fwd(pv, feats)
+        # -- action entropy on the (attached) imagined states: 100-sample Monte-Carlo estimate
+        raw2, a2_hid = ops.mlp_fwd(pa, feats)
+        mean2, std2, _ = ops.actor_head_fwd(raw2, *a_consts)
+        eps_ent = self._noise("entropy", (am._samples, Hm * N, A))
+        ent_sum, dmean2, dstd2 = ops.tanh_normal_entropy(mean2, std2, eps_ent, gscale=-c.action_ent_coef / (Hm * gN))
+        lat_sum, dpstd = ops.normal_entropy(sv.prior_std, gscale=-c.latent_ent_coef / (Hm * gN),
+                                            want_grad=c.latent_ent_coef != 0)
+        # -- lambda returns and the actor objective
+        gret = -1.0 / ((Hm - 1) * gN)
+        returns, dr, dv, ret_sum = ops.lambda_return(r_pred.view(Hm, N), v_pred.view(Hm, N), c.gamma, c.gae_lambda,
+                                                     gret)
+        # -- backward: heads -> entropy path -> reverse rollout -> actor trunk over all steps
+        dfeat = torch.empty(Hm * N, F_, device=dev)
+        ops.mlp_bwd(pw, feats, r_hid, dr.view(Hm * N, 1), dparams=None, dx=dfeat)
+        ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat, accumulate_dx=True)
+        draw2 = ops.actor_head_bwd(mean2, std2, dmean=dmean2, dstd=dstd2, min_std=a_consts[0], mean_scale=a_consts[2])
+        ops.mlp_bwd(pa, feats, a2_hid, draw2, dparams=ga, accumulate_w=False, dx=dfeat, accumulate_dx=True)
+        d_araw, _ = ops.rssm_imagine_bwd(pr, sv, dfeat, dprior_std=dpstd, min_std=self.transition_model.min_std_dev,
+                                         a_min_std=a_consts[0], a_mean_scale=a_consts[2])
+        x_act = sv.featx[:Hm].reshape(Hm * N, F_)
+        a_hid = [sv.a_hidden[l] for l in range(sv.a_hidden.shape[0])]
+        ops.mlp_bwd(pa, x_act, a_hid, d_araw, dparams=ga, accumulate_w=True, dx=None)
+        self._allreduce(self.actor_optimizer.grad)
+        self.actor_optimizer.clip_and_step(c.grad_clip_norm)
+        # -- critic on detached imag[:-1] against detached returns (dreamer.py:362-373).  The value
+        #    weights have not changed since v_pred was computed, so its activations are reused.
+        nv = (Hm - 1) * N
+        v_sums, dv2 = ops.scalar_nll(v_pred.view(-1)[:nv], returns.view(-1), None, 1.0 / ((Hm - 1) * gN))
+        ops.mlp_bwd(pv, feats[:nv], [h[:nv] for h in v_hid], dv2.view(nv, 1), dparams=gv, dx=None)
+        self._allreduce(self.value_optimizer.grad)
+        self.value_optimizer.clip_and_step(c.grad_clip_norm)
+        self._pending_ac = (ret_sum, ent_sum, lat_sum, v_sums, Hm, gN)
+        self._log_update()
+
+    # ------------------------------------------------------------------ logging: one D2H per update
+    def _log_update(self):
+        c = self.c
+        nll_sum, rew_sums, kl_sum, dual, grow = self._pending_model
+        ret_sum, ent_sum, lat_sum, v_sums, Hm, gN = self._pending_ac
+        parts = [nll_sum, rew_sums, kl_sum, ret_sum, ent_sum, lat_sum, v_sums, self.model_optimizer.sqnorm,
+                 self.actor_optimizer.sqnorm, self.value_optimizer.sqnorm]
+        if dual is not None:
+            parts.append(dual)
+        buf = torch.cat([p.reshape(-1) for p in parts])
+        self._allreduce_scalars(buf, n_sum=10)
+        h = buf.cpu().tolist()
+        nll, rsq, rmask, kl, ret, ent, lat, vsq, _vn, gm, ga_, gv_ = h[:12]
+        npix = 3 * 64 * 64
+        out = {}
+        out["train/obs_loss"] = nll / grow + 0.5 * LOG_2PI * npix
+        out["train/reward_loss"] = (rsq + 0.5 * LOG_2PI * rmask) / grow
+        if dual is not None:
+            kl_div, kl_loss, beta_loss, beta = h[12:16]
+            out["train/kl_loss"] = kl_loss
+            out["train/kl_div"] = kl_div
+            out["train/beta"] = beta
+            out["train/beta_loss"] = beta_loss
+        else:
+            out["train/kl_loss"] = kl / grow
+        out["train/model_loss"] = out["train/obs_loss"] + out["train/reward_loss"] + out["train/kl_loss"]
+        action_entropy = ent / (Hm * gN)
+        latent_entropy = lat / (Hm * gN)
+        out["train/actor_loss"] = (-ret / ((Hm - 1) * gN) - c.action_ent_coef * action_entropy
+                                   - c.latent_ent_coef * latent_entropy)
+        out["train/value_loss"] = vsq / ((Hm - 1) * gN) + 0.5 * LOG_2PI
+        out["train/action_entropy"] = action_entropy
+        out["train/latent_entropy"] = latent_entropy
+        self.last_scalars = out
+        self.last_grad_norms = {"model": math.sqrt(max(gm, 0.0)), "actor": math.sqrt(max(ga_, 0.0)),
+                                "value": math.sqrt(max(gv_, 0.0))}
+        for k, v in out.items():
+            self.logger.record(k, v)
+
+    def _allreduce_scalars(self, buf, n_sum):
+        """Loss sums are per-rank partial sums; gradient norms (already global) are not summed."""
+        if self.dp is not None:
+            self.dp.all_reduce_prefix(buf, 9)
+
+    # ------------------------------------------------------------------ update loop
+    def update(self, batch):
+        """One iteration of the train_agent loop body on a device batch
+        (obs (L,B,3,64,64) uint8|float32, actions (L,B,A), rewards (L,B,1), dones (L,B,1))."""
+        obs, actions, rewards, dones = batch
+        nonterms = 1.0 - dones.float()
+        beliefs, post = self.train_dynamics(obs, actions, rewards, nonterms)
+        self.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
+        return self.last_scalars
+
+    def train_agent(self):
+        c = self.c
+        B, L = c.batch_size, c.chunk_size
+        h = self.buffer.prefetch(B, L, self.device)
+        for i in range(c.train_steps):
+            batch = self.buffer.acquire(h, B, L, self.device)
+            cur = h
+            self.update(batch)
+            self.buffer.release(cur, B, L, self.device)
+            if i + 1 < c.train_steps:
+                # host gather + PCIe copy of the next batch overlap the update just enqueued
+                h = self.buffer.prefetch(B, L, self.device)
+
+    # ------------------------------------------------------------------ acting
+    def collect_seed_data(self):
+        obs = self.env.reset()
+        done = False
+        while len(self.buffer) < self.c.prefill or not done:
+            action = self.env.action_space.sample()
+            next_obs, reward, done, _ = self.env.step(action)
+            self.buffer.push(obs, action, reward, done)
+            obs = next_obs if not done else self.env.reset()
+
+    def init_latent_and_action(self):
+        belief = torch.zeros(1, self.c.belief_size, device=self.device)
+        posterior_state = torch.zeros(1, self.c.state_size, device=self.device)
+        action = torch.zeros(1, int(np.prod(self.env.action_space.shape)), device=self.device)
+        return belief, posterior_state, action
+
+    @torch.no_grad()
+    def update_latent_and_select_action(self, belief, posterior_state, action, obs, explore=False):
+        """One filtering step + policy (reference dreamer.py:175-196)."""
+        embed = self.encoder(obs)
+        outs = self.transition_model.observe(belief, posterior_state, action.unsqueeze(0), embed.unsqueeze(0))
+        belief, posterior_state = outs[0].squeeze(0), outs[4].squeeze(0)
+        action = self.actor_model.get_action(belief, posterior_state, det=not explore)
+        if explore and self.c.action_noise > 0:
+            action = torch.clamp(action + torch.randn_like(action) * self.c.action_noise, -1, 1)
+        return belief, posterior_state, action
+
+    def train(self):
+        if self.c.load_checkpoint:
+            self.load_checkpoint()
+        if len(self.buffer) == 0:
+            self.collect_seed_data()
+        belief, posterior_state, action_tensor = self.init_latent_and_action()
+        obs = self.env.reset()
+        episode_reward = 0
+        episode_success = 0
+        while self.step < self.c.num_steps:
+            obs_tensor = to_torch(preprocess(obs[None]))
+            belief, posterior_state, action_tensor = self.update_latent_and_select_action(
+                belief, posterior_state, action_tensor, obs_tensor, True
+            )
+            action = to_np(action_tensor)[0]
+            next_obs, reward, done, info = self.env.step(action)
+            self.buffer.push(obs, action, reward, done)
+            obs = next_obs
+            episode_reward += reward
+            episode_success += info.get("success", 0)
+            if done:
+                self.logger.record("train/return", episode_reward)
+                self.logger.record("train/success", float(episode_success > 0))
+                belief, posterior_state, action_tensor = self.init_latent_and_action()
+                obs = self.env.reset()
+                episode_reward = 0
+                episode_success = 0
+            if self.step % self.c.train_every == 0:
+                self.train_agent()
+            if self.step % self.c.eval_every == 0:
+                self.eval_agent()
+            if self.step % self.c.checkpoint_every == 0:
+                self.save_checkpoint()
+            if self.step % self.c.log_every == 0:
+                self.logger.record("train/step", self.step)
+                self.logger.dump(step=self.step)
+            self.step += 1
+
+    def eval_agent(self):
+        self.toggle_train(False)
+        belief, posterior_state, action_tensor = self.init_latent_and_action()
+        obs = self.eval_env.reset()
+        done = False
+        episode_reward = 0
+        episode_success = 0
+        frames = []
+        with torch.no_grad():
+            while not done:
+                obs_tensor = to_torch(preprocess(obs[None]))
+                belief, posterior_state, action_tensor = self.update_latent_and_select_action(
+                    belief, posterior_state, action_tensor, obs_tensor, False
+                )
+                action = to_np(action_tensor)[0]
+                next_obs, reward, done, info = self.eval_env.step(action)
+                if self.c.pixel_obs:
+                    obs_hat = postprocess(to_np(self.obs_model(belief, posterior_state)))[0]
+                    frames.append([obs, obs_hat])
+                obs = next_obs
+                episode_reward += reward
+                episode_success += info.get("success", 0)
+        self.logger.record("test/return", episode_reward)
+        self.logger.record("test/success", float(episode_success > 0))
+        if self.c.pixel_obs and frames:
+            video = np.stack(frames).transpose(1, 0, 2, 3, 4)
+            try:
+                self.logger.record("test/video", video, exclude="stdout")
+            except TypeError:
+                self.logger.record("test/video", video)
+        self.toggle_train(True)
+
+    # ------------------------------------------------------------------ checkpoints (reference key layout)
+    def save_checkpoint(self):
+        torch.save(self.get_param_dict(), os.path.join(self.logger.dir, "models.pt"))
+        if self.c.save_buffer:
+            self.buffer.save(os.path.join(self.logger.dir, "buffer.npz"))
+
+    def get_param_dict(self):
+        def sd(m):
+            return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+        return {
+            "step": self.step,
+            "encoder": sd(self.encoder),
+            "transition_model": sd(self.transition_model),
+            "obs_model": sd(self.obs_model),
+            "reward_model": sd(self.reward_model),
+            "actor_model": sd(self.actor_model),
+            "value_model": sd(self.value_model),
+            "model_optimizer": self.model_optimizer.state_dict(),
+            "actor_optimizer": self.actor_optimizer.state_dict(),
+            "value_optimizer": self.value_optimizer.state_dict(),
+        }
+
+    def load_checkpoint(self, ckpt_dir=None):
+        if ckpt_dir is None:
+            ckpt_dir = self.logger.dir
+        buffer_path = os.path.join(ckpt_dir, "buffer.npz")
+        if os.path.exists(buffer_path):
+            self.buffer.load(buffer_path)
+            print(f"Loaded buffer from {buffer_path}")
+        elif self.c.load_offline:
+            self.load_offline_data()
+        params_path = os.path.join(ckpt_dir, "models.pt")
+        if os.path.exists(params_path):
+            params = torch.load(params_path, map_location=self.device, weights_only=False)
+            self.load_param_dict(params)
+            print(f"Loaded parameters from {params_path}")
+
+    def _load_module(self, module, sd):
+        """copy_ into the existing (flat-buffer backed) parameters; never rebinds storage."""
+        own = module.state_dict()
+        assert set(own.keys()) == set(sd.keys()), (sorted(own.keys()), sorted(sd.keys()))
+        with torch.no_grad():
+            for k, v in own.items():
+                v.copy_(sd[k].to(v.device))
+
+    def load_param_dict(self, params):
+        self.step = params["step"]
+        for name in ("encoder", "transition_model", "obs_model", "reward_model", "actor_model", "value_model"):
+            self._load_module(getattr(self, name), params[name])
+        self.model_optimizer.load_state_dict(params["model_optimizer"])
+        self.actor_optimizer.load_state_dict(params["actor_optimizer"])
+        self.value_optimizer.load_state_dict(params["value_optimizer"])
+
+    def load_offline_data(self):
+        paths = list(glob.glob(os.path.join(self.c.offline_dir, "buffer*.npz")))
+        keys = ["observations", "actions", "rewards", "dones"]
+        buffers = {k: [] for k in keys}
+        for path in paths:
+            with np.load(path) as buf:
+                data = {k: buf[k] for k in keys}
+                pos, full = int(buf["pos"]), bool(buf["full"])
+            if full:
+                data = {k: np.concatenate((v[pos:], v[:pos])) for k, v in data.items()}
+            else:
+                data = {k: v[:pos] for k, v in data.items()}
+            size = min(len(data["observations"]), self.c.offline_truncate_size)
+            data = {k: v[:size] for k, v in data.items()}
+            data["dones"][-1, :] = 1
+            for k in keys:
+                buffers[k].append(data[k])
+            print(f"Loaded buffer from {path}")
+        merged = {k: np.concatenate(v) for k, v in buffers.items()}
+        for k, v in merged.items():
+            setattr(self.buffer, k, v)
+        self.buffer.capacity = len(merged["observations"])
+        self.buffer.pos = 0
+        self.buffer.full = True

@@ -1,0 +1,8 @@
+from .actor_critic import ActorModel, ValueModel
+from .decoder import ObservationModel, RewardModel, VisualObservationModel
+from .encoder import Encoder, VisualEncoder
+from .rssm import TransitionModel
+from .utils import FlatAdam, bottle
+
+__all__ = ["ActorModel", "ValueModel", "ObservationModel", "RewardModel", "VisualObservationModel", "Encoder",
+           "VisualEncoder", "TransitionModel", "FlatAdam", "bottle"]

@@ -1,0 +1,102 @@
+"""bottle + the flat-buffer Adam that replaces torch.optim.Adam / clip_grad_norm_.
+
+bottle: /root/reference/algorithms/repo/models/utils.py:9-16.
+FlatAdam: the reference builds Adam(list_of_params, lr) (dreamer.py:96,106,114; repo.py:23) and
+calls zero_grad / clip_grad_norm_ / step (repo.py:87-90).  Here all parameters of a group live
+in ONE contiguous device buffer (each nn.Parameter is a view into it, as is its .grad), so the
+global-norm clip and the Adam update are two streaming kernels over the flat buffers, and a
+data-parallel all-reduce is one collective.  state_dict()/load_state_dict() keep
+torch.optim.Adam's layout so reference checkpoints round-trip.
+"""
+import torch
+
+from .... import ops
+
+
+def bottle(f, xs):
+    """Apply f to (time*batch, ...) views of (time, batch, ...) tensors and fold back."""
+    horizon, batch_size = xs[0].shape[:2]
+    ys = f(*(x.reshape(horizon * batch_size, *x.shape[2:]) for x in xs))
+    if isinstance(ys, tuple):
+        return tuple(y.reshape(horizon, batch_size, *y.shape[1:]) for y in ys)
+    return ys.reshape(horizon, batch_size, *ys.shape[1:])
+
+
+class FlatAdam:
+    """Adam over a flat parameter buffer with fused global-norm clipping."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.params = list(params)
+        assert self.params, "FlatAdam needs at least one parameter"
+        self.lr, self.betas, self.eps = float(lr), tuple(betas), float(eps)
+        self.step_count = 0
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        # 16-byte aligned offsets so every view can be read with 128-bit loads
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append(off)
+            off += (n + 3) // 4 * 4
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gviews = []
+        with torch.no_grad():
+            for p, o, n in zip(self.params, self.offsets, sizes):
+                self.flat[o : o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o : o + n].view(p.shape)
+                gv = self.grad[o : o + n].view(p.shape)
+                p.grad = gv
+                self.gviews.append(gv)
+
+    # -- reference-style surface -----------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
+
+    def clip_and_step(self, max_norm):
+        """clip_grad_norm_(params, max_norm) + step() (repo.py:89-90).  The squared global
+        norm stays on the device in self.sqnorm (read it after the update's single sync)."""
+        self.step_count += 1
+        ops.grad_sqnorm(self.grad, out=self.sqnorm)
+        ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.sqnorm, max_norm, self.lr,
+                      self.step_count, self.betas, self.eps)
+
+    def step(self):
+        self.step_count += 1
+        ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, None, 0.0, self.lr, self.step_count,
+                      self.betas, self.eps)
+
+    # -- torch.optim.Adam-compatible checkpoint layout -------------------------------------
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                n = p.numel()
+                state[i] = {
+                    "step": torch.tensor(float(self.step_count)),
+                    "exp_avg": self.exp_avg[o : o + n].view(p.shape).clone(),
+                    "exp_avg_sq": self.exp_avg_sq[o : o + n].view(p.shape).clone(),
+                }
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])
+        steps = set()
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                st = sd["state"].get(i)
+                if st is None:
+                    continue
+                n = p.numel()
+                self.exp_avg[o : o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o : o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+        assert len(steps) <= 1, "per-parameter step counts differ; not an Adam state this optimiser can hold"
+        self.step_count = steps.pop() if steps else 0

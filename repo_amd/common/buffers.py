@@ -1,0 +1,176 @@
+"""Sequence replay buffer: NumPy ring on the host + pinned staging for async H2D.
+
+Ring semantics follow the reference's SequenceReplayBuffer
+(/root/reference/common/buffers.py:128-202): flat arrays, `push` advances a write head that
+wraps (:146-154); `sample(B, L)` draws B start indices with np.random.choice(len - L),
+builds a (B, L) index matrix, transposes it to time-major, rotates by the write head once
+the ring is full so a sequence never straddles the head (:156-166); save/load as .npz of the
+instance dict, marking the last stored transition done on load (:193-202).
+
+MI355X addition: `sample_to_device` gathers straight into one of
+two page-locked staging slots and issues the copies on a side HIP stream
+(hipMemcpyAsync under torch's non_blocking copy), so the 30.7 MB uint8 batch of update k+1
+crosses PCIe while update k computes.  Frames stay uint8 on the device; normalisation is
+fused into the first convolution's loader.
+"""
+import numpy as np
+import torch
+
+
+class SequenceReplayBuffer:
+    def __init__(self, capacity, obs_shape, act_shape, obs_type=np.float32, act_type=np.float32):
+        self.capacity = capacity
+        self.observations = np.zeros((self.capacity,) + tuple(obs_shape), dtype=obs_type)
+        self.actions = np.zeros((self.capacity,) + tuple(act_shape), dtype=act_type)
+        self.rewards = np.zeros((self.capacity, 1), dtype=np.float32)
+        self.dones = np.zeros((self.capacity, 1), dtype=np.float32)
+        self.pos = 0
+        self.full = False
+
+    _DATA_KEYS = ("capacity", "observations", "actions", "rewards", "dones", "pos", "full")
+
+    def __len__(self):
+        return self.capacity if self.full else self.pos
+
+    def push(self, obs, act, rew, done):
+        self.observations[self.pos] = np.array(obs).copy()
+        self.actions[self.pos] = np.array(act).copy()
+        self.rewards[self.pos] = np.array(rew).copy()
+        self.dones[self.pos] = np.array(done).copy()
+        self.pos += 1
+        if self.pos == self.capacity:
+            self.pos = 0
+            self.full = True
+
+    def _sample_inds(self, batch_size, seq_len):
+        start_inds = np.random.choice(len(self) - seq_len, size=batch_size)
+        batch_inds = start_inds[None, :] + np.arange(seq_len)[:, None]  # (L, B): already time-major
+        batch_inds = batch_inds.reshape(-1)
+        if self.full:
+            batch_inds = (batch_inds + self.pos) % len(self)
+        return batch_inds
+
+    def sample(self, batch_size, seq_len):
+        """-> (obs, act, rew, done), each (seq_len, batch_size, ...), host arrays."""
+        inds = self._sample_inds(batch_size, seq_len)
+        batch = self._get_samples(inds)
+        return tuple(d.reshape(seq_len, batch_size, *d.shape[1:]) for d in batch)
+
+    def iterate(self, batch_size, seq_len):
+        all_start = np.arange(0, len(self) - seq_len, seq_len)
+        if self.full:
+            all_start = (all_start + self.pos) % len(self)
+        np.random.shuffle(all_start)
+        for i in range(0, len(all_start) - batch_size, batch_size):
+            starts = all_start[i : i + batch_size]
+            inds = (starts[None, :] + np.arange(seq_len)[:, None]).reshape(-1)
+            if self.full:
+                inds = (inds + self.pos) % len(self)
+            batch = self._get_samples(inds)
+            yield [d.reshape(seq_len, batch_size, *d.shape[1:]) for d in batch]
+
+    def _get_samples(self, batch_inds):
+        return (
+            self.observations[batch_inds],
+            self.actions[batch_inds],
+            self.rewards[batch_inds],
+            self.dones[batch_inds],
+        )
+
+    def save(self, path):
+        np.savez(path, **{k: getattr(self, k) for k in self._DATA_KEYS})
+
+    def load(self, path):
+        with np.load(path) as buffer:
+            for key in self._DATA_KEYS:
+                setattr(self, key, buffer[key])
+        self.capacity = int(self.capacity)
+        self.pos = int(self.pos)
+        self.full = bool(self.full)
+        if self.pos > 0 or self.full:
+            self.dones[self.pos - 1] = 1
+
+    # ------------------------------------------------------------------ device staging
+    def _staging(self, batch_size, seq_len, device):
+        key = (batch_size, seq_len, str(device))
+        st = getattr(self, "_stage", None)
+        if st is None or st["key"] != key:
+            pin = device.type == "cuda"
+
+            def host(shape, dtype):
+                t = torch.empty(shape, dtype=dtype)
+                return t.pin_memory() if pin else t
+
+            n = seq_len * batch_size
+            slots = []
+            for _ in range(2):
+                h = (
+                    host((n,) + self.observations.shape[1:], torch.from_numpy(self.observations[:0]).dtype),
+                    host((n,) + self.actions.shape[1:], torch.float32),
+                    host((n, 1), torch.float32),
+                    host((n, 1), torch.float32),
+                )
+                d = tuple(torch.empty(t.shape, dtype=t.dtype, device=device) for t in h)
+                slots.append({"host": h, "dev": d, "event": None})
+            st = {"key": key, "slots": slots, "next": 0,
+                  "stream": torch.cuda.Stream(device=device) if pin else None}
+            self._stage = st
+        return st
+
+    def prefetch(self, batch_size, seq_len, device):
+        """Sample a batch on the host into the next pinned slot and start its host->device
+        copy on the side stream.  Returns a handle for acquire()/release().  Call it right
+        AFTER enqueuing update k so the gather and the PCIe copy of batch k+1 overlap it."""
+        st = self._staging(batch_size, seq_len, device)
+        idx = st["next"]
+        st["next"] ^= 1
+        slot = st["slots"][idx]
+        inds = self._sample_inds(batch_size, seq_len)
+        if slot["event"] is not None:
+            slot["event"].synchronize()  # previous copy out of this pinned slot has finished
+        srcs = (self.observations, self.actions, self.rewards, self.dones)
+        for h, src in zip(slot["host"], srcs):
+            np.take(src, inds, axis=0, out=h.numpy())
+        if st["stream"] is not None:
+            consumed = slot.get("consumed")
+            if consumed is not None:
+                st["stream"].wait_event(consumed)  # the update that last read this device slot
+            else:
+                st["stream"].wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(st["stream"]):
+                for h, d in zip(slot["host"], slot["dev"]):
+                    d.copy_(h, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(st["stream"])
+            slot["event"] = ev
+        else:
+            for h, d in zip(slot["host"], slot["dev"]):
+                d.copy_(h)
+        return idx
+
+    def acquire(self, handle, batch_size, seq_len, device):
+        """Make the current stream wait for the slot's copy; returns the device tensors
+        (obs uint8 (L,B,C,H,W), actions (L,B,A), rewards (L,B,1), dones (L,B,1))."""
+        st = self._staging(batch_size, seq_len, device)
+        slot = st["slots"][handle]
+        if slot["event"] is not None and st["stream"] is not None:
+            torch.cuda.current_stream(device).wait_event(slot["event"])
+        return tuple(d.view(seq_len, batch_size, *d.shape[1:]) for d in slot["dev"])
+
+    def release(self, handle, batch_size, seq_len, device):
+        """Record that everything enqueued so far on the current stream has consumed the slot."""
+        st = self._staging(batch_size, seq_len, device)
+        if st["stream"] is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            st["slots"][handle]["consumed"] = ev
+
+    def sample_to_device(self, batch_size, seq_len, device):
+        """prefetch + acquire in one call (no overlap; for simple callers and tests)."""
+        h = self.prefetch(batch_size, seq_len, device)
+        return self.acquire(h, batch_size, seq_len, device)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_stage", None)
+        return d

@@ -226,6 +226,38 @@ __global__ __launch_bounds__(256) void lambda_return_kernel(int Hm, int N, const
   if (threadIdx.x == 0) parts[blockIdx.x] = s;
 }
 
+
+// ------------------------------------------------------------------ SampleDist.mode (models/utils.py:149-158)
+// action[row] = the sample with the highest log-probability among NS draws; eps (NS, rows, A).
+__global__ void tanh_normal_mode_kernel(int rows, int A, int NS, const float* __restrict__ mean,
+                                        const float* __restrict__ stdv, const float* __restrict__ eps,
+                                        float* __restrict__ action) {
+  const float kClamp = 0.99999994f;
+  const float kLog2 = 0.69314718055994531f;
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+    float best = -INFINITY;
+    int bi = 0;
+    for (int s = 0; s < NS; ++s) {
+      float lp = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float mu = mean[(size_t)row * A + a], sd = stdv[(size_t)row * A + a];
+        const float y = tanhf(fmaf(sd, eps[((size_t)s * rows + row) * A + a], mu));
+        const float x = atanhf(fminf(fmaxf(y, -kClamp), kClamp));
+        const float d = (x - mu) / sd;
+        lp += -0.5f * d * d - logf(sd) - 0.5f * kLog2Pi - 2.f * (kLog2 - x - softplus(-2.f * x));
+      }
+      if (lp > best) {  // first maximum wins, like torch.argmax
+        best = lp;
+        bi = s;
+      }
+    }
+    for (int a = 0; a < A; ++a) {
+      const float mu = mean[(size_t)row * A + a], sd = stdv[(size_t)row * A + a];
+      action[(size_t)row * A + a] = tanhf(fmaf(sd, eps[((size_t)bi * rows + row) * A + a], mu));
+    }
+  }
+}
+
 static inline int red_blocks(long n, int per_block) {
   long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -315,4 +347,15 @@ extern "C" int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, c
                      lambda_, gret, returns, drewards, dvalues, (float*)ws);
   REPO_CHECK_LAUNCH();
   return final_sum((const float*)ws, blocks, 1, ret_sum, stream);
+}
+
+extern "C" int repo_tanh_normal_mode(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,
+                                     const float* eps, float* action, hipStream_t stream) {
+  REPO_REQUIRE(rows > 0 && A > 0 && samples > 0 && rows * A * samples < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(mean && std && eps && action, REPO_E_BADARG);
+  const int blocks = (int)((rows + 63) / 64 > 1024 ? 1024 : (rows + 63) / 64);
+  hipLaunchKernelGGL(tanh_normal_mode_kernel, dim3(blocks), dim3(64), 0, stream, (int)rows, (int)A, (int)samples, mean,
+                     std, eps, action);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
 }

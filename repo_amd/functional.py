@@ -1,0 +1,86 @@
+"""Multi-kernel building blocks shared by the nn.Module wrappers and the agents' hand-scheduled
+update: conv encoder, transposed-conv decoder (+ fused pixel NLL) and their backward passes,
+expressed over repo_amd.ops (the C ABI).  Parameter lists are in the reference modules'
+state_dict order; gradients are written in place into caller-provided tensors (views of the
+flat gradient buffer), so no autograd graph and no extra accumulation pass are involved.
+"""
+import torch
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- encoder
+def encoder_fwd(p, obs):
+    """VisualEncoder.forward (models/encoder.py:34-41).  obs (n,3,64,64) uint8 or float32.
+    p = [conv1.w, conv1.b, ..., conv4.w, conv4.b].  Returns (embeds (n,1024), saved)."""
+    h1 = ops.conv_down(ops.ENC1, obs, p[0], p[1], epi=ops.EPI_RELU)
+    h2 = ops.conv_down(ops.ENC2, h1, p[2], p[3], epi=ops.EPI_RELU)
+    h3 = ops.conv_down(ops.ENC3, h2, p[4], p[5], epi=ops.EPI_RELU)
+    h4 = ops.conv_down(ops.ENC4, h3, p[6], p[7], epi=ops.EPI_RELU)
+    return h4.view(-1, 1024), (h1, h2, h3, h4)
+
+
+def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False):
+    """Gradients of all eight encoder tensors into g (same order as p)."""
+    h1, h2, h3, h4 = saved
+    n = h4.shape[0]
+    d4 = ops.relu_mask(dembeds.reshape(n, 256, 2, 2).contiguous(), h4)
+    ops.conv_wgrad(ops.ENC4, d4, h3, dw=g[6], db=g[7], accumulate=accumulate)
+    d3 = ops.conv_up(ops.ENC4, d4, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h3)
+    ops.conv_wgrad(ops.ENC3, d3, h2, dw=g[4], db=g[5], accumulate=accumulate)
+    d2 = ops.conv_up(ops.ENC3, d3, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h2)
+    ops.conv_wgrad(ops.ENC2, d2, h1, dw=g[2], db=g[3], accumulate=accumulate)
+    d1 = ops.conv_up(ops.ENC2, d2, p[2], None, epi=ops.EPI_MUL_DRELU, aux=h1)
+    ops.conv_wgrad(ops.ENC1, d1, obs, dw=g[0], db=g[1], accumulate=accumulate)
+
+
+# ----------------------------------------------------------------------------- decoder
+def decoder_trunk_fwd(p, feat):
+    """fc1 + the first three transposed convolutions (models/decoder.py:41-46).
+    feat (rows, 230) = [belief|state]; p = [fc1.w, fc1.b, conv1.w, conv1.b, ..., conv4.w, conv4.b]."""
+    rows = feat.shape[0]
+    h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
+    w1 = p[2].view(p[2].shape[0], -1)  # (1024, 128*25): 1x1 -> 5x5 transposed conv is a GEMM
+    h1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_RELU).view(rows, 128, 5, 5)
+    h2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_RELU)
+    h3 = ops.conv_up(ops.DEC3, h2, p[6], p[7], epi=ops.EPI_RELU)
+    return h0, h1, h2, h3
+
+
+def decoder_fwd(p, feat):
+    """VisualObservationModel.forward -> (recon (rows,3,64,64), saved)."""
+    h0, h1, h2, h3 = decoder_trunk_fwd(p, feat)
+    recon = ops.conv_up(ops.DEC4, h3, p[8], p[9], epi=ops.EPI_NONE)
+    return recon, (h0, h1, h2, h3)
+
+
+def decoder_fwd_nll(p, feat, target, grad_scale):
+    """Decoder forward fused with the unit-variance pixel NLL (repo.py:46-53).
+    Returns (sum 0.5*(recon-target)^2 (1,), saved incl. d loss/d recon * grad_scale)."""
+    h0, h1, h2, h3 = decoder_trunk_fwd(p, feat)
+    loss_sum, dpre4, _ = ops.decoder_out_nll(h3, p[8], p[9], target, grad_scale)
+    return loss_sum, (h0, h1, h2, h3, dpre4)
+
+
+def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False):
+    """Backward from d recon (= saved[4]) to all ten decoder tensors (into g) and, if dfeat is
+    given (Dreamer's attached decoder, dreamer.py:262), to the [belief|state] input."""
+    h0, h1, h2, h3, d4 = saved
+    rows = feat.shape[0]
+    ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
+    ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+    d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
+    ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
+    ops.channel_sum(d3, out=g[7], accumulate=accumulate)
+    d2 = ops.conv_down(ops.DEC3, d3, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h2)
+    ops.conv_wgrad(ops.DEC2, h1, d2, dw=g[4], db=None, accumulate=accumulate, want_bias=False)
+    ops.channel_sum(d2, out=g[5], accumulate=accumulate)
+    d1 = ops.conv_down(ops.DEC2, d2, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h1)
+    d1f = d1.view(rows, 128 * 25)
+    w1 = p[2].view(p[2].shape[0], -1)
+    ops.gemm_wgrad(h0, d1f, dW=g[2].view(w1.shape), db=None, accumulate=accumulate, want_bias=False)
+    ops.channel_sum(d1.view(rows, 128, 25), out=g[3], accumulate=accumulate)
+    dh0 = ops.gemm(d1f, w1, transb=True)
+    ops.gemm_wgrad(dh0, feat, dW=g[0], db=g[1], accumulate=accumulate)
+    if dfeat is not None:
+        ops.gemm(dh0, p[0], out=dfeat, accumulate=accumulate_dfeat)

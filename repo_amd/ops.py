@@ -465,6 +465,17 @@ def tanh_normal_entropy(mean, std, eps, gscale=0.0, want_grads=True):
     return out, dmean, dstd
 
 
+def tanh_normal_mode(mean, std, eps):
+    rows, A = mean.shape
+    action = torch.empty_like(mean)
+    check(
+        lib().repo_tanh_normal_mode(rows, A, eps.shape[0], _ptr(_f32c(mean)), _ptr(_f32c(std)), _ptr(_f32c(eps)),
+                                    _ptr(action), _stream()),
+        "repo_tanh_normal_mode",
+    )
+    return action
+
+
 def normal_entropy(std, gscale=0.0, want_grad=False):
     dev = std.device
     dstd = torch.empty_like(std) if want_grad else None
