@@ -54,19 +54,28 @@ struct ConvDownOp {
   const float* aux;
   float* out;
   int nimg, epi;
+  typedef int AM;
+  typedef int AK;
+  typedef int BN;
+  typedef int BK;
   __device__ void init(int) {}
   __device__ int M() const { return G::CS; }
   __device__ int N() const { return nimg * G::PS; }
   __device__ int kbeg() const { return 0; }
   __device__ int kend() const { return G::CB * G::KK; }
-  __device__ float a(int m, int k) const { return w[m * (G::CB * G::KK) + k]; }
-  __device__ float b(int k, int n) const {
+  __device__ AM a_m(int m) const { return m * (G::CB * G::KK); }
+  __device__ AK a_k(int k) const { return k; }
+  __device__ float a(const AM& m, const AK& k) const { return w[m + k]; }
+  // big[img][cb][2sy+ky][2sx+kx] = big[ nOff(img,sy,sx) + kOff(cb,ky,kx) ]
+  __device__ BN b_n(int n) const {
     const int img = n / G::PS, p = n % G::PS;
-    const int sy = p / G::WS, sx = p % G::WS;
-    const int cb = k / G::KK, r = k % G::KK;
-    const int ky = r / G::KS, kx = r % G::KS;
-    return load_as_float(big, ((img * G::CB + cb) * G::HB + 2 * sy + ky) * G::WB + 2 * sx + kx);
+    return (img * G::CB * G::HB + 2 * (p / G::WS)) * G::WB + 2 * (p % G::WS);
   }
+  __device__ BK b_k(int k) const {
+    const int cb = k / G::KK, r = k % G::KK;
+    return cb * G::PB + (r / G::KS) * G::WB + r % G::KS;
+  }
+  __device__ float b(const BK& k, const BN& n) const { return load_as_float(big, n + k); }
   __device__ void store(int m, int n, float v) {
     const int img = n / G::PS, p = n % G::PS;
     const int o = (img * G::CS + m) * G::PS + p;
@@ -88,23 +97,49 @@ struct ConvUpOp {
   const float* aux;
   float* out;
   int nimg, epi;
+  typedef int AM;
+  typedef int AK;
+  struct BN {
+    int off;
+    unsigned mask;  // bits 0..3: tap jy in range for this y; bits 4..7: tap jx in range for this x
+  };
+  struct BK {
+    int off;
+    int sh;  // jy | (4 + jx) << 8
+  };
   __device__ void init(int) {}
   __device__ int M() const { return G::CB; }
   __device__ int N() const { return nimg * NY * NX; }
   __device__ int kbeg() const { return 0; }
   __device__ int kend() const { return G::CS * JJ; }
-  __device__ float a(int m, int k) const {
+  // w[cs][cb][PY+2jy][PX+2jx] = w[ m*KK + kOff(cs,jy,jx) ]
+  __device__ AM a_m(int m) const { return m * G::KK; }
+  __device__ AK a_k(int k) const {
     const int cs = k / JJ, r = k % JJ;
-    const int jy = r / JX, jx = r % JX;
-    return w[((cs * G::CB + m) * G::KS + PY + 2 * jy) * G::KS + PX + 2 * jx];
+    return cs * (G::CB * G::KK) + (PY + 2 * (r / JX)) * G::KS + PX + 2 * (r % JX);
   }
-  __device__ float b(int k, int n) const {
+  __device__ float a(const AM& m, const AK& k) const { return w[m + k]; }
+  // small[img][cs][y-jy][x-jx] = small[ nOff(img,y,x) + kOff(cs,jy,jx) ] where the tap exists
+  __device__ BN b_n(int n) const {
     const int img = n / (NY * NX), q = n % (NY * NX);
     const int y = q / NX, x = q % NX;
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mask |= ((y - j >= 0 && y - j < G::HS) ? 1u : 0u) << j;
+      mask |= ((x - j >= 0 && x - j < G::WS) ? 1u : 0u) << (4 + j);
+    }
+    return BN{(img * G::CS * G::HS + y) * G::WS + x, mask};
+  }
+  __device__ BK b_k(int k) const {
     const int cs = k / JJ, r = k % JJ;
-    const int iy = y - r / JX, ix = x - r % JX;
-    if (iy < 0 || iy >= G::HS || ix < 0 || ix >= G::WS) return 0.f;
-    return small[((img * G::CS + cs) * G::HS + iy) * G::WS + ix];
+    const int jy = r / JX, jx = r % JX;
+    return BK{cs * G::PS - jy * G::WS - jx, jy | ((4 + jx) << 8)};
+  }
+  __device__ float b(const BK& k, const BN& n) const {
+    const bool ok = ((n.mask >> (k.sh & 0xff)) & (n.mask >> (k.sh >> 8)) & 1u) != 0;
+    const float v = small[ok ? n.off + k.off : 0];
+    return ok ? v : 0.f;
   }
   __device__ void store(int m, int n, float v) {
     const int img = n / (NY * NX), q = n % (NY * NX);
@@ -135,25 +170,62 @@ struct ConvUpMergedOp {
   float grad_scale;
   float lsum;
 
+  struct AM {
+    int off;
+    int py, px;
+  };
+  struct AK {
+    int off;
+    int jy2, jx2;  // 2*jy, 2*jx
+  };
+  struct BN {
+    int off;
+    unsigned mask;
+  };
+  struct BK {
+    int off;
+    int sh;
+  };
   __device__ void init(int) { lsum = 0.f; }
   __device__ int M() const { return 4 * G::CB; }
   __device__ int N() const { return nimg * NY * NX; }
   __device__ int kbeg() const { return 0; }
   __device__ int kend() const { return G::CS * JJ; }
-  __device__ float a(int m, int k) const {
+  __device__ AM a_m(int m) const {
     const int cls = m / G::CB, cb = m % G::CB;
-    const int cs = k / JJ, r = k % JJ;
-    const int ky = (cls >> 1) + 2 * (r / J), kx = (cls & 1) + 2 * (r % J);
-    if (ky >= G::KS || kx >= G::KS) return 0.f;
-    return w[((cs * G::CB + cb) * G::KS + ky) * G::KS + kx];
+    const int py = cls >> 1, px = cls & 1;
+    return AM{cb * G::KK + py * G::KS + px, py, px};
   }
-  __device__ float b(int k, int n) const {
+  __device__ AK a_k(int k) const {
+    const int cs = k / JJ, r = k % JJ;
+    const int jy2 = 2 * (r / J), jx2 = 2 * (r % J);
+    return AK{cs * (G::CB * G::KK) + jy2 * G::KS + jx2, jy2, jx2};
+  }
+  __device__ float a(const AM& m, const AK& k) const {
+    const bool ok = (m.py + k.jy2 < G::KS) && (m.px + k.jx2 < G::KS);
+    const float v = w[ok ? m.off + k.off : 0];
+    return ok ? v : 0.f;
+  }
+  __device__ BN b_n(int n) const {
     const int img = n / (NY * NX), q = n % (NY * NX);
     const int y = q / NX, x = q % NX;
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mask |= ((y - j >= 0 && y - j < G::HS) ? 1u : 0u) << j;
+      mask |= ((x - j >= 0 && x - j < G::WS) ? 1u : 0u) << (4 + j);
+    }
+    return BN{(img * G::CS * G::HS + y) * G::WS + x, mask};
+  }
+  __device__ BK b_k(int k) const {
     const int cs = k / JJ, r = k % JJ;
-    const int iy = y - r / J, ix = x - r % J;
-    if (iy < 0 || iy >= G::HS || ix < 0 || ix >= G::WS) return 0.f;
-    return small[((img * G::CS + cs) * G::HS + iy) * G::WS + ix];
+    const int jy = r / J, jx = r % J;
+    return BK{cs * G::PS - jy * G::WS - jx, jy | ((4 + jx) << 8)};
+  }
+  __device__ float b(const BK& k, const BN& n) const {
+    const bool ok = ((n.mask >> (k.sh & 0xff)) & (n.mask >> (k.sh >> 8)) & 1u) != 0;
+    const float v = small[ok ? n.off + k.off : 0];
+    return ok ? v : 0.f;
   }
   __device__ void store(int m, int n, float v) {
     const int cls = m / G::CB, cb = m % G::CB;
@@ -196,20 +268,34 @@ struct ConvWgradOp {
     kb = zz * imgs_per_split * G::PS;
     ke = min(nimg * G::PS, kb + imgs_per_split * G::PS);
   }
+  typedef int AM;
+  typedef int AK;
+  struct BN {
+    int off;
+    bool one;
+  };
+  typedef int BK;
   __device__ int M() const { return G::CS; }
   __device__ int N() const { return NW + 1; }
   __device__ int kbeg() const { return kb; }
   __device__ int kend() const { return ke; }
-  __device__ float a(int m, int k) const {
-    const int img = k / G::PS, p = k % G::PS;
-    return small[(img * G::CS + m) * G::PS + p];
+  // small[img][m][p] = small[ m*PS + kOff(img,p) ]
+  __device__ AM a_m(int m) const { return m * G::PS; }
+  __device__ AK a_k(int k) const { return (k / G::PS) * (G::CS * G::PS) + k % G::PS; }
+  __device__ float a(const AM& m, const AK& k) const { return small[m + k]; }
+  // big[img][cb][2sy+ky][2sx+kx] = big[ kOff(img,sy,sx) + nOff(cb,ky,kx) ]
+  __device__ BN b_n(int n) const {
+    const int nc = min(n, NW - 1);
+    const int cb = nc / G::KK, r = nc % G::KK;
+    return BN{cb * G::PB + (r / G::KS) * G::WB + r % G::KS, n == NW};
   }
-  __device__ float b(int k, int n) const {
-    if (n == NW) return 1.f;
+  __device__ BK b_k(int k) const {
     const int img = k / G::PS, p = k % G::PS;
-    const int sy = p / G::WS, sx = p % G::WS;
-    const int cb = n / G::KK, r = n % G::KK;
-    return load_as_float(big, ((img * G::CB + cb) * G::HB + 2 * sy + r / G::KS) * G::WB + 2 * sx + r % G::KS);
+    return (img * G::CB * G::HB + 2 * (p / G::WS)) * G::WB + 2 * (p % G::WS);
+  }
+  __device__ float b(const BK& k, const BN& n) const {
+    const float v = load_as_float(big, k + n.off);
+    return n.one ? 1.f : v;
   }
   __device__ void store(int m, int n, float v) { slab[((size_t)z * G::CS + m) * (NW + 1) + n] = v; }
   __device__ void finish() {}
@@ -299,9 +385,13 @@ template <class G>
 static int conv_up_t(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
                      const float* aux, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
-  if (G::CB < 8) {
+  // All four output parity classes read the same (J x J) input taps, so for even kernels
+  // (no zero taps) they are merged on M: one pass over `small`, 4x fewer operand loads per
+  // MFMA and the four interleaved output pixels are written by the same workgroup.
+  if (G::CB < 8 || G::KS % 2 == 0) {
     ConvUpMergedOp<G, float, 0> op{small, w, bias, aux, big, (int)nimg, epi, nullptr, nullptr, nullptr, 0.f, 0.f};
-    return launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
+    using TM_ = typename std::conditional<(4 * G::CB <= 32), T32x256, T128x128>::type;
+    return launch_igemm<TM_>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
   }
   int rc;
   if ((rc = conv_up_class<G, 0, 0>(nimg, small, w, bias, big, epi, aux, s))) return rc;

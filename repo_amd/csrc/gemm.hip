@@ -1,5 +1,7 @@
 // Dense-layer GEMMs on the igemm tile engine: forward / backward-data (repo_gemm) and the
 // split-K weight gradient (repo_gemm_wgrad).
+#include <stdlib.h>
+
 #include "igemm.h"
 
 namespace repo {
@@ -17,13 +19,21 @@ struct GemmOp {
   int M_, N_, K_;
   int epi, accumulate;
 
+  typedef int AM;
+  typedef int AK;
+  typedef int BN;
+  typedef int BK;
   __device__ void init(int) {}
   __device__ int M() const { return M_; }
   __device__ int N() const { return N_; }
   __device__ int kbeg() const { return 0; }
   __device__ int kend() const { return K_; }
-  __device__ float a(int m, int k) const { return TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]; }
-  __device__ float b(int k, int n) const { return TB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]; }
+  __device__ AM a_m(int m) const { return TA ? m : m * lda; }
+  __device__ AK a_k(int k) const { return TA ? k * lda : k; }
+  __device__ float a(const AM& m, const AK& k) const { return A[m + k]; }
+  __device__ BN b_n(int n) const { return TB ? n * ldb : n; }
+  __device__ BK b_k(int k) const { return TB ? k : k * ldb; }
+  __device__ float b(const BK& k, const BN& n) const { return B[k + n]; }
   __device__ void store(int m, int n, float v) {
     if (bias) v += bias[n / bias_div];
     switch (epi) {
@@ -42,6 +52,16 @@ struct GemmOp {
 template <bool TA, bool TB>
 static int gemm_dispatch(const GemmOp<TA, TB>& op, long M, long N, hipStream_t s) {
   // pick the tile by how many workgroups the problem yields (256 CUs to fill)
+  static const int force = getenv("REPO_GEMM_TILE") ? atoi(getenv("REPO_GEMM_TILE")) : 0;  // experiments only
+  switch (force) {
+    case 1: return launch_igemm<T64x64>(op, M, N, 1, s);
+    case 2: return launch_igemm<T64x64k32>(op, M, N, 1, s);
+    case 3: return launch_igemm<T32x64k32>(op, M, N, 1, s);
+    case 4: return launch_igemm<T32x128k32>(op, M, N, 1, s);
+    case 5: return launch_igemm<T64x128k32>(op, M, N, 1, s);
+    case 6: return launch_igemm<T128x128>(op, M, N, 1, s);
+    default: break;
+  }
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128);
   if (M >= 512 && N >= 512 && t128 >= 192) return launch_igemm<T128x128>(op, M, N, 1, s);
   if (M <= 32) return launch_igemm<T32x128>(op, M, N, 1, s);
@@ -64,12 +84,26 @@ struct WgradOp {
     kb = zz * rows_per_split;
     ke = min(rows, kb + rows_per_split);
   }
+  typedef int AM;
+  typedef int AK;
+  struct BN {
+    int off;
+    bool one;
+  };
+  typedef int BK;
   __device__ int M() const { return N_; }
   __device__ int N() const { return K_ + 1; }
   __device__ int kbeg() const { return kb; }
   __device__ int kend() const { return ke; }
-  __device__ float a(int m, int k) const { return dY[(size_t)k * lddy + m]; }
-  __device__ float b(int k, int n) const { return n == K_ ? 1.f : X[(size_t)k * ldx + n]; }
+  __device__ AM a_m(int m) const { return m; }
+  __device__ AK a_k(int k) const { return k * lddy; }
+  __device__ float a(const AM& m, const AK& k) const { return dY[m + k]; }
+  __device__ BN b_n(int n) const { return BN{min(n, K_ - 1), n == K_}; }
+  __device__ BK b_k(int k) const { return k * ldx; }
+  __device__ float b(const BK& k, const BN& n) const {
+    const float v = X[k + n.off];
+    return n.one ? 1.f : v;
+  }
   __device__ void store(int m, int n, float v) { slab[((size_t)z * N_ + m) * (K_ + 1) + n] = v; }
   __device__ void finish() {}
 };
@@ -117,6 +151,11 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
   REPO_REQUIRE((epi != REPO_EPI_MUL_DELU && epi != REPO_EPI_MUL_DRELU) || aux, REPO_E_BADARG);
   REPO_REQUIRE(M < kMaxIdx && N < kMaxIdx && K < kMaxIdx && lda < kMaxIdx && ldb < kMaxIdx && ldc < kMaxIdx,
                REPO_E_SHAPE);
+  {  // operand offsets are 32-bit inside the kernel
+    const int64_t ea = transa ? (K - 1) * lda + M : (M - 1) * lda + K;
+    const int64_t eb = transb ? (N - 1) * ldb + K : (K - 1) * ldb + N;
+    REPO_REQUIRE(ea < kMaxIdx && eb < kMaxIdx, REPO_E_SHAPE);
+  }
   if (bias_div <= 0) bias_div = 1;
 #define REPO_GEMM_CASE(TA, TB)                                                                   \
   {                                                                                              \
@@ -143,6 +182,7 @@ extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY,
   if (N == 0 || K == 0) return REPO_OK;
   REPO_REQUIRE(dY && X && dW, REPO_E_BADARG);
   REPO_REQUIRE(M < kMaxIdx && N < kMaxIdx && K < kMaxIdx - 1, REPO_E_SHAPE);
+  REPO_REQUIRE(M * lddy < kMaxIdx && M * ldx < kMaxIdx, REPO_E_SHAPE);
   if (M == 0) {
     if (!accumulate) {
       for (int64_t n = 0; n < N; ++n) (void)hipMemsetAsync(dW + n * lddw, 0, K * sizeof(float), stream);

@@ -2,10 +2,10 @@
 //
 //   C[m][n] = sum_k A(m,k) * B(k,n)      m in [0,M)  n in [0,N)  k in [kbeg,kend)
 //
-// The operands are *functors*: an Op supplies element loaders a(m,k), b(k,n) and an
-// epilogue store(m,n,acc), so the same tile engine serves the dense layers (NT/NN/TN),
-// the strided convolutions (gather form), the transposed convolutions (parity-class
-// form) and their weight gradients (split-K over images) without materialising im2col.
+// The operands are *functors*: an Op supplies element loaders and an epilogue, so the same
+// tile engine serves the dense layers (NT/NN/TN), the strided convolutions (gather form),
+// the transposed convolutions (parity-class form) and their weight gradients (split-K over
+// images) without materialising im2col.
 //
 // Mapping to the hardware:
 //  * one wave64 owns TM x TN accumulator tiles of 32x32, each fed by
@@ -20,7 +20,17 @@
 //    MFMAs of slice t and written to the other buffer afterwards: one barrier per slice.
 //  * lanes run along n in the epilogue, so Ops are arranged with the memory-contiguous
 //    output index on n (pixels for NCHW activations, features for row-major matrices).
+//
+// Address generation is SEPARABLE: every operand element address is rowctx(m or n) (+)
+// colctx(k).  The engine hoists whichever context is fixed for a thread out of the K loop
+// (an m/n-major operand: the thread's single m/n, decoded once; a k-major operand: its
+// A_PER/B_PER rows, decoded once, plus ONE k decode per slice) and, when all lanes of a
+// wave share k, computes the k context on the scalar unit.  Loads are unconditional from a
+// clamped in-range address followed by a select: a predicated load makes hipcc branch
+// around every element and drain vmcnt per element (measured 2-5x slower).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace repo {
@@ -34,6 +44,7 @@ struct TileCfg {
   static constexpr int NT = WM * WN * 64;
   static_assert(BK % 2 == 0, "BK must be even (mfma 32x32x2)");
   static_assert((BM * BK) % NT == 0 && (BN * BK) % NT == 0, "tile must divide over threads");
+  static_assert(NT % BM == 0 && NT % BN == 0 && NT % BK == 0, "one row context per thread");
 };
 
 using T128x128 = TileCfg<2, 2, 2, 2>;
@@ -42,18 +53,30 @@ using T64x64 = TileCfg<2, 2, 1, 1>;
 using T32x128 = TileCfg<1, 4, 1, 1>;
 using T32x256 = TileCfg<1, 4, 1, 2>;
 using T128x64 = TileCfg<2, 2, 2, 1>;
-using T256x64 = TileCfg<4, 1, 2, 2>;
+using T64x64k32 = TileCfg<2, 2, 1, 1, 32>;
+using T32x64k32 = TileCfg<1, 2, 1, 1, 32>;
+using T32x128k32 = TileCfg<1, 4, 1, 1, 32>;
+using T64x128k32 = TileCfg<2, 2, 1, 2, 32>;
 
 // Op concept:
 //   __device__ void  init(int z);                 // per-blockIdx.z setup (class / split)
 //   __device__ int   M() const, N() const;        // logical extents for this z
 //   __device__ int   kbeg() const, kend() const;
-//   __device__ float a(int m, int k) const;       // 0 <= m < M, kbeg <= k < kend
-//   __device__ float b(int k, int n) const;
+//   types AM, AK, BN, BK (trivially copyable contexts)
+//   __device__ AM a_m(int m) const;  AK a_k(int k) const;  float a(const AM&, const AK&) const;
+//   __device__ BN b_n(int n) const;  BK b_k(int k) const;  float b(const BK&, const BN&) const;
+//        indices handed to a_m/a_k/b_n/b_k are always in range; a()/b() must be branch-free
 //   __device__ void  store(int m, int n, float v);
 //   __device__ void  finish();                    // after the epilogue (block-level reductions)
 //   static constexpr bool A_KMAJOR, B_KMAJOR;     // staging thread order: k fastest (source is
 //                                                 // k-contiguous) or m/n fastest
+template <int ROWS, int NT>
+__device__ __forceinline__ int uniform_div(int tid) {
+  // tid / ROWS; wave-uniform (hence scalar) when a wave of 64 lanes cannot straddle two values
+  if (ROWS % 64 == 0) return __builtin_amdgcn_readfirstlane(tid / ROWS);
+  return tid / ROWS;
+}
+
 template <class Op, class T>
 __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;
@@ -83,54 +106,101 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[A_PER], rb[B_PER];
+    // ---- per-thread staging roles and hoisted row contexts
+    // k-major: kk = tid % BK fixed, rows r_j = tid / BK + j * (NT / BK)
+    // m-major: row = tid % BM fixed, kk_j = tid / BM + j * (NT / BM)
+    constexpr int A_NCTX = Op::A_KMAJOR ? A_PER : 1;
+    constexpr int B_NCTX = Op::B_KMAJOR ? B_PER : 1;
+    typename Op::AM am[A_NCTX];
+    typename Op::BN bn[B_NCTX];
+    unsigned a_ok = 0, b_ok = 0;  // bit j: row of element j is inside the matrix
+    const int a_kk0 = Op::A_KMAJOR ? (tid % BK) : uniform_div<BM, NT>(tid);
+    const int b_kk0 = Op::B_KMAJOR ? (tid % BK) : uniform_div<BN, NT>(tid);
+#pragma unroll
+    for (int j = 0; j < A_NCTX; ++j) {
+      const int mm = Op::A_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BM);
+      const int m = m0 + mm;
+      am[j] = op.a_m(min(m, M - 1));
+      a_ok |= (m < M ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int j = 0; j < B_NCTX; ++j) {
+      const int nn = Op::B_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BN);
+      const int n = n0 + nn;
+      bn[j] = op.b_n(min(n, N - 1));
+      b_ok |= (n < N ? 1u : 0u) << j;
+    }
 
-    auto gload = [&](int kt) {
+    // Two register staging sets: while slice t is being multiplied out of LDS, slice t+1 sits
+    // in one set (in flight or landed) and the loads of slice t+2 are issued into the other,
+    // so a global load has two MFMA phases (>= 1000 cycles) to land before its LDS write.
+    // Needed where a launch has <= 1 workgroup per CU (the 2450-row dense layers of the
+    // imagination rollout: one wave per SIMD, nothing else to hide HBM/L2 latency behind).
+    // Raw loaded values + validity bitmasks per set.  The zero-fill select is applied when the
+    // slice is written to LDS, NOT at load time: a select on the loaded value right after the
+    // load makes hipcc wait for the load immediately and serialises the whole pipeline.
+    float ra[2][A_PER], rb[2][B_PER];
+    unsigned amask[2] = {0u, 0u}, bmask[2] = {0u, 0u};
+
+    // CK = false: the whole slice [kt, kt+BK) is inside [kbeg, kend) -> no k checks at all
+    auto gload = [&](int kt, auto set_c, auto check_k) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
+      constexpr bool CK = decltype(check_k)::value;
+      if (Op::A_KMAJOR) {
+        const int k = kt + a_kk0;
+        const typename Op::AK ak = op.a_k(CK ? min(k, kend - 1) : k);
+        amask[S] = (!CK || k < kend) ? a_ok : 0u;
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) {
-        const int e = tid + j * NT;
-        const int kk = Op::A_KMAJOR ? (e % BK) : (e / BM);
-        const int mm = Op::A_KMAJOR ? (e / BK) : (e % BM);
-        const int m = m0 + mm, k = kt + kk;
-        ra[j] = (m < M && k < kend) ? op.a(m, k) : 0.f;
+        for (int j = 0; j < A_PER; ++j) ra[S][j] = op.a(am[j], ak);
+      } else {
+        unsigned mk = 0;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+          const int k = kt + a_kk0 + j * (NT / BM);
+          ra[S][j] = op.a(am[0], op.a_k(CK ? min(k, kend - 1) : k));
+          mk |= ((!CK || k < kend) ? 1u : 0u) << j;
+        }
+        amask[S] = (a_ok & 1u) ? mk : 0u;
       }
+      if (Op::B_KMAJOR) {
+        const int k = kt + b_kk0;
+        const typename Op::BK bk = op.b_k(CK ? min(k, kend - 1) : k);
+        bmask[S] = (!CK || k < kend) ? b_ok : 0u;
 #pragma unroll
-      for (int j = 0; j < B_PER; ++j) {
-        const int e = tid + j * NT;
-        const int kk = Op::B_KMAJOR ? (e % BK) : (e / BN);
-        const int nn = Op::B_KMAJOR ? (e / BK) : (e % BN);
-        const int n = n0 + nn, k = kt + kk;
-        rb[j] = (n < N && k < kend) ? op.b(k, n) : 0.f;
+        for (int j = 0; j < B_PER; ++j) rb[S][j] = op.b(bk, bn[j]);
+      } else {
+        unsigned mk = 0;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+          const int k = kt + b_kk0 + j * (NT / BN);
+          rb[S][j] = op.b(op.b_k(CK ? min(k, kend - 1) : k), bn[0]);
+          mk |= ((!CK || k < kend) ? 1u : 0u) << j;
+        }
+        bmask[S] = (b_ok & 1u) ? mk : 0u;
       }
     };
-    auto lstore = [&](int buf) {
+    auto gload_any = [&](int kt, auto set_c) __attribute__((always_inline)) {
+      if (kt + BK <= kend) gload(kt, set_c, std::false_type{});
+      else gload(kt, set_c, std::true_type{});
+    };
+    auto lstore = [&](int buf, auto set_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(set_c)::value;
       float* as = As + buf * BK * LDA;
       float* bs = Bs + buf * BK * LDB;
 #pragma unroll
       for (int j = 0; j < A_PER; ++j) {
-        const int e = tid + j * NT;
-        const int kk = Op::A_KMAJOR ? (e % BK) : (e / BM);
-        const int mm = Op::A_KMAJOR ? (e / BK) : (e % BM);
-        as[kk * LDA + mm] = ra[j];
+        const int kk = Op::A_KMAJOR ? (tid % BK) : (tid / BM + j * (NT / BM));
+        const int mm = Op::A_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BM);
+        as[kk * LDA + mm] = ((amask[S] >> j) & 1u) ? ra[S][j] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < B_PER; ++j) {
-        const int e = tid + j * NT;
-        const int kk = Op::B_KMAJOR ? (e % BK) : (e / BN);
-        const int nn = Op::B_KMAJOR ? (e / BK) : (e % BN);
-        bs[kk * LDB + nn] = rb[j];
+        const int kk = Op::B_KMAJOR ? (tid % BK) : (tid / BN + j * (NT / BN));
+        const int nn = Op::B_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BN);
+        bs[kk * LDB + nn] = ((bmask[S] >> j) & 1u) ? rb[S][j] : 0.f;
       }
     };
-
-    int buf = 0;
-    if (kbeg < kend) {
-      gload(kbeg);
-      lstore(0);
-    }
-    __syncthreads();
-    for (int kt = kbeg; kt < kend; kt += BK) {
-      const bool more = kt + BK < kend;
-      if (more) gload(kt + BK);
+    auto compute = [&](int buf) __attribute__((always_inline)) {
       const float* as = As + buf * BK * LDA + wm * (T::TM * 32) + li;
       const float* bs = Bs + buf * BK * LDB + wn * (T::TN * 32) + li;
 #pragma unroll
@@ -146,9 +216,40 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
           for (int j = 0; j < T::TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
-      if (more) lstore(buf ^ 1);
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    // Loads and LDS writes are issued UNCONDITIONALLY (slice index clamped to the last slice):
+    // hipcc's s_waitcnt insertion is static, so a load that is skipped on some path makes every
+    // later counted wait collapse to vmcnt(0) and drains the prefetch.  Re-loading the last
+    // slice once or twice at the tail is cheaper than losing the overlap everywhere.
+    auto slice_k = [&](int t) __attribute__((always_inline)) { return kbeg + min(t, nt - 1) * BK; };
+    if (nt > 0) {
+      gload_any(slice_k(0), S0{});
+      lstore(0, S0{});
+      gload_any(slice_k(1), S1{});
       __syncthreads();
-      buf ^= 1;
+      for (int t = 0; t < nt; t += 2) {
+        // even slice t: LDS buffer 0; slice t+1 is in set 1; issue slice t+2 into set 0
+        gload_any(slice_k(t + 2), S0{});
+        // coarse fences: keep the LDS-write selects of the landed set BEHIND the MFMA phase and
+        // the new loads AHEAD of it (hipcc otherwise hoists the selects above the load issue)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(1, S1{});
+        __syncthreads();
+        if (t + 1 >= nt) break;
+        // odd slice t+1: LDS buffer 1; slice t+2 is in set 0; issue slice t+3 into set 1
+        gload_any(slice_k(t + 3), S1{});
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(0, S0{});
+        __syncthreads();
+      }
     }
 
 #pragma unroll
