@@ -76,10 +76,17 @@ struct ConvDownOp {
     return cb * G::PB + (r / G::KS) * G::WB + r % G::KS;
   }
   __device__ float b(const BK& k, const BN& n) const { return load_as_float(big, n + k); }
-  __device__ void store(int m, int n, float v) {
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
     const int img = n / G::PS, p = n % G::PS;
-    const int o = (img * G::CS + m) * G::PS + p;
-    out[o] = epi_apply(v, epi, bias, m, aux, o);
+    const int o0 = (img * G::CS + mb) * G::PS + p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) {
+        const int o = o0 + dm * G::PS;
+        out[o] = epi_apply(acc[r], epi, bias, mb + dm, aux, o);
+      }
+    }
   }
   __device__ void finish() {}
 };
@@ -141,11 +148,18 @@ struct ConvUpOp {
     const float v = small[ok ? n.off + k.off : 0];
     return ok ? v : 0.f;
   }
-  __device__ void store(int m, int n, float v) {
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
     const int img = n / (NY * NX), q = n % (NY * NX);
     const int y = q / NX, x = q % NX;
-    const int o = ((img * G::CB + m) * G::HB + 2 * y + PY) * G::WB + 2 * x + PX;
-    out[o] = epi_apply(v, epi, bias, m, aux, o);
+    const int o0 = ((img * G::CB + mb) * G::HB + 2 * y + PY) * G::WB + 2 * x + PX;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) {
+        const int o = o0 + dm * G::PB;
+        out[o] = epi_apply(acc[r], epi, bias, mb + dm, aux, o);
+      }
+    }
   }
   __device__ void finish() {}
 };
@@ -227,20 +241,30 @@ struct ConvUpMergedOp {
     const float v = small[ok ? n.off + k.off : 0];
     return ok ? v : 0.f;
   }
-  __device__ void store(int m, int n, float v) {
-    const int cls = m / G::CB, cb = m % G::CB;
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
     const int img = n / (NY * NX), q = n % (NY * NX);
-    const int by = 2 * (q / NX) + (cls >> 1), bx = 2 * (q % NX) + (cls & 1);
-    if (by >= G::HB || bx >= G::WB) return;
-    const int o = ((img * G::CB + cb) * G::HB + by) * G::WB + bx;
-    if (MODE == 0) {
-      out[o] = epi_apply(v, epi, bias, cb, aux, o);
-    } else {
-      if (bias) v += bias[cb];
-      const float d = v - load_as_float(target, o);
-      if (out) out[o] = v;
-      if (dpre) dpre[o] = d * grad_scale;
-      lsum += 0.5f * d * d;
+    const int y2 = 2 * (q / NX), x2 = 2 * (q % NX);
+    const int obase = img * G::CB * G::PB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);
+      if (m < M) {
+        const int cls = m / G::CB, cb = m % G::CB;
+        const int by = y2 + (cls >> 1), bx = x2 + (cls & 1);
+        if (by < G::HB && bx < G::WB) {
+          const int o = obase + (cb * G::HB + by) * G::WB + bx;
+          float v = acc[r];
+          if (MODE == 0) {
+            out[o] = epi_apply(v, epi, bias, cb, aux, o);
+          } else {
+            if (bias) v += bias[cb];
+            const float d = v - load_as_float(target, o);
+            if (out) out[o] = v;
+            if (dpre) dpre[o] = d * grad_scale;
+            lsum += 0.5f * d * d;
+          }
+        }
+      }
     }
   }
   __device__ void finish() {
@@ -297,7 +321,14 @@ struct ConvWgradOp {
     const float v = load_as_float(big, k + n.off);
     return n.one ? 1.f : v;
   }
-  __device__ void store(int m, int n, float v) { slab[((size_t)z * G::CS + m) * (NW + 1) + n] = v; }
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
+    float* c = slab + ((size_t)z * G::CS + mb) * (NW + 1) + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) c[dm * (NW + 1)] = acc[r];
+    }
+  }
   __device__ void finish() {}
 };
 

@@ -34,17 +34,23 @@ struct GemmOp {
   __device__ BN b_n(int n) const { return TB ? n * ldb : n; }
   __device__ BK b_k(int k) const { return TB ? k : k * ldb; }
   __device__ float b(const BK& k, const BN& n) const { return B[k + n]; }
-  __device__ void store(int m, int n, float v) {
-    if (bias) v += bias[n / bias_div];
-    switch (epi) {
-      case REPO_EPI_ELU: v = elu(v); break;
-      case REPO_EPI_RELU: v = fmaxf(v, 0.f); break;
-      case REPO_EPI_MUL_DELU: v *= elu_grad_from_out(aux[(size_t)m * ldaux + n]); break;
-      case REPO_EPI_MUL_DRELU: v = aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f; break;
-      default: break;
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
+    const float bv = bias ? bias[bias_div == 1 ? n : n / bias_div] : 0.f;
+    float* c = C + mb * ldc + n;
+    const float* ax = aux ? aux + mb * ldaux + n : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) {
+        float v = acc[r] + bv;
+        if (epi == REPO_EPI_ELU) v = elu(v);
+        else if (epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
+        else if (epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(ax[dm * ldaux]);
+        else if (epi == REPO_EPI_MUL_DRELU) v = ax[dm * ldaux] > 0.f ? v : 0.f;
+        if (accumulate) v += c[dm * ldc];
+        c[dm * ldc] = v;
+      }
     }
-    float* c = C + (size_t)m * ldc + n;
-    *c = accumulate ? *c + v : v;
   }
   __device__ void finish() {}
 };
@@ -104,7 +110,14 @@ struct WgradOp {
     const float v = X[k + n.off];
     return n.one ? 1.f : v;
   }
-  __device__ void store(int m, int n, float v) { slab[((size_t)z * N_ + m) * (K_ + 1) + n] = v; }
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
+    float* c = slab + ((size_t)z * N_ + mb) * (K_ + 1) + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) c[dm * (K_ + 1)] = acc[r];
+    }
+  }
   __device__ void finish() {}
 };
 
@@ -154,7 +167,7 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
   {  // operand offsets are 32-bit inside the kernel
     const int64_t ea = transa ? (K - 1) * lda + M : (M - 1) * lda + K;
     const int64_t eb = transb ? (N - 1) * ldb + K : (K - 1) * ldb + N;
-    REPO_REQUIRE(ea < kMaxIdx && eb < kMaxIdx, REPO_E_SHAPE);
+    REPO_REQUIRE(ea < kMaxIdx && eb < kMaxIdx && M * ldc < kMaxIdx && M * ldaux < kMaxIdx, REPO_E_SHAPE);
   }
   if (bias_div <= 0) bias_div = 1;
 #define REPO_GEMM_CASE(TA, TB)                                                                   \

@@ -66,7 +66,7 @@ using T64x128k32 = TileCfg<2, 2, 1, 2, 32>;
 //   __device__ AM a_m(int m) const;  AK a_k(int k) const;  float a(const AM&, const AK&) const;
 //   __device__ BN b_n(int n) const;  BK b_k(int k) const;  float b(const BK&, const BN&) const;
 //        indices handed to a_m/a_k/b_n/b_k are always in range; a()/b() must be branch-free
-//   __device__ void  store(int m, int n, float v);
+//   __device__ void  store_col(int mb, int n, const f32x16& acc, int M);  // rows mb+(r&3)+8*(r>>2) < M
 //   __device__ void  finish();                    // after the epilogue (block-level reductions)
 //   static constexpr bool A_KMAJOR, B_KMAJOR;     // staging thread order: k fastest (source is
 //                                                 // k-contiguous) or m/n fastest
@@ -203,19 +203,24 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
     auto compute = [&](int buf) __attribute__((always_inline)) {
       const float* as = As + buf * BK * LDA + wm * (T::TM * 32) + li;
       const float* bs = Bs + buf * BK * LDB + wn * (T::TN * 32) + li;
+      // All operand fragments of the slice are read from LDS up front, then the MFMA chain runs
+      // with counted lgkmcnt waits: with one wave per SIMD (small launches) a read->wait->MFMA
+      // sequence per k-step exposes the ~130-cycle LDS latency on every 64-cycle MFMA.
+      float av[BK / 2][T::TM], bv[BK / 2][T::TN];
 #pragma unroll
       for (int ks = 0; ks < BK / 2; ++ks) {
-        float av[T::TM], bv[T::TN];
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i) av[i] = as[(ks * 2 + lh) * LDA + i * 32];
+        for (int i = 0; i < T::TM; ++i) av[ks][i] = as[(ks * 2 + lh) * LDA + i * 32];
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) bv[j] = bs[(ks * 2 + lh) * LDB + j * 32];
+        for (int j = 0; j < T::TN; ++j) bv[ks][j] = bs[(ks * 2 + lh) * LDB + j * 32];
+      }
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks)
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
           for (int j = 0; j < T::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
     };
 
     using S0 = std::integral_constant<int, 0>;
@@ -252,16 +257,18 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
       }
     }
 
+    // Epilogue: lane (li, lh) of tile (i, j) holds column n and the 16 rows
+    // mb + (r & 3) + 8 * (r >> 2), r = 0..15.  The Op gets the whole column at once so that
+    // everything that depends on n only (bias, pixel decode, base pointers) is computed once,
+    // not 16 times: for the small dense layers the per-element epilogue used to cost more
+    // than the K loop.
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
       for (int j = 0; j < T::TN; ++j) {
         const int n = n0 + (wn * T::TN + j) * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * T::TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < M && n < N) op.store(m, n, acc[i][j][r]);
-        }
+        const int mb = m0 + (wm * T::TM + i) * 32 + 4 * lh;
+        if (n < N && mb < M) op.store_col(mb, n, acc[i][j], M);
       }
   }
   op.finish();
