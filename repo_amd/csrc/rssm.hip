@@ -62,8 +62,12 @@ struct ObsFwdArgs {
   float min_std;
 };
 
-template <int R>
-__global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
+// R rows per workgroup, KQ-way split of every reduction (k) range over thread groups of 256:
+// thread (kq, j) accumulates feature j over its quarter of k, partials meet in LDS.  The scan is
+// bound by the latency of streaming ~1.4 MB of L2-resident weights per step through ONE CU; the
+// k-split multiplies the loads in flight (memory-level parallelism), which is what that needs.
+template <int R, int KQ>
+__global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
   const int T = p.d.T, B = p.d.B, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
   const int X = S + A, F = D + S;
   __shared__ float xs[R][kMaxX];
@@ -73,24 +77,32 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
   __shared__ float hqs[R][kMaxW];
   __shared__ float outs[R][2 * kMaxS2];  // [0,2S) prior raw, [2S,4S) posterior raw
   __shared__ float st[R][kMaxS2];
+  __shared__ float part[KQ][6][R][kMaxW];  // k-split partial sums
 
   const int tid = threadIdx.x;
+  const int j = tid & 255;
+  const int kq = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int b0 = blockIdx.x * R;
   int nr = B - b0;
   if (nr > R) nr = R;
+  auto krange = [&](int K, int& k0, int& k1) {
+    const int per = (K + KQ - 1) / KQ;
+    k0 = kq * per;
+    k1 = min(K, k0 + per);
+  };
 
   // slot 0 of featx and the carried state
   for (int i = tid; i < R * D; i += blockDim.x) {
-    const int r = i / D, j = i % D;
-    const float v = r < nr ? p.prev_belief[(size_t)(b0 + r) * D + j] : 0.f;
-    hs[0][r][j] = v;
-    if (r < nr) p.featx[(size_t)(b0 + r) * F + j] = v;
+    const int r = i / D, c = i % D;
+    const float v = r < nr ? p.prev_belief[(size_t)(b0 + r) * D + c] : 0.f;
+    hs[0][r][c] = v;
+    if (r < nr) p.featx[(size_t)(b0 + r) * F + c] = v;
   }
   for (int i = tid; i < R * S; i += blockDim.x) {
-    const int r = i / S, j = i % S;
-    const float v = r < nr ? p.prev_state[(size_t)(b0 + r) * S + j] : 0.f;
-    st[r][j] = v;
-    if (r < nr) p.featx[(size_t)(b0 + r) * F + D + j] = v;
+    const int r = i / S, c = i % S;
+    const float v = r < nr ? p.prev_state[(size_t)(b0 + r) * S + c] : 0.f;
+    st[r][c] = v;
+    if (r < nr) p.featx[(size_t)(b0 + r) * F + D + c] = v;
   }
   __syncthreads();
 
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
       xs[r][k] = v;
     }
     __syncthreads();
-    // ---- e = elu(W_sa x + b)
+    // ---- e = elu(W_sa x + b)   (K = S+A is short: no split)
     if (tid < D) {
       float acc[R];
 #pragma unroll
@@ -126,21 +138,20 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
       }
     }
     __syncthreads();
-    // ---- GRU cell (gate order r,z,n)
-    if (tid < D) {
+    // ---- GRU cell (gate order r,z,n): partial sums over this thread's k range
+    if (j < D) {
       float gi[3][R], gh[3][R];
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          gi[g][r] = p.bih[g * D + tid];
-          gh[g][r] = p.bhh[g * D + tid];
-        }
+        for (int r = 0; r < R; ++r) gi[g][r] = gh[g][r] = 0.f;
       const float* hc = &hs[cur][0][0];
+      int k0, k1;
+      krange(D, k0, k1);
 #pragma unroll 4
-      for (int k = 0; k < D; ++k) {
-        const float* wi = p.WihT + (size_t)k * 3 * D + tid;
-        const float* wh = p.WhhT + (size_t)k * 3 * D + tid;
+      for (int k = k0; k < k1; ++k) {
+        const float* wi = p.WihT + (size_t)k * 3 * D + j;
+        const float* wh = p.WhhT + (size_t)k * 3 * D + j;
         const float wi0 = wi[0], wi1 = wi[D], wi2 = wi[2 * D];
         const float wh0 = wh[0], wh1 = wh[D], wh2 = wh[2 * D];
 #pragma unroll
@@ -155,11 +166,29 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
         }
       }
 #pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          part[kq][g][r][j] = gi[g][r];
+          part[kq][3 + g][r][j] = gh[g][r];
+        }
+    }
+    __syncthreads();
+    if (tid < D) {
+#pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float rg = sigmoidf(gi[0][r] + gh[0][r]);
-        const float zg = sigmoidf(gi[1][r] + gh[1][r]);
-        const float ng = tanhf(gi[2][r] + rg * gh[2][r]);
-        const float hprev = hc[r * kMaxW + tid];
+        float g6[6];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          float sacc = g < 3 ? p.bih[g * D + tid] : p.bhh[(g - 3) * D + tid];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) sacc += part[q][g][r][tid];
+          g6[g] = sacc;
+        }
+        const float rg = sigmoidf(g6[0] + g6[3]);
+        const float zg = sigmoidf(g6[1] + g6[4]);
+        const float ng = tanhf(g6[2] + rg * g6[5]);
+        const float hprev = hs[cur][r][tid];
         const float hn = (1.f - zg) * ng + zg * hprev;
         hs[cur ^ 1][r][tid] = hn;
         if (r < nr) {
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
           g[tid] = rg;
           g[D + tid] = zg;
           g[2 * D + tid] = ng;
-          g[3 * D + tid] = gh[2][r];
+          g[3 * D + tid] = g6[5];
           p.featx[((size_t)(t + 1) * B + b0 + r) * F + tid] = hn;
         }
       }
@@ -175,18 +204,17 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
     __syncthreads();
     cur ^= 1;
     // ---- hidden layers of the prior and the posterior heads
-    if (tid < Hd) {
+    if (j < Hd) {
       float ap[R], aq[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        ap[r] = p.bbp[tid];
-        aq[r] = p.bbq[tid] + (r < nr ? p.eemb[(row0 + r) * Hd + tid] : 0.f);
-      }
+      for (int r = 0; r < R; ++r) ap[r] = aq[r] = 0.f;
       const float* hc = &hs[cur][0][0];
+      int k0, k1;
+      krange(D, k0, k1);
 #pragma unroll 4
-      for (int k = 0; k < D; ++k) {
-        const float wp = p.WbpT[(size_t)k * Hd + tid];
-        const float wq = p.WbqT[(size_t)k * Hd + tid];
+      for (int k = k0; k < k1; ++k) {
+        const float wp = p.WbpT[(size_t)k * Hd + j];
+        const float wq = p.WbqT[(size_t)k * Hd + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const float hv = hc[r * kMaxW + k];
@@ -196,7 +224,21 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float vp = elu(ap[r]), vq = elu(aq[r]);
+        part[kq][0][r][j] = ap[r];
+        part[kq][1][r][j] = aq[r];
+      }
+    }
+    __syncthreads();
+    if (tid < Hd) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float ap = p.bbp[tid], aq = p.bbq[tid] + (r < nr ? p.eemb[(row0 + r) * Hd + tid] : 0.f);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          ap += part[q][0][r][tid];
+          aq += part[q][1][r][tid];
+        }
+        const float vp = elu(ap), vq = elu(aq);
         hps[r][tid] = vp;
         hqs[r][tid] = vq;
         if (r < nr) {
@@ -206,23 +248,37 @@ __global__ __launch_bounds__(256) void observe_fwd_kernel(ObsFwdArgs p) {
       }
     }
     __syncthreads();
-    // ---- output layers: threads [0,2S) prior, [2S,4S) posterior
-    if (tid < 4 * S) {
-      const bool post = tid >= 2 * S;
-      const int o = post ? tid - 2 * S : tid;
+    // ---- output layers: columns [0,2S) prior, [2S,4S) posterior; k split as above
+    if (j < 4 * S) {
+      const bool post = j >= 2 * S;
+      const int o = post ? j - 2 * S : j;
       const float* Wt = post ? p.WsqT : p.WspT;
       const float* hsrc = post ? &hqs[0][0] : &hps[0][0];
       float acc[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = post ? p.bsq[o] : p.bsp[o];
+      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      int k0, k1;
+      krange(Hd, k0, k1);
 #pragma unroll 4
-      for (int k = 0; k < Hd; ++k) {
+      for (int k = k0; k < k1; ++k) {
         const float w = Wt[(size_t)k * 2 * S + o];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = fmaf(w, hsrc[r * kMaxW + k], acc[r]);
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) outs[r][tid] = acc[r];
+      for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
+    }
+    __syncthreads();
+    if (tid < 4 * S) {
+      const bool post = tid >= 2 * S;
+      const int o = post ? tid - 2 * S : tid;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = post ? p.bsq[o] : p.bsp[o];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) acc += part[q][0][r][tid];
+        outs[r][tid] = acc;
+      }
     }
     __syncthreads();
     // ---- softplus + reparameterised samples
@@ -271,8 +327,8 @@ struct ObsBwdArgs {
   float min_std;
 };
 
-template <int R>
-__global__ __launch_bounds__(256) void observe_bwd_kernel(ObsBwdArgs p) {
+template <int R, int KQ>
+__global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
   const int T = p.d.T, B = p.d.B, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
   const int X = S + A, F = D + S;
   __shared__ float dh[R][kMaxW];      // carried d belief
@@ -284,11 +340,19 @@ __global__ __launch_bounds__(256) void observe_bwd_kernel(ObsBwdArgs p) {
   __shared__ float dgis[R][3 * kMaxW];
   __shared__ float dghs[R][3 * kMaxW];
   __shared__ float des[R][kMaxW];
+  __shared__ float part[KQ][2][R][kMaxW];  // k-split partial sums
 
   const int tid = threadIdx.x;
+  const int j = tid & 255;
+  const int kq = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int b0 = blockIdx.x * R;
   int nr = B - b0;
   if (nr > R) nr = R;
+  auto krange = [&](int K, int& k0, int& k1) {
+    const int per = (K + KQ - 1) / KQ;
+    k0 = kq * per;
+    k1 = min(K, k0 + per);
+  };
   for (int i = tid; i < R * kMaxW; i += blockDim.x) (&dh[0][0])[i] = 0.f;
   for (int i = tid; i < R * kMaxS2; i += blockDim.x) (&dst[0][0])[i] = 0.f;
   __syncthreads();
@@ -338,7 +402,7 @@ __global__ __launch_bounds__(256) void observe_bwd_kernel(ObsBwdArgs p) {
       douts[r][base + S + s] = draw;
     }
     __syncthreads();
-    // ---- back through the output layers to the hidden pre-activations
+    // ---- back through the output layers to the hidden pre-activations (K = 2S: no split)
     if (tid < Hd) {
       float ap[R], aq[R];
 #pragma unroll
@@ -366,26 +430,36 @@ __global__ __launch_bounds__(256) void observe_bwd_kernel(ObsBwdArgs p) {
       }
     }
     __syncthreads();
-    // ---- into belief_t, then through the GRU gates (pointwise in the feature index)
-    if (tid < D) {
+    // ---- into belief_t (k-split partial sums over the hidden index)
+    if (j < D) {
       float acc[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = dbel[r][tid];
+      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      int k0, k1;
+      krange(Hd, k0, k1);
 #pragma unroll 4
-      for (int j = 0; j < Hd; ++j) {
-        const float wp = p.Wbp[(size_t)j * D + tid];
-        const float wq = p.Wbq[(size_t)j * p.ldbq + tid];
+      for (int jj = k0; jj < k1; ++jj) {
+        const float wp = p.Wbp[(size_t)jj * D + j];
+        const float wq = p.Wbq[(size_t)jj * p.ldbq + j];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fmaf(wp, dhps[r][j], fmaf(wq, dhqs[r][j], acc[r]));
+        for (int r = 0; r < R; ++r) acc[r] = fmaf(wp, dhps[r][jj], fmaf(wq, dhqs[r][jj], acc[r]));
       }
 #pragma unroll
+      for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
+    }
+    __syncthreads();
+    // ---- through the GRU gates (pointwise in the feature index)
+    if (tid < D) {
+#pragma unroll
       for (int r = 0; r < R; ++r) {
+        float db_ = dbel[r][tid];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) db_ += part[q][0][r][tid];
         float g_r = 0.f, g_z = 0.f, g_n = 0.f, g_hn = 0.f, dhprev = 0.f;
         if (r < nr) {
           const float* g = p.gates + (row0 + r) * 4 * D;
           const float rg = g[tid], zg = g[D + tid], ng = g[2 * D + tid], ghn = g[3 * D + tid];
           const float hprev = p.featx[((size_t)t * B + b0 + r) * F + tid];
-          const float db_ = acc[r];
           const float dn = db_ * (1.f - zg);
           const float dz = db_ * (hprev - ng);
           dhprev = db_ * zg;
@@ -412,30 +486,43 @@ __global__ __launch_bounds__(256) void observe_bwd_kernel(ObsBwdArgs p) {
       }
     }
     __syncthreads();
-    // ---- through W_hh into belief_{t-1}, through W_ih into e
-    if (tid < D) {
+    // ---- through W_hh into belief_{t-1}, through W_ih into e (k-split over the 3D gate index)
+    if (j < D) {
       float ah[R], ae[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        ah[r] = dh[r][tid];
-        ae[r] = 0.f;
-      }
+      for (int r = 0; r < R; ++r) ah[r] = ae[r] = 0.f;
+      int k0, k1;
+      krange(3 * D, k0, k1);
 #pragma unroll 4
-      for (int j = 0; j < 3 * D; ++j) {
-        const float wh = p.Whh[(size_t)j * D + tid];
-        const float wi = p.Wih[(size_t)j * D + tid];
+      for (int jj = k0; jj < k1; ++jj) {
+        const float wh = p.Whh[(size_t)jj * D + j];
+        const float wi = p.Wih[(size_t)jj * D + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          ah[r] = fmaf(wh, dghs[r][j], ah[r]);
-          ae[r] = fmaf(wi, dgis[r][j], ae[r]);
+          ah[r] = fmaf(wh, dghs[r][jj], ah[r]);
+          ae[r] = fmaf(wi, dgis[r][jj], ae[r]);
         }
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        dh[r][tid] = ah[r];
+        part[kq][0][r][j] = ah[r];
+        part[kq][1][r][j] = ae[r];
+      }
+    }
+    __syncthreads();
+    if (tid < D) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float ah = dh[r][tid], ae = 0.f;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          ah += part[q][0][r][tid];
+          ae += part[q][1][r][tid];
+        }
+        dh[r][tid] = ah;
         float v = 0.f;
         if (r < nr) {
-          v = ae[r] * elu_grad_from_out(p.e[(row0 + r) * D + tid]);
+          v = ae * elu_grad_from_out(p.e[(row0 + r) * D + tid]);
           p.de[(row0 + r) * D + tid] = v;
         }
         des[r][tid] = v;
@@ -448,10 +535,10 @@ __global__ __launch_bounds__(256) void observe_bwd_kernel(ObsBwdArgs p) {
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r] = 0.f;
 #pragma unroll 4
-      for (int j = 0; j < D; ++j) {
-        const float w = p.Wsa[(size_t)j * X + tid];
+      for (int jj = 0; jj < D; ++jj) {
+        const float w = p.Wsa[(size_t)jj * X + tid];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, des[r][j], acc[r]);
+        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, des[r][jj], acc[r]);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) dst[r][tid] = r < nr ? acc[r] * p.nonterms[row0 + r] : 0.f;
@@ -530,11 +617,11 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   a.min_std = min_std;
   // rows per workgroup: spread B over as many CUs as possible (the scan is latency-bound)
   if (B >= 512) {
-    hipLaunchKernelGGL(observe_fwd_kernel<4>, dim3(cdiv(B, 4)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((observe_fwd_kernel<4, 1>), dim3(cdiv(B, 4)), dim3(256), 0, stream, a);
   } else if (B >= 128) {
-    hipLaunchKernelGGL(observe_fwd_kernel<2>, dim3(cdiv(B, 2)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((observe_fwd_kernel<2, 2>), dim3(cdiv(B, 2)), dim3(512), 0, stream, a);
   } else {
-    hipLaunchKernelGGL(observe_fwd_kernel<1>, dim3((unsigned)B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((observe_fwd_kernel<1, 4>), dim3((unsigned)B), dim3(1024), 0, stream, a);
   }
   REPO_CHECK_LAUNCH();
   return REPO_OK;
@@ -593,11 +680,11 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
   a.doutp = doutp; a.doutq = doutq; a.dhp = dhp; a.dhq = dhq; a.dgi = dgi; a.dgh = dgh; a.de = de;
   a.dprev_belief = dprev_belief; a.dprev_state = dprev_state; a.min_std = min_std;
   if (B >= 512) {
-    hipLaunchKernelGGL(observe_bwd_kernel<4>, dim3(cdiv(B, 4)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((observe_bwd_kernel<4, 1>), dim3(cdiv(B, 4)), dim3(256), 0, stream, a);
   } else if (B >= 128) {
-    hipLaunchKernelGGL(observe_bwd_kernel<2>, dim3(cdiv(B, 2)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((observe_bwd_kernel<2, 2>), dim3(cdiv(B, 2)), dim3(512), 0, stream, a);
   } else {
-    hipLaunchKernelGGL(observe_bwd_kernel<1>, dim3((unsigned)B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((observe_bwd_kernel<1, 4>), dim3((unsigned)B), dim3(1024), 0, stream, a);
   }
   REPO_CHECK_LAUNCH();
 
