@@ -30,15 +30,15 @@ __global__ void actor_head_fwd_kernel(int rows, int A, int S, const float* __res
         xsa[(size_t)row * X + k] = state[(size_t)row * ldstate + k];
       } else {
         const int a = k - S;
-        const float mu = mean_scale * tanhf(raw[(size_t)row * 2 * A + a] / mean_scale);
+        const float mu = mean_scale * tanh_fast(raw[(size_t)row * 2 * A + a] / mean_scale);
         const float sd = softplus(raw[(size_t)row * 2 * A + A + a] + init_std) + min_std;
         mean[(size_t)row * A + a] = mu;
         stdv[(size_t)row * A + a] = sd;
-        xsa[(size_t)row * X + k] = tanhf(fmaf(sd, eps[(size_t)row * A + a], mu));
+        xsa[(size_t)row * X + k] = tanh_fast(fmaf(sd, eps[(size_t)row * A + a], mu));
       }
     } else {
       const int row = i / A, a = i % A;
-      mean[i] = mean_scale * tanhf(raw[(size_t)row * 2 * A + a] / mean_scale);
+      mean[i] = mean_scale * tanh_fast(raw[(size_t)row * 2 * A + a] / mean_scale);
       stdv[i] = softplus(raw[(size_t)row * 2 * A + A + a] + init_std) + min_std;
     }
   }
@@ -77,7 +77,7 @@ __global__ void gru_fwd_kernel(int rows, int D, const float* __restrict__ gi, co
     const float rg = sigmoidf(a[j] + b[j]);
     const float zg = sigmoidf(a[D + j] + b[D + j]);
     const float ghn = b[2 * D + j];
-    const float ng = tanhf(a[2 * D + j] + rg * ghn);
+    const float ng = tanh_fast(a[2 * D + j] + rg * ghn);
     const float hp = hprev[(size_t)row * ldh + j];
     hnew[(size_t)row * ldn + j] = (1.f - zg) * ng + zg * hp;
     float* g = gates + (size_t)row * 4 * D;
@@ -176,6 +176,21 @@ static inline int lin_bwd_data(int64_t rows, int64_t n, int64_t k, const float* 
   return repo_gemm(0, 0, rows, k, n, dy, lddy, w, k, nullptr, 1, dx, lddx, aux ? REPO_EPI_MUL_DELU : REPO_EPI_NONE,
                    aux, ldaux, accumulate, s);
 }
+
+// persistent row-tiled rollout (imagine_fused.hip)
+bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers);
+size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
+int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
+                      const float* const* ap, const float* belief0, const float* state0, const float* eps_act,
+                      const float* eps_prior, float min_std, float a_min_std, float a_init_std, float a_mean_scale,
+                      float* featx, float* prior_mean, float* prior_std, float* a_hidden, float* a_raw, float* a_mean,
+                      float* a_std, float* xsa, float* e, float* gates, float* hp, void* ws, hipStream_t stream);
+int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
+                      const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
+                      float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
+                      const float* a_std, const float* xsa, const float* e, const float* gates, const float* hp,
+                      const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
+                      float* dfeat0, hipStream_t stream);
 
 }  // namespace repo
 
@@ -280,8 +295,10 @@ static bool img_dims_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
 
 extern "C" size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S) {
-  (void)Hm; (void)A; (void)Hd;
-  return (size_t)N * (6 * D + 2 * S) * sizeof(float);
+  (void)Hm;
+  const size_t unfused = (size_t)N * (6 * D + 2 * S) * sizeof(float);
+  const size_t fused = imagine_fused_fwd_ws_floats(A, D, Hd, S) * sizeof(float);
+  return unfused > fused ? unfused : fused;
 }
 
 extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
@@ -297,6 +314,10 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                    prior_std && a_hidden && a_raw && a_mean && a_std && xsa && e && gates && hp,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_fwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
+  if (imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers))
+    return imagine_fused_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0, eps_act, eps_prior,
+                             min_std, a_min_std, a_init_std, a_mean_scale, featx, prior_mean, prior_std, a_hidden,
+                             a_raw, a_mean, a_std, xsa, e, gates, hp, ws, stream);
   const int64_t F = D + S, X = S + A, rowsAll = Hm * N;
   const float* const* P = rssm_params;
   float* gi = (float*)ws;
@@ -354,6 +375,10 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                    hp && dfeat && d_araw,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_bwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
+  if (imagine_fused_ok(Hm, N, A, D, Hd, S, 5))
+    return imagine_fused_bwd(Hm, N, A, D, Hd, S, rssm_params, eps_act, eps_prior, min_std, a_min_std, a_mean_scale,
+                             featx, prior_std, a_mean, a_std, xsa, e, gates, hp, dfeat, dprior_mean, dprior_std,
+                             d_araw, dfeat0, stream);
   const int64_t F = D + S, X = S + A;
   const float* const* P = rssm_params;
   float* w = (float*)ws;

@@ -120,19 +120,30 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       xs[r][k] = v;
     }
     __syncthreads();
-    // ---- e = elu(W_sa x + b)   (K = S+A is short: no split)
-    if (tid < D) {
+    // ---- e = elu(W_sa x + b)
+    if (j < D) {
       float acc[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = p.bsa[tid];
-      for (int k = 0; k < X; ++k) {
-        const float w = p.WsaT[k * D + tid];
+      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      int k0, k1;
+      krange(X, k0, k1);
+#pragma unroll 4
+      for (int k = k0; k < k1; ++k) {
+        const float w = p.WsaT[k * D + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = fmaf(w, xs[r][k], acc[r]);
       }
 #pragma unroll
+      for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
+    }
+    __syncthreads();
+    if (tid < D) {
+#pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float v = elu(acc[r]);
+        float acc = p.bsa[tid];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) acc += part[q][0][r][tid];
+        const float v = elu(acc);
         es[r][tid] = v;
         if (r < nr) p.e[(row0 + r) * D + tid] = v;
       }
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       const float* hc = &hs[cur][0][0];
       int k0, k1;
       krange(D, k0, k1);
-#pragma unroll 4
+#pragma unroll 8
       for (int k = k0; k < k1; ++k) {
         const float* wi = p.WihT + (size_t)k * 3 * D + j;
         const float* wh = p.WhhT + (size_t)k * 3 * D + j;
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
         }
         const float rg = sigmoidf(g6[0] + g6[3]);
         const float zg = sigmoidf(g6[1] + g6[4]);
-        const float ng = tanhf(g6[2] + rg * g6[5]);
+        const float ng = tanh_fast(g6[2] + rg * g6[5]);
         const float hprev = hs[cur][r][tid];
         const float hn = (1.f - zg) * ng + zg * hprev;
         hs[cur ^ 1][r][tid] = hn;
@@ -402,14 +413,17 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       douts[r][base + S + s] = draw;
     }
     __syncthreads();
-    // ---- back through the output layers to the hidden pre-activations (K = 2S: no split)
-    if (tid < Hd) {
+    // ---- back through the output layers to the hidden pre-activations
+    if (j < Hd) {
       float ap[R], aq[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) ap[r] = aq[r] = 0.f;
-      for (int o = 0; o < 2 * S; ++o) {
-        const float wp = p.Wsp[(size_t)o * Hd + tid];
-        const float wq = p.Wsq[(size_t)o * Hd + tid];
+      int k0, k1;
+      krange(2 * S, k0, k1);
+#pragma unroll 4
+      for (int o = k0; o < k1; ++o) {
+        const float wp = p.Wsp[(size_t)o * Hd + j];
+        const float wq = p.Wsq[(size_t)o * Hd + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           ap[r] = fmaf(wp, douts[r][o], ap[r]);
@@ -418,10 +432,24 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+        part[kq][0][r][j] = ap[r];
+        part[kq][1][r][j] = aq[r];
+      }
+    }
+    __syncthreads();
+    if (tid < Hd) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float ap = 0.f, aq = 0.f;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          ap += part[q][0][r][tid];
+          aq += part[q][1][r][tid];
+        }
         float vp = 0.f, vq = 0.f;
         if (r < nr) {
-          vp = ap[r] * elu_grad_from_out(p.hp[(row0 + r) * Hd + tid]);
-          vq = aq[r] * elu_grad_from_out(p.hq[(row0 + r) * Hd + tid]);
+          vp = ap * elu_grad_from_out(p.hp[(row0 + r) * Hd + tid]);
+          vq = aq * elu_grad_from_out(p.hq[(row0 + r) * Hd + tid]);
           p.dhp[(row0 + r) * Hd + tid] = vp;
           p.dhq[(row0 + r) * Hd + tid] = vq;
         }
@@ -493,7 +521,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       for (int r = 0; r < R; ++r) ah[r] = ae[r] = 0.f;
       int k0, k1;
       krange(3 * D, k0, k1);
-#pragma unroll 4
+#pragma unroll 8
       for (int jj = k0; jj < k1; ++jj) {
         const float wh = p.Whh[(size_t)jj * D + j];
         const float wi = p.Wih[(size_t)jj * D + j];
@@ -530,18 +558,30 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
     }
     __syncthreads();
     // ---- through W_sa into the previous posterior state (masked by nonterminal)
-    if (tid < S) {
+    if (j < S) {
       float acc[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      int k0, k1;
+      krange(D, k0, k1);
 #pragma unroll 4
-      for (int jj = 0; jj < D; ++jj) {
-        const float w = p.Wsa[(size_t)jj * X + tid];
+      for (int jj = k0; jj < k1; ++jj) {
+        const float w = p.Wsa[(size_t)jj * X + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = fmaf(w, des[r][jj], acc[r]);
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) dst[r][tid] = r < nr ? acc[r] * p.nonterms[row0 + r] : 0.f;
+      for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
+    }
+    __syncthreads();
+    if (tid < S) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) acc += part[q][0][r][tid];
+        dst[r][tid] = r < nr ? acc * p.nonterms[row0 + r] : 0.f;
+      }
     }
     __syncthreads();
   }
