@@ -64,6 +64,7 @@ class Dreamer:
         )
         self.free_nats = torch.full((1,), float(config.free_nats), device=self.device)
         self._scal = torch.zeros(32, dtype=torch.float32, device=self.device)
+        self._side_stream = torch.cuda.Stream(device=self.device)
         self.last_scalars = {}
 
     # ------------------------------------------------------------------ construction
@@ -182,14 +183,29 @@ class Dreamer:
         pw, gw = self._pg(self.reward_model)
         ops.mlp_bwd(pw, feat, st["rew_hid"], st["drew"].view(rows, 1), dparams=gw, dx=dfeat)
         pd, gd = self._pg(self.obs_model)
-        Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, dfeat=dfeat if decoder_attached else None,
-                       accumulate_dfeat=True)
         pr, gr = self._pg(self.transition_model)
+        pe, ge = self._pg(self.encoder)
         dembeds = torch.empty(rows, self.c.embedding_size, device=dev)
         dpm, dps, dqm, dqs = kl_grads
-        ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
-                             min_std=self.transition_model.min_std_dev)
-        pe, ge = self._pg(self.encoder)
+        if decoder_attached:
+            # Dreamer: the decoder's input gradient feeds the reverse scan -> strictly serial
+            Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, dfeat=dfeat, accumulate_dfeat=True)
+            ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
+                                 min_std=self.transition_model.min_std_dev)
+            Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge)
+            return
+        # RePo: the decoder is a probe on detached latents (repo.py:46-48), so its backward is
+        # independent of the RSSM/encoder backward.  The reverse scan is a latency-bound chain
+        # that occupies ~50 CUs; running it on a side stream lets the compute-bound decoder
+        # backward fill the other ~200 CUs instead of waiting for it.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
+                                 min_std=self.transition_model.min_std_dev)
+        Fn.decoder_bwd(pd, feat, st["dec_saved"], gd)
+        main.wait_stream(side)
         Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge)
 
     def _model_step(self):

@@ -47,8 +47,10 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (stream-ordered reuse on the current stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, current stream): reuse is stream-ordered, and work
+    running concurrently on a side stream never shares scratch with the main stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
