@@ -44,6 +44,38 @@ __device__ __forceinline__ float epi_apply(float v, int epi, const float* bias, 
   return v;
 }
 
+// Compile-time k -> address-offset tables (one per geometry), read with scalar loads: inside the K
+// loop k is wave-uniform for the n-major operands, so the (channel, ky, kx) decode -- ~10 scalar ALU
+// instructions per element when done with div/mod by constants -- becomes one s_load per element.
+template <class G>
+struct DownKTab {
+  int v[G::CB * G::KK];
+  constexpr DownKTab() : v() {
+    for (int k = 0; k < G::CB * G::KK; ++k) {
+      const int cb = k / G::KK, r = k % G::KK;
+      v[k] = cb * G::PB + (r / G::KS) * G::WB + r % G::KS;
+    }
+  }
+};
+template <class G>
+__device__ const DownKTab<G> g_down_ktab{};
+
+template <class G, int JY, int JX>
+struct UpKTab {
+  int off[G::CS * JY * JX];
+  int sh[G::CS * JY * JX];
+  constexpr UpKTab() : off(), sh() {
+    for (int k = 0; k < G::CS * JY * JX; ++k) {
+      const int cs = k / (JY * JX), r = k % (JY * JX);
+      const int jy = r / JX, jx = r % JX;
+      off[k] = cs * G::PS - jy * G::WS - jx;
+      sh[k] = jy | ((4 + jx) << 8);
+    }
+  }
+};
+template <class G, int JY, int JX>
+__device__ const UpKTab<G, JY, JX> g_up_ktab{};
+
 // ------------------------------------------------------------------------------- down
 template <class G, class BigT>
 struct ConvDownOp {
@@ -71,10 +103,7 @@ struct ConvDownOp {
     const int img = n / G::PS, p = n % G::PS;
     return (img * G::CB * G::HB + 2 * (p / G::WS)) * G::WB + 2 * (p % G::WS);
   }
-  __device__ BK b_k(int k) const {
-    const int cb = k / G::KK, r = k % G::KK;
-    return cb * G::PB + (r / G::KS) * G::WB + r % G::KS;
-  }
+  __device__ BK b_k(int k) const { return g_down_ktab<G>.v[k]; }
   __device__ float b(const BK& k, const BN& n) const { return load_as_float(big, n + k); }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
     const int img = n / G::PS, p = n % G::PS;
@@ -138,11 +167,7 @@ struct ConvUpOp {
     }
     return BN{(img * G::CS * G::HS + y) * G::WS + x, mask};
   }
-  __device__ BK b_k(int k) const {
-    const int cs = k / JJ, r = k % JJ;
-    const int jy = r / JX, jx = r % JX;
-    return BK{cs * G::PS - jy * G::WS - jx, jy | ((4 + jx) << 8)};
-  }
+  __device__ BK b_k(int k) const { return BK{g_up_ktab<G, JY, JX>.off[k], g_up_ktab<G, JY, JX>.sh[k]}; }
   __device__ float b(const BK& k, const BN& n) const {
     const bool ok = ((n.mask >> (k.sh & 0xff)) & (n.mask >> (k.sh >> 8)) & 1u) != 0;
     const float v = small[ok ? n.off + k.off : 0];
@@ -231,11 +256,7 @@ struct ConvUpMergedOp {
     }
     return BN{(img * G::CS * G::HS + y) * G::WS + x, mask};
   }
-  __device__ BK b_k(int k) const {
-    const int cs = k / JJ, r = k % JJ;
-    const int jy = r / J, jx = r % J;
-    return BK{cs * G::PS - jy * G::WS - jx, jy | ((4 + jx) << 8)};
-  }
+  __device__ BK b_k(int k) const { return BK{g_up_ktab<G, J, J>.off[k], g_up_ktab<G, J, J>.sh[k]}; }
   __device__ float b(const BK& k, const BN& n) const {
     const bool ok = ((n.mask >> (k.sh & 0xff)) & (n.mask >> (k.sh >> 8)) & 1u) != 0;
     const float v = small[ok ? n.off + k.off : 0];
@@ -348,6 +369,29 @@ __global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, int spli
   }
 }
 
+// Many splits, few outputs (the 3-channel layers: 613 slabs of 32x49): one wave per output,
+// lanes stride over the slabs, fixed-order shuffle reduction (still bit-reproducible).
+__global__ void conv_slab_reduce_wave_kernel(const float* __restrict__ slab, int splits, int Mrows, int Ncols,
+                                             float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const int total = Mrows * (Ncols + 1);
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < total; i += gridDim.x * wpb) {
+    float s = 0.f;
+    for (int z = lane; z < splits; z += 64) s += slab[(size_t)z * total + i];
+    s = wave_sum(s);
+    if (lane == 0) {
+      const int m = i / (Ncols + 1), n = i % (Ncols + 1);
+      if (n < Ncols) {
+        float* p = dw + (size_t)m * Ncols + n;
+        *p = accumulate ? *p + s : s;
+      } else if (db) {
+        db[m] = accumulate ? db[m] + s : s;
+      }
+    }
+  }
+}
+
 __global__ void partial_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ out, int accumulate) {
   __shared__ float red[16];
   float s = 0.f;
@@ -393,6 +437,7 @@ struct TileFor {
                                          typename std::conditional<(G::CS <= 64), T64x128, T128x128>::type>::type;
   using Up = typename std::conditional<(G::CB <= 32), T32x256,
                                        typename std::conditional<(G::CB <= 64), T64x128, T128x128>::type>::type;
+  // measured: 64x64 tiles beat 64x128 / 128x128 for the split-K weight gradients (occupancy)
   using Wgrad = typename std::conditional<(G::CS <= 32), T32x128, T64x64>::type;
 };
 
@@ -459,9 +504,14 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
   int rc = launch_igemm<typename TileFor<G>::Wgrad>(op, G::CS, G::CB * G::KK + 1, splits, s);
   if (rc) return rc;
   const int total = G::CS * (G::CB * G::KK + 1);
-  const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
-  hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, splits, G::CS,
-                     G::CB * G::KK, dw, db, accumulate);
+  if (splits >= 64 && total <= 65536) {
+    hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(total, 4)), dim3(256), 0, s, (const float*)ws, splits,
+                       G::CS, G::CB * G::KK, dw, db, accumulate);
+  } else {
+    const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
+    hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, splits, G::CS,
+                       G::CB * G::KK, dw, db, accumulate);
+  }
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }
