@@ -37,8 +37,8 @@ __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * rcp_fas
 // u8 pixel -> [-1,1], same expression/rounding as common/utils.py:79 ((x/255)*2)-1
 __device__ __forceinline__ float pix_norm(uint8_t v) { return ((float)v / 255.f) * 2.f - 1.f; }
 
-__device__ __forceinline__ float load_as_float(const float* p, int i) { return p[i]; }
-__device__ __forceinline__ float load_as_float(const uint8_t* p, int i) { return pix_norm(p[i]); }
+__device__ __forceinline__ float load_as_float(const float* p, unsigned i) { return p[i]; }
+__device__ __forceinline__ float load_as_float(const uint8_t* p, unsigned i) { return pix_norm(p[i]); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -97,14 +97,14 @@ struct ConvDownOp {
   __device__ int kend() const { return G::CB * G::KK; }
   __device__ AM a_m(int m) const { return m * (G::CB * G::KK); }
   __device__ AK a_k(int k) const { return k; }
-  __device__ float a(const AM& m, const AK& k) const { return w[m + k]; }
+  __device__ float a(const AM& m, const AK& k) const { return w[(unsigned)(m + k)]; }
   // big[img][cb][2sy+ky][2sx+kx] = big[ nOff(img,sy,sx) + kOff(cb,ky,kx) ]
   __device__ BN b_n(int n) const {
     const int img = n / G::PS, p = n % G::PS;
     return (img * G::CB * G::HB + 2 * (p / G::WS)) * G::WB + 2 * (p % G::WS);
   }
   __device__ BK b_k(int k) const { return g_down_ktab<G>.v[k]; }
-  __device__ float b(const BK& k, const BN& n) const { return load_as_float(big, n + k); }
+  __device__ float b(const BK& k, const BN& n) const { return load_as_float(big, (unsigned)(n + k)); }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
     const int img = n / G::PS, p = n % G::PS;
     const int o0 = (img * G::CS + mb) * G::PS + p;
@@ -154,7 +154,7 @@ struct ConvUpOp {
     const int cs = k / JJ, r = k % JJ;
     return cs * (G::CB * G::KK) + (PY + 2 * (r / JX)) * G::KS + PX + 2 * (r % JX);
   }
-  __device__ float a(const AM& m, const AK& k) const { return w[m + k]; }
+  __device__ float a(const AM& m, const AK& k) const { return w[(unsigned)(m + k)]; }
   // small[img][cs][y-jy][x-jx] = small[ nOff(img,y,x) + kOff(cs,jy,jx) ] where the tap exists
   __device__ BN b_n(int n) const {
     const int img = n / (NY * NX), q = n % (NY * NX);
@@ -170,7 +170,7 @@ struct ConvUpOp {
   __device__ BK b_k(int k) const { return BK{g_up_ktab<G, JY, JX>.off[k], g_up_ktab<G, JY, JX>.sh[k]}; }
   __device__ float b(const BK& k, const BN& n) const {
     const bool ok = ((n.mask >> (k.sh & 0xff)) & (n.mask >> (k.sh >> 8)) & 1u) != 0;
-    const float v = small[ok ? n.off + k.off : 0];
+    const float v = small[(unsigned)(ok ? n.off + k.off : 0)];
     return ok ? v : 0.f;
   }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
@@ -242,7 +242,7 @@ struct ConvUpMergedOp {
   }
   __device__ float a(const AM& m, const AK& k) const {
     const bool ok = (m.py + k.jy2 < G::KS) && (m.px + k.jx2 < G::KS);
-    const float v = w[ok ? m.off + k.off : 0];
+    const float v = w[(unsigned)(ok ? m.off + k.off : 0)];
     return ok ? v : 0.f;
   }
   __device__ BN b_n(int n) const {
@@ -259,7 +259,7 @@ struct ConvUpMergedOp {
   __device__ BK b_k(int k) const { return BK{g_up_ktab<G, J, J>.off[k], g_up_ktab<G, J, J>.sh[k]}; }
   __device__ float b(const BK& k, const BN& n) const {
     const bool ok = ((n.mask >> (k.sh & 0xff)) & (n.mask >> (k.sh >> 8)) & 1u) != 0;
-    const float v = small[ok ? n.off + k.off : 0];
+    const float v = small[(unsigned)(ok ? n.off + k.off : 0)];
     return ok ? v : 0.f;
   }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
@@ -327,7 +327,7 @@ struct ConvWgradOp {
   // small[img][m][p] = small[ m*PS + kOff(img,p) ]
   __device__ AM a_m(int m) const { return m * G::PS; }
   __device__ AK a_k(int k) const { return (k / G::PS) * (G::CS * G::PS) + k % G::PS; }
-  __device__ float a(const AM& m, const AK& k) const { return small[m + k]; }
+  __device__ float a(const AM& m, const AK& k) const { return small[(unsigned)(m + k)]; }
   // big[img][cb][2sy+ky][2sx+kx] = big[ kOff(img,sy,sx) + nOff(cb,ky,kx) ]
   __device__ BN b_n(int n) const {
     const int nc = min(n, NW - 1);
@@ -339,7 +339,7 @@ struct ConvWgradOp {
     return (img * G::CB * G::HB + 2 * (p / G::WS)) * G::WB + 2 * (p % G::WS);
   }
   __device__ float b(const BK& k, const BN& n) const {
-    const float v = load_as_float(big, k + n.off);
+    const float v = load_as_float(big, (unsigned)(k + n.off));
     return n.one ? 1.f : v;
   }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {

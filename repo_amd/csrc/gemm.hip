@@ -30,10 +30,10 @@ struct GemmOp {
   __device__ int kend() const { return K_; }
   __device__ AM a_m(int m) const { return TA ? m : m * lda; }
   __device__ AK a_k(int k) const { return TA ? k * lda : k; }
-  __device__ float a(const AM& m, const AK& k) const { return A[m + k]; }
+  __device__ float a(const AM& m, const AK& k) const { return A[(unsigned)(m + k)]; }
   __device__ BN b_n(int n) const { return TB ? n * ldb : n; }
   __device__ BK b_k(int k) const { return TB ? k : k * ldb; }
-  __device__ float b(const BK& k, const BN& n) const { return B[k + n]; }
+  __device__ float b(const BK& k, const BN& n) const { return B[(unsigned)(k + n)]; }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
     const float bv = bias ? bias[bias_div == 1 ? n : n / bias_div] : 0.f;
     float* c = C + mb * ldc + n;
@@ -103,11 +103,11 @@ struct WgradOp {
   __device__ int kend() const { return ke; }
   __device__ AM a_m(int m) const { return m; }
   __device__ AK a_k(int k) const { return k * lddy; }
-  __device__ float a(const AM& m, const AK& k) const { return dY[m + k]; }
+  __device__ float a(const AM& m, const AK& k) const { return dY[(unsigned)(m + k)]; }
   __device__ BN b_n(int n) const { return BN{min(n, K_ - 1), n == K_}; }
   __device__ BK b_k(int k) const { return k * ldx; }
   __device__ float b(const BK& k, const BN& n) const {
-    const float v = X[k + n.off];
+    const float v = X[(unsigned)(k + n.off)];
     return n.one ? 1.f : v;
   }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {

@@ -183,21 +183,38 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
       if (kt + BK <= kend) gload(kt, set_c, std::false_type{});
       else gload(kt, set_c, std::true_type{});
     };
+    // interior workgroups (whole tile inside M x N, K a multiple of BK) skip the zero-fill selects
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && ((kend - kbeg) % BK == 0);
     auto lstore = [&](int buf, auto set_c) __attribute__((always_inline)) {
       constexpr int S = decltype(set_c)::value;
       float* as = As + buf * BK * LDA;
       float* bs = Bs + buf * BK * LDB;
+      if (interior) {
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) {
-        const int kk = Op::A_KMAJOR ? (tid % BK) : (tid / BM + j * (NT / BM));
-        const int mm = Op::A_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BM);
-        as[kk * LDA + mm] = ((amask[S] >> j) & 1u) ? ra[S][j] : 0.f;
-      }
+        for (int j = 0; j < A_PER; ++j) {
+          const int kk = Op::A_KMAJOR ? (tid % BK) : (tid / BM + j * (NT / BM));
+          const int mm = Op::A_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BM);
+          as[kk * LDA + mm] = ra[S][j];
+        }
 #pragma unroll
-      for (int j = 0; j < B_PER; ++j) {
-        const int kk = Op::B_KMAJOR ? (tid % BK) : (tid / BN + j * (NT / BN));
-        const int nn = Op::B_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BN);
-        bs[kk * LDB + nn] = ((bmask[S] >> j) & 1u) ? rb[S][j] : 0.f;
+        for (int j = 0; j < B_PER; ++j) {
+          const int kk = Op::B_KMAJOR ? (tid % BK) : (tid / BN + j * (NT / BN));
+          const int nn = Op::B_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BN);
+          bs[kk * LDB + nn] = rb[S][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+          const int kk = Op::A_KMAJOR ? (tid % BK) : (tid / BM + j * (NT / BM));
+          const int mm = Op::A_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BM);
+          as[kk * LDA + mm] = ((amask[S] >> j) & 1u) ? ra[S][j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+          const int kk = Op::B_KMAJOR ? (tid % BK) : (tid / BN + j * (NT / BN));
+          const int nn = Op::B_KMAJOR ? (tid / BK + j * (NT / BK)) : (tid % BN);
+          bs[kk * LDB + nn] = ((bmask[S] >> j) & 1u) ? rb[S][j] : 0.f;
+        }
       }
     };
     auto compute = [&](int buf) __attribute__((always_inline)) {
