@@ -359,7 +359,7 @@ class OracleAgent:
         self.last["imagine"] = [x.detach() for x in (ib, istate, im, isd)]
         self.last["returns"] = returns.detach()
         return {
-            "train/actor_loss": float(actor_loss),
+            "train/actor_loss": float(actor_loss.detach()),
             "train/value_loss": float(value_loss),
             "train/action_entropy": float(action_entropy),
             "train/latent_entropy": float(latent_entropy),
