@@ -199,7 +199,7 @@ int repo_actor_head_fwd(int64_t rows, int64_t A, int64_t S, const float* raw, co
 int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, const float* dstd,
                         const float* daction, int64_t ldda, const float* action, int64_t ldact,
                         const float* eps, const float* mean, const float* std, float min_std,
-                        float mean_scale, float* draw, hipStream_t stream);
+                        float mean_scale, float* draw, int accumulate, hipStream_t stream);
 
 /* ------------------------------------------------------------------ imagination rollout
  * TransitionModel.imagine(prev_belief, prev_state, actor, horizon) (models/rssm.py:148-184)
@@ -209,8 +209,9 @@ int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, const float
  * eps_act (Hm,N,A) then eps_prior (Hm,N,S) per step, in the reference's draw order.
  * Outputs: featx (Hm+1,N,D+S), slot 0 = start, slot t+1 = [belief|prior sample];
  *          prior_mean/std (Hm,N,S).
- * Saved  : a_hidden (n_actor_layers-1, Hm*N, Hd), a_raw (Hm*N,2A), a_mean/a_std (Hm*N,A),
- *          xsa (Hm*N,S+A), e (Hm*N,D), gates (Hm*N,4D), hp (Hm*N,Hd). */
+ * Saved  : a_hidden (n_actor_layers-1, a_layer_rows, Hd) with a_layer_rows >= Hm*N (row stride of a
+ *          layer, so the caller can keep one spare step slot behind the rollout's rows), a_raw
+ *          (Hm*N,2A), a_mean/a_std (Hm*N,A), xsa (Hm*N,S+A), e (Hm*N,D), gates (Hm*N,4D), hp (Hm*N,Hd). */
 size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                              int64_t S);
 int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
@@ -218,9 +219,9 @@ int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t H
                           const float* const* actor_params, const float* belief0, const float* state0,
                           const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
                           float a_init_std, float a_mean_scale, float* featx, float* prior_mean,
-                          float* prior_std, float* a_hidden, float* a_raw, float* a_mean, float* a_std,
-                          float* xsa, float* e, float* gates, float* hp, void* ws, size_t ws_bytes,
-                          hipStream_t stream);
+                          float* prior_std, float* a_hidden, int64_t a_layer_rows, float* a_raw,
+                          float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp,
+                          void* ws, size_t ws_bytes, hipStream_t stream);
 /* Reverse pass with frozen world-model weights: dfeat (Hm,N,D+S) is the gradient w.r.t.
  * featx[1:] (from the heads and the entropy term), dprior_mean/std nullable.  Emits
  * d_araw (Hm*N,2A), the gradient at the actor trunk's output of every step (the caller

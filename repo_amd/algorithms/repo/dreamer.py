@@ -252,14 +252,21 @@ class Dreamer:
         # -- imagine (world model frozen, actor inputs detached)
         sv = ops.rssm_imagine_fwd(
             pr, pa, beliefs.contiguous(), posterior_states.contiguous(), self._noise("img_act", (Hm, N, A)),
-            self._noise("img_prior", (Hm, N, S)), self.transition_model.min_std_dev, *a_consts,
+            self._noise("img_prior", (Hm, N, S)), self.transition_model.min_std_dev, *a_consts, spare_slot=True,
         )
         feats = sv.featx[1:].reshape(Hm * N, F_)
         r_pred, r_hid = ops.mlp_fwd(pw, feats)
         v_pred, v_hid = ops.mlp_fwd(pv, feats)
-        # -- action entropy on the (attached) imagined states: 100-sample Monte-Carlo estimate
-        raw2, a2_hid = ops.mlp_fwd(pa, feats)
-        mean2, std2, _ = ops.actor_head_fwd(raw2, *a_consts)
+        # -- action entropy on the (attached) imagined states (dreamer.py:320-324).  The reference
+        #    re-runs the actor on imag[0..Hm-1]; rows of steps 1..Hm-1 are the very inputs the rollout
+        #    already pushed through the actor (detaching does not change values), so only the final
+        #    state is evaluated here, into the spare step slot of the rollout's saved activations.
+        nl = sv.a_hidden.shape[0]
+        tail = slice(Hm * N, (Hm + 1) * N)
+        ops.mlp_fwd(pa, sv.featx[Hm], out=sv.a_raw[tail], hid=[sv.a_hidden[l, tail] for l in range(nl)])
+        ops.actor_head_fwd(sv.a_raw[tail], *a_consts, mean=sv.a_mean[tail], std=sv.a_std[tail])
+        ent_rows = slice(N, (Hm + 1) * N)  # imagined steps 1..Hm
+        mean2, std2 = sv.a_mean[ent_rows], sv.a_std[ent_rows]
         eps_ent = self._noise("entropy", (am._samples, Hm * N, A))
         ent_sum, dmean2, dstd2 = ops.tanh_normal_entropy(mean2, std2, eps_ent, gscale=-c.action_ent_coef / (Hm * gN))
         lat_sum, dpstd = ops.normal_entropy(sv.prior_std, gscale=-c.latent_ent_coef / (Hm * gN),
@@ -268,17 +275,24 @@ class Dreamer:
         gret = -1.0 / ((Hm - 1) * gN)
         returns, dr, dv, ret_sum = ops.lambda_return(r_pred.view(Hm, N), v_pred.view(Hm, N), c.gamma, c.gae_lambda,
                                                      gret)
-        # -- backward: heads -> entropy path -> reverse rollout -> actor trunk over all steps
+        # -- backward: heads -> entropy path (input gradient only) -> reverse rollout
         dfeat = torch.empty(Hm * N, F_, device=dev)
         ops.mlp_bwd(pw, feats, r_hid, dr.view(Hm * N, 1), dparams=None, dx=dfeat)
         ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat, accumulate_dx=True)
+        # gradient at the actor trunk's output, all (Hm+1)*N rows: rollout path on steps 0..Hm-1
+        # (written by the reverse rollout), entropy path on steps 1..Hm (added on top)
+        d_out = torch.zeros((Hm + 1) * N, 2 * A, device=dev)
         draw2 = ops.actor_head_bwd(mean2, std2, dmean=dmean2, dstd=dstd2, min_std=a_consts[0], mean_scale=a_consts[2])
-        ops.mlp_bwd(pa, feats, a2_hid, draw2, dparams=ga, accumulate_w=False, dx=dfeat, accumulate_dx=True)
-        d_araw, _ = ops.rssm_imagine_bwd(pr, sv, dfeat, dprior_std=dpstd, min_std=self.transition_model.min_std_dev,
-                                         a_min_std=a_consts[0], a_mean_scale=a_consts[2])
-        x_act = sv.featx[:Hm].reshape(Hm * N, F_)
-        a_hid = [sv.a_hidden[l] for l in range(sv.a_hidden.shape[0])]
-        ops.mlp_bwd(pa, x_act, a_hid, d_araw, dparams=ga, accumulate_w=True, dx=None)
+        ops.mlp_bwd(pa, feats, [sv.a_hidden[l, ent_rows] for l in range(nl)], draw2, dparams=None, dx=dfeat,
+                    accumulate_dx=True)
+        ops.rssm_imagine_bwd(pr, sv, dfeat, dprior_std=dpstd, min_std=self.transition_model.min_std_dev,
+                             a_min_std=a_consts[0], a_mean_scale=a_consts[2], d_araw=d_out)
+        ops.actor_head_bwd(mean2, std2, dmean=dmean2, dstd=dstd2, min_std=a_consts[0], mean_scale=a_consts[2],
+                           out=d_out[ent_rows], accumulate=True)
+        # -- ONE actor-trunk backward over every row the actor saw: both gradient paths share the
+        #    same forward activations, and the chain is linear in the output gradient
+        x_all = sv.featx.reshape((Hm + 1) * N, F_)
+        ops.mlp_bwd(pa, x_all, [sv.a_hidden[l] for l in range(nl)], d_out, dparams=ga, accumulate_w=False, dx=None)
         self._allreduce(self.actor_optimizer.grad)
         self.actor_optimizer.clip_and_step(c.grad_clip_norm)
         # -- critic on detached imag[:-1] against detached returns (dreamer.py:362-373).  The value

@@ -49,7 +49,7 @@ __global__ void actor_head_bwd_kernel(int rows, int A, const float* __restrict__
                                       const float* __restrict__ daction, int ldda, const float* __restrict__ action,
                                       int ldact, const float* __restrict__ eps, const float* __restrict__ mean,
                                       const float* __restrict__ stdv, float min_std, float mean_scale,
-                                      float* __restrict__ draw) {
+                                      float* __restrict__ draw, int accumulate) {
   const int total = rows * A;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int row = i / A, a = i % A;
@@ -61,8 +61,10 @@ __global__ void actor_head_bwd_kernel(int rows, int A, const float* __restrict__
       gs = fmaf(du, eps[i], gs);
     }
     const float tm = mean[i] / mean_scale;  // tanh(raw_m / ms)
-    draw[(size_t)row * 2 * A + a] = gm * (1.f - tm * tm);
-    draw[(size_t)row * 2 * A + A + a] = gs * (-expm1f(-(stdv[i] - min_std)));
+    const float v0 = gm * (1.f - tm * tm), v1 = gs * (-expm1f(-(stdv[i] - min_std)));
+    float* d0 = draw + (size_t)row * 2 * A + a;
+    d0[0] = accumulate ? d0[0] + v0 : v0;
+    d0[A] = accumulate ? d0[A] + v1 : v1;
   }
 }
 
@@ -183,8 +185,9 @@ size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
 int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
                       const float* const* ap, const float* belief0, const float* state0, const float* eps_act,
                       const float* eps_prior, float min_std, float a_min_std, float a_init_std, float a_mean_scale,
-                      float* featx, float* prior_mean, float* prior_std, float* a_hidden, float* a_raw, float* a_mean,
-                      float* a_std, float* xsa, float* e, float* gates, float* hp, void* ws, hipStream_t stream);
+                      float* featx, float* prior_mean, float* prior_std, float* a_hidden, int64_t a_layer_rows,
+                      float* a_raw, float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp, void* ws,
+                      hipStream_t stream);
 int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
                       const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
                       float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
@@ -279,11 +282,11 @@ extern "C" int repo_actor_head_fwd(int64_t rows, int64_t A, int64_t S, const flo
 extern "C" int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, const float* dstd,
                                    const float* daction, int64_t ldda, const float* action, int64_t ldact,
                                    const float* eps, const float* mean, const float* std, float min_std,
-                                   float mean_scale, float* draw, hipStream_t stream) {
+                                   float mean_scale, float* draw, int accumulate, hipStream_t stream) {
   REPO_REQUIRE(rows > 0 && A > 0 && rows * 2 * A < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(mean && std && draw && (!daction || (action && eps)), REPO_E_BADARG);
   hipLaunchKernelGGL(actor_head_bwd_kernel, dim3(ew_blocks(rows * A)), dim3(256), 0, stream, (int)rows, (int)A, dmean,
-                     dstd, daction, (int)ldda, action, (int)ldact, eps, mean, std, min_std, mean_scale, draw);
+                     dstd, daction, (int)ldda, action, (int)ldact, eps, mean, std, min_std, mean_scale, draw, accumulate);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }
@@ -306,10 +309,11 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                                      const float* const* actor_params, const float* belief0, const float* state0,
                                      const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
                                      float a_init_std, float a_mean_scale, float* featx, float* prior_mean,
-                                     float* prior_std, float* a_hidden, float* a_raw, float* a_mean, float* a_std,
-                                     float* xsa, float* e, float* gates, float* hp, void* ws, size_t ws_bytes,
-                                     hipStream_t stream) {
+                                     float* prior_std, float* a_hidden, int64_t a_layer_rows, float* a_raw,
+                                     float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp,
+                                     void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_REQUIRE(img_dims_ok(Hm, N, A, D, Hd, S) && n_actor_layers >= 2 && n_actor_layers <= 8, REPO_E_SHAPE);
+  REPO_REQUIRE(a_layer_rows >= Hm * N, REPO_E_SHAPE);
   REPO_REQUIRE(rssm_params && actor_params && belief0 && state0 && eps_act && eps_prior && featx && prior_mean &&
                    prior_std && a_hidden && a_raw && a_mean && a_std && xsa && e && gates && hp,
                REPO_E_BADARG);
@@ -317,7 +321,7 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
   if (imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers))
     return imagine_fused_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0, eps_act, eps_prior,
                              min_std, a_min_std, a_init_std, a_mean_scale, featx, prior_mean, prior_std, a_hidden,
-                             a_raw, a_mean, a_std, xsa, e, gates, hp, ws, stream);
+                             a_layer_rows, a_raw, a_mean, a_std, xsa, e, gates, hp, ws, stream);
   const int64_t F = D + S, X = S + A, rowsAll = Hm * N;
   const float* const* P = rssm_params;
   float* gi = (float*)ws;
@@ -335,7 +339,7 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
     const size_t r0 = (size_t)t * N;
     // actor MLP on (detached) [belief, state]
     float* hid[8];
-    for (int l = 0; l < n_actor_layers - 1; ++l) hid[l] = a_hidden + ((size_t)l * rowsAll + r0) * Hd;
+    for (int l = 0; l < n_actor_layers - 1; ++l) hid[l] = a_hidden + ((size_t)l * a_layer_rows + r0) * Hd;
     REPO_RC(repo_mlp_fwd(N, F, Hd, 2 * A, n_actor_layers, ft, F, actor_params, hid, a_raw + r0 * 2 * A, 2 * A, stream));
     REPO_RC(repo_actor_head_fwd(N, A, S, a_raw + r0 * 2 * A, eps_act + r0 * A, ft + D, F, a_min_std, a_init_std,
                                 a_mean_scale, a_mean + r0 * A, a_std + r0 * A, xsa + r0 * X, stream));
@@ -420,7 +424,7 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                        (const float*)nullptr, 0, carry + D, (int)F);
     REPO_CHECK_LAUNCH();
     REPO_RC(repo_actor_head_bwd(N, A, nullptr, nullptr, dxsa + S, X, xsa + r0 * X + S, X, eps_act + r0 * A,
-                                a_mean + r0 * A, a_std + r0 * A, a_min_std, a_mean_scale, d_araw + r0 * 2 * A, stream));
+                                a_mean + r0 * A, a_std + r0 * A, a_min_std, a_mean_scale, d_araw + r0 * 2 * A, 0, stream));
     have_carry = true;
     (void)dbel;
   }

@@ -112,6 +112,7 @@ struct ImgFwdArgs {
   const float *belief0, *state0, *eps_act, *eps_prior;
   float min_std, a_min_std, a_init_std, a_mean_scale;
   float *featx, *prior_mean, *prior_std, *a_hidden, *a_raw, *a_mean, *a_std, *xsa, *e, *gates, *hp;
+  size_t a_layer_rows;
 };
 
 __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
   const int li = lane & 31, lh = lane >> 5;
   const int r0 = blockIdx.x * kRows;
   const int nr = min(kRows, N - r0);
-  const size_t rowsAll = (size_t)Hm * N;
+  const size_t rowsAll = p.a_layer_rows;  // row stride between the saved actor layers
 
   // ---- slot 0: start states (row-major global -> [feature][row] LDS), also echoed to featx[0]
   for (int i = tid; i < kRows * F; i += blockDim.x) {
@@ -517,8 +518,8 @@ int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
                       const float* const* rp, const float* const* ap, const float* belief0, const float* state0,
                       const float* eps_act, const float* eps_prior, float min_std, float a_min_std, float a_init_std,
                       float a_mean_scale, float* featx, float* prior_mean, float* prior_std, float* a_hidden,
-                      float* a_raw, float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp,
-                      void* ws, hipStream_t stream) {
+                      int64_t a_layer_rows, float* a_raw, float* a_mean, float* a_std, float* xsa, float* e,
+                      float* gates, float* hp, void* ws, hipStream_t stream) {
   const int F = (int)(D + S), X = (int)(S + A);
   float* w = (float*)ws;
   ImgFwdArgs a;
@@ -547,6 +548,7 @@ int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
   a.min_std = min_std; a.a_min_std = a_min_std; a.a_init_std = a_init_std; a.a_mean_scale = a_mean_scale;
   a.featx = featx; a.prior_mean = prior_mean; a.prior_std = prior_std; a.a_hidden = a_hidden; a.a_raw = a_raw;
   a.a_mean = a_mean; a.a_std = a_std; a.xsa = xsa; a.e = e; a.gates = gates; a.hp = hp;
+  a.a_layer_rows = (size_t)a_layer_rows;
   const size_t lds_b = fwd_lds_bytes((int)A, (int)D, (int)Hd, (int)S);
   hipError_t he = hipFuncSetAttribute((const void*)imagine_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds_b);

@@ -279,14 +279,16 @@ def rssm_observe_bwd(params, sv, dparams, dfeat=None, dprior_state=None, dpm=Non
 
 
 # ----------------------------------------------------------------------------- MLP heads
-def mlp_fwd(params, x, out=None):
-    """params: [w1,b1,...,wL,bL]; x (rows, in_dim) view with contiguous rows.  Returns (out, hidden list)."""
+def mlp_fwd(params, x, out=None, hid=None):
+    """params: [w1,b1,...,wL,bL]; x (rows, in_dim) view with contiguous rows.  Returns (out, hidden list).
+    `hid`: optional caller-provided (rows, hidden) buffers for the L-1 hidden activations."""
     L = len(params) // 2
     rows, in_dim = x.shape
     hidden = params[0].shape[0] if L > 1 else 0
     out_dim = params[-2].shape[0]
     dev = x.device
-    hid = [torch.empty(rows, hidden, dtype=torch.float32, device=dev) for _ in range(L - 1)]
+    if hid is None:
+        hid = [torch.empty(rows, hidden, dtype=torch.float32, device=dev) for _ in range(L - 1)]
     if out is None:
         out = torch.empty(rows, out_dim, dtype=torch.float32, device=dev)
     pa, ha = ptr_array(params), ptr_array(hid)
@@ -315,12 +317,14 @@ def mlp_bwd(params, x, hid, dout, dparams=None, accumulate_w=False, dx=None, acc
     )
 
 
-def actor_head_fwd(raw, min_std=0.1, init_std=0.0, mean_scale=5.0, eps=None, state=None):
+def actor_head_fwd(raw, min_std=0.1, init_std=0.0, mean_scale=5.0, eps=None, state=None, mean=None, std=None):
     rows, A2 = raw.shape
     A = A2 // 2
     dev = raw.device
-    mean = torch.empty(rows, A, dtype=torch.float32, device=dev)
-    std = torch.empty(rows, A, dtype=torch.float32, device=dev)
+    if mean is None:
+        mean = torch.empty(rows, A, dtype=torch.float32, device=dev)
+    if std is None:
+        std = torch.empty(rows, A, dtype=torch.float32, device=dev)
     xsa = None
     S = 0
     if eps is not None:
@@ -335,14 +339,15 @@ def actor_head_fwd(raw, min_std=0.1, init_std=0.0, mean_scale=5.0, eps=None, sta
     return mean, std, xsa
 
 
-def actor_head_bwd(mean, std, dmean=None, dstd=None, daction=None, action=None, eps=None, min_std=0.1, mean_scale=5.0):
+def actor_head_bwd(mean, std, dmean=None, dstd=None, daction=None, action=None, eps=None, min_std=0.1, mean_scale=5.0,
+                   out=None, accumulate=False):
     rows, A = mean.shape
-    draw = torch.empty(rows, 2 * A, dtype=torch.float32, device=mean.device)
+    draw = out if out is not None else torch.empty(rows, 2 * A, dtype=torch.float32, device=mean.device)
     check(
         lib().repo_actor_head_bwd(rows, A, _ptr(dmean), _ptr(dstd), _ptr(daction),
                                   _ld(daction) if daction is not None else 0, _ptr(action),
                                   _ld(action) if action is not None else 0, _ptr(eps), _ptr(mean), _ptr(std), min_std,
-                                  mean_scale, _ptr(draw), _stream()),
+                                  mean_scale, _ptr(draw), int(accumulate), _stream()),
         "repo_actor_head_bwd",
     )
     return draw
@@ -355,7 +360,9 @@ class ImagineSaved:
 
 
 def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_prior, min_std=0.1, a_min_std=0.1,
-                     a_init_std=0.0, a_mean_scale=5.0):
+                     a_init_std=0.0, a_mean_scale=5.0, spare_slot=False):
+    """spare_slot: allocate the saved actor tensors with one extra step slot ((Hm+1)*N rows) so the
+    caller can evaluate the actor on the final imagined state into the same buffers."""
     Hm, N, A = eps_act.shape
     D, S = belief0.shape[1], state0.shape[1]
     Hd = rssm_params[6].shape[0]
@@ -366,8 +373,9 @@ def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_pr
     sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S = Hm, N, A, D, Hd, S
     sv.featx = f(Hm + 1, N, D + S)
     sv.prior_mean, sv.prior_std = f(Hm, N, S), f(Hm, N, S)
-    sv.a_hidden = f(La - 1, Hm * N, Hd)
-    sv.a_raw, sv.a_mean, sv.a_std = f(Hm * N, 2 * A), f(Hm * N, A), f(Hm * N, A)
+    ar = (Hm + 1) * N if spare_slot else Hm * N
+    sv.a_hidden = f(La - 1, ar, Hd)
+    sv.a_raw, sv.a_mean, sv.a_std = f(ar, 2 * A), f(ar, A), f(ar, A)
     sv.xsa, sv.e, sv.gates, sv.hp = f(Hm * N, S + A), f(Hm * N, D), f(Hm * N, 4 * D), f(Hm * N, Hd)
     sv.eps_act, sv.eps_prior = _f32c(eps_act), _f32c(eps_prior)
     nb = lib().repo_rssm_imagine_fwd_workspace_bytes(Hm, N, A, D, Hd, S)
@@ -377,7 +385,7 @@ def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_pr
         lib().repo_rssm_imagine_fwd(
             Hm, N, A, D, Hd, S, La, ra, aa, _ptr(_f32c(belief0)), _ptr(_f32c(state0)), _ptr(sv.eps_act),
             _ptr(sv.eps_prior), min_std, a_min_std, a_init_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_mean),
-            _ptr(sv.prior_std), _ptr(sv.a_hidden), _ptr(sv.a_raw), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
+            _ptr(sv.prior_std), _ptr(sv.a_hidden), ar, _ptr(sv.a_raw), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(ws), ws.numel(), _stream(),
         ),
         "repo_rssm_imagine_fwd",
@@ -386,9 +394,10 @@ def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_pr
 
 
 def rssm_imagine_bwd(rssm_params, sv, dfeat, dprior_mean=None, dprior_std=None, want_dfeat0=False, min_std=0.1,
-                     a_min_std=0.1, a_mean_scale=5.0):
+                     a_min_std=0.1, a_mean_scale=5.0, d_araw=None):
     dev = dfeat.device
-    d_araw = torch.empty(sv.Hm * sv.N, 2 * sv.A, dtype=torch.float32, device=dev)
+    if d_araw is None:
+        d_araw = torch.empty(sv.Hm * sv.N, 2 * sv.A, dtype=torch.float32, device=dev)
     dfeat0 = torch.empty(sv.N, sv.D + sv.S, dtype=torch.float32, device=dev) if want_dfeat0 else None
     nb = lib().repo_rssm_imagine_bwd_workspace_bytes(sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S)
     ws = workspace(nb, dev)
