@@ -230,9 +230,13 @@ struct ConvUpMergedOp {
   __device__ int N() const { return nimg * NY * NX; }
   __device__ int kbeg() const { return 0; }
   __device__ int kend() const { return G::CS * JJ; }
+  // M index = (py, cb, px) with px fastest: two consecutive accumulator registers of a lane are the
+  // two horizontally adjacent output pixels, so the epilogue stores them as one 8-byte word and a
+  // wave writes whole 256-byte runs (the separate px classes wrote every line twice, half each:
+  // WRITE_SIZE was 2.0x the tensor).
   __device__ AM a_m(int m) const {
-    const int cls = m / G::CB, cb = m % G::CB;
-    const int py = cls >> 1, px = cls & 1;
+    const int py = m / (2 * G::CB), rem = m % (2 * G::CB);
+    const int cb = rem >> 1, px = rem & 1;
     return AM{cb * G::KK + py * G::KS + px, py, px};
   }
   __device__ AK a_k(int k) const {
@@ -267,22 +271,41 @@ struct ConvUpMergedOp {
     const int y2 = 2 * (q / NX), x2 = 2 * (q % NX);
     const int obase = img * G::CB * G::PB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = mb + (r & 3) + 8 * (r >> 2);
+    for (int r = 0; r < 16; r += 2) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);  // even: px = 0; register r+1 is px = 1
       if (m < M) {
-        const int cls = m / G::CB, cb = m % G::CB;
-        const int by = y2 + (cls >> 1), bx = x2 + (cls & 1);
-        if (by < G::HB && bx < G::WB) {
-          const int o = obase + (cb * G::HB + by) * G::WB + bx;
-          float v = acc[r];
+        const int py = m / (2 * G::CB), cb = (m % (2 * G::CB)) >> 1;
+        const int by = y2 + py;
+        if (by < G::HB && x2 < G::WB) {
+          const int o = obase + (cb * G::HB + by) * G::WB + x2;
+          const bool two = x2 + 1 < G::WB;
+          float v0 = acc[r], v1 = acc[r + 1];
           if (MODE == 0) {
-            out[o] = epi_apply(v, epi, bias, cb, aux, o);
+            v0 = epi_apply(v0, epi, bias, cb, aux, o);
+            if (two) v1 = epi_apply(v1, epi, bias, cb, aux, o + 1);
           } else {
-            if (bias) v += bias[cb];
-            const float d = v - load_as_float(target, o);
-            if (out) out[o] = v;
-            if (dpre) dpre[o] = d * grad_scale;
-            lsum += 0.5f * d * d;
+            const float bv = bias ? bias[cb] : 0.f;
+            v0 += bv;
+            v1 += bv;
+            const float d0 = v0 - load_as_float(target, (unsigned)o);
+            const float d1 = two ? v1 - load_as_float(target, (unsigned)(o + 1)) : 0.f;
+            lsum += 0.5f * (d0 * d0 + d1 * d1);
+            if (dpre) {
+              if (G::WB % 2 == 0) {
+                *reinterpret_cast<float2*>(dpre + o) = make_float2(d0 * grad_scale, d1 * grad_scale);
+              } else {
+                dpre[o] = d0 * grad_scale;
+                if (two) dpre[o + 1] = d1 * grad_scale;
+              }
+            }
+          }
+          if (out) {
+            if (G::WB % 2 == 0) {
+              *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
+            } else {
+              out[o] = v0;
+              if (two) out[o + 1] = v1;
+            }
           }
         }
       }

@@ -37,9 +37,12 @@ namespace repo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM_, int WN_, int TM_, int TN_, int BK_ = 16>
+template <int WM_, int WN_, int TM_, int TN_, int BK_ = 16, int SETS_ = 2>
 struct TileCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
+  // register staging sets: 2 = loads issued two slices ahead (launches with <= 1 workgroup per CU),
+  // 1 = one slice ahead, 32-64 fewer VGPRs (compute-bound launches that rely on occupancy instead)
+  static constexpr int SETS = SETS_;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static constexpr int NT = WM * WN * 64;
   static_assert(BK % 2 == 0, "BK must be even (mfma 32x32x2)");
@@ -48,6 +51,8 @@ struct TileCfg {
 };
 
 using T128x128 = TileCfg<2, 2, 2, 2>;
+using T128x128s1 = TileCfg<2, 2, 2, 2, 16, 1>;
+using T64x128s1 = TileCfg<2, 2, 1, 2, 16, 1>;
 using T64x128 = TileCfg<2, 2, 1, 2>;
 using T64x64 = TileCfg<2, 2, 1, 1>;
 using T32x128 = TileCfg<1, 4, 1, 1>;
@@ -248,7 +253,21 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
     // later counted wait collapse to vmcnt(0) and drains the prefetch.  Re-loading the last
     // slice once or twice at the tail is cheaper than losing the overlap everywhere.
     auto slice_k = [&](int t) __attribute__((always_inline)) { return kbeg + min(t, nt - 1) * BK; };
-    if (nt > 0) {
+    if (nt > 0 && T::SETS == 1) {
+      gload_any(slice_k(0), S0{});
+      lstore(0, S0{});
+      __syncthreads();
+      int buf = 0;
+      for (int t = 0; t < nt; ++t) {
+        gload_any(slice_k(t + 1), S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(buf ^ 1, S0{});
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else if (nt > 0) {
       gload_any(slice_k(0), S0{});
       lstore(0, S0{});
       gload_any(slice_k(1), S1{});
