@@ -65,6 +65,7 @@ class Dreamer:
         self.free_nats = torch.full((1,), float(config.free_nats), device=self.device)
         self._scal = torch.zeros(32, dtype=torch.float32, device=self.device)
         self._side_stream = torch.cuda.Stream(device=self.device)
+        self._wgrad_stream = torch.cuda.Stream(device=self.device)
         self.last_scalars = {}
 
     # ------------------------------------------------------------------ construction
@@ -204,9 +205,9 @@ class Dreamer:
         with torch.cuda.stream(side):
             ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
                                  min_std=self.transition_model.min_std_dev)
-        Fn.decoder_bwd(pd, feat, st["dec_saved"], gd)
+        Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, side=self._wgrad_stream)
         main.wait_stream(side)
-        Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge)
+        Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
 
     def _model_step(self):
         self._allreduce(self.model_optimizer.grad)

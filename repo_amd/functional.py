@@ -20,18 +20,44 @@ def encoder_fwd(p, obs):
     return h4.view(-1, 1024), (h1, h2, h3, h4)
 
 
-def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False):
+class _Fork:
+    """Runs weight-gradient kernels on a side stream while the data-gradient chain (the critical
+    path) continues on the current stream.  A weight gradient of layer l and the data gradient
+    into layer l-1 both only READ d pre_l, so they are independent; on their own each of these
+    kernels leaves the matrix pipe ~40% idle (barrier / load phases), and two resident kernels
+    fill each other's gaps."""
+
+    def __init__(self, side):
+        self.side = side
+        self.main = torch.cuda.current_stream() if side is not None else None
+
+    def run(self, fn):
+        if self.side is None:
+            fn()
+            return
+        self.side.wait_stream(self.main)  # everything fn reads has been enqueued on main
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+
+
+def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False, side=None):
     """Gradients of all eight encoder tensors into g (same order as p)."""
     h1, h2, h3, h4 = saved
     n = h4.shape[0]
+    fk = _Fork(side)
     d4 = ops.relu_mask(dembeds.reshape(n, 256, 2, 2).contiguous(), h4)
-    ops.conv_wgrad(ops.ENC4, d4, h3, dw=g[6], db=g[7], accumulate=accumulate)
+    fk.run(lambda: ops.conv_wgrad(ops.ENC4, d4, h3, dw=g[6], db=g[7], accumulate=accumulate))
     d3 = ops.conv_up(ops.ENC4, d4, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h3)
-    ops.conv_wgrad(ops.ENC3, d3, h2, dw=g[4], db=g[5], accumulate=accumulate)
+    fk.run(lambda: ops.conv_wgrad(ops.ENC3, d3, h2, dw=g[4], db=g[5], accumulate=accumulate))
     d2 = ops.conv_up(ops.ENC3, d3, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h2)
-    ops.conv_wgrad(ops.ENC2, d2, h1, dw=g[2], db=g[3], accumulate=accumulate)
+    fk.run(lambda: ops.conv_wgrad(ops.ENC2, d2, h1, dw=g[2], db=g[3], accumulate=accumulate))
     d1 = ops.conv_up(ops.ENC2, d2, p[2], None, epi=ops.EPI_MUL_DRELU, aux=h1)
     ops.conv_wgrad(ops.ENC1, d1, obs, dw=g[0], db=g[1], accumulate=accumulate)
+    fk.join()
 
 
 # ----------------------------------------------------------------------------- decoder
@@ -62,25 +88,43 @@ def decoder_fwd_nll(p, feat, target, grad_scale):
     return loss_sum, (h0, h1, h2, h3, dpre4)
 
 
-def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False):
+def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None):
     """Backward from d recon (= saved[4]) to all ten decoder tensors (into g) and, if dfeat is
     given (Dreamer's attached decoder, dreamer.py:262), to the [belief|state] input."""
     h0, h1, h2, h3, d4 = saved
     rows = feat.shape[0]
-    ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
-    ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+    fk = _Fork(side)
+
+    def w4():
+        ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+
+    fk.run(w4)
     d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
-    ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
-    ops.channel_sum(d3, out=g[7], accumulate=accumulate)
+
+    def w3():
+        ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d3, out=g[7], accumulate=accumulate)
+
+    fk.run(w3)
     d2 = ops.conv_down(ops.DEC3, d3, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h2)
-    ops.conv_wgrad(ops.DEC2, h1, d2, dw=g[4], db=None, accumulate=accumulate, want_bias=False)
-    ops.channel_sum(d2, out=g[5], accumulate=accumulate)
+
+    def w2():
+        ops.conv_wgrad(ops.DEC2, h1, d2, dw=g[4], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d2, out=g[5], accumulate=accumulate)
+
+    fk.run(w2)
     d1 = ops.conv_down(ops.DEC2, d2, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h1)
     d1f = d1.view(rows, 128 * 25)
     w1 = p[2].view(p[2].shape[0], -1)
-    ops.gemm_wgrad(h0, d1f, dW=g[2].view(w1.shape), db=None, accumulate=accumulate, want_bias=False)
-    ops.channel_sum(d1.view(rows, 128, 25), out=g[3], accumulate=accumulate)
+
+    def w1f():
+        ops.gemm_wgrad(h0, d1f, dW=g[2].view(w1.shape), db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d1.view(rows, 128, 25), out=g[3], accumulate=accumulate)
+
+    fk.run(w1f)
     dh0 = ops.gemm(d1f, w1, transb=True)
     ops.gemm_wgrad(dh0, feat, dW=g[0], db=g[1], accumulate=accumulate)
     if dfeat is not None:
         ops.gemm(dh0, p[0], out=dfeat, accumulate=accumulate_dfeat)
+    fk.join()
