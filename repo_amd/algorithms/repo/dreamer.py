@@ -280,6 +280,19 @@ class Dreamer:
         dfeat = torch.empty(Hm * N, F_, device=dev)
         ops.mlp_bwd(pw, feats, r_hid, dr.view(Hm * N, 1), dparams=None, dx=dfeat)
         ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat, accumulate_dx=True)
+        # -- critic on detached imag[:-1] against detached returns (dreamer.py:362-373), forked onto a
+        #    side stream: it needs only `returns` and the value head's saved activations (the value
+        #    weights have not changed since v_pred was computed), so it runs while the reverse
+        #    rollout (which fills only ~77 CUs) and the actor backward proceed on the main stream.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream
+        side.wait_stream(main)  # after the value head's input-gradient pass above read the weights
+        nv = (Hm - 1) * N
+        with torch.cuda.stream(side):
+            v_sums, dv2 = ops.scalar_nll(v_pred.view(-1)[:nv], returns.view(-1), None, 1.0 / ((Hm - 1) * gN))
+            ops.mlp_bwd(pv, feats[:nv], [h[:nv] for h in v_hid], dv2.view(nv, 1), dparams=gv, dx=None)
+            self._allreduce(self.value_optimizer.grad)
+            self.value_optimizer.clip_and_step(c.grad_clip_norm)
         # gradient at the actor trunk's output, all (Hm+1)*N rows: rollout path on steps 0..Hm-1
         # (written by the reverse rollout), entropy path on steps 1..Hm (added on top)
         d_out = torch.zeros((Hm + 1) * N, 2 * A, device=dev)
@@ -296,13 +309,7 @@ class Dreamer:
         ops.mlp_bwd(pa, x_all, [sv.a_hidden[l] for l in range(nl)], d_out, dparams=ga, accumulate_w=False, dx=None)
         self._allreduce(self.actor_optimizer.grad)
         self.actor_optimizer.clip_and_step(c.grad_clip_norm)
-        # -- critic on detached imag[:-1] against detached returns (dreamer.py:362-373).  The value
-        #    weights have not changed since v_pred was computed, so its activations are reused.
-        nv = (Hm - 1) * N
-        v_sums, dv2 = ops.scalar_nll(v_pred.view(-1)[:nv], returns.view(-1), None, 1.0 / ((Hm - 1) * gN))
-        ops.mlp_bwd(pv, feats[:nv], [h[:nv] for h in v_hid], dv2.view(nv, 1), dparams=gv, dx=None)
-        self._allreduce(self.value_optimizer.grad)
-        self.value_optimizer.clip_and_step(c.grad_clip_norm)
+        main.wait_stream(side)
         self._pending_ac = (ret_sum, ent_sum, lat_sum, v_sums, Hm, gN)
         self._log_update()
 
