@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--algo", default="repo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--join", action="store_true", help="join the two update lanes after every update (no overlap)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,14 +200,19 @@ def main():
     host = synthetic_batch(1234 + rank)  # each rank holds its own B=50 shard of the global batch
     batch = tuple(torch.from_numpy(x).to(dev) for x in host)
 
+    # same call pattern as Dreamer.train_agent()'s loop: update(join=False) lets the world-model
+    # half of update k+1 overlap the actor-critic half of update k; the timed region is closed by
+    # joining both lanes + a device synchronize, so every one of the K updates is complete
     for _ in range(args.warmup):
-        agent.update(batch)
+        agent.update(batch, join=args.join)
+    agent.synchronize()
     if dp is not None:
         dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        agent.update(batch)
+        agent.update(batch, join=args.join)
+    agent.synchronize()
     torch.cuda.synchronize()
     if dp is not None:
         dp.barrier()

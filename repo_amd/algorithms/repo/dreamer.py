@@ -63,10 +63,18 @@ class Dreamer:
             obs_type=np.uint8 if config.pixel_obs else np.float32,
         )
         self.free_nats = torch.full((1,), float(config.free_nats), device=self.device)
-        self._scal = torch.zeros(32, dtype=torch.float32, device=self.device)
         self._side_stream = torch.cuda.Stream(device=self.device)
         self._wgrad_stream = torch.cuda.Stream(device=self.device)
-        self.last_scalars = {}
+        self._ac_side_stream = torch.cuda.Stream(device=self.device)
+        # update(): the world-model lane and the actor-critic lane run on their own streams so
+        # that WM(k+1) overlaps AC(k) (see update()); events order the only true dependencies
+        self._wm_stream = torch.cuda.Stream(device=self.device)
+        self._ac_stream = torch.cuda.Stream(device=self.device)
+        self._ev_ac_done = None      # AC(k) finished reading the world-model parameters
+        self._log_pending = None     # (event, pinned host buffer, meta) of the last enqueued update
+        self._log_host = torch.empty(32, dtype=torch.float32).pin_memory()
+        self._last_scalars = {}
+        self.last_grad_norms = {}
 
     # ------------------------------------------------------------------ construction
     def build_models(self, config, env):
@@ -210,6 +218,10 @@ class Dreamer:
         Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
 
     def _model_step(self):
+        # the optimiser step WRITES the world-model parameters the previous update's imagination
+        # may still be reading on the actor-critic stream
+        if self._ev_ac_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_ac_done)
         self._allreduce(self.model_optimizer.grad)
         self.model_optimizer.clip_and_step(self.c.grad_clip_norm)
 
@@ -229,7 +241,8 @@ class Dreamer:
                                           float(c.free_nats), 1.0 / grow)
         self._world_model_backward(st, kl_grads, decoder_attached=True)
         self._model_step()
-        self._pending_model = (st["nll_sum"], st["rew_sums"], kl_sum, None, grow)
+        self._pending_model = (torch.cat([st["nll_sum"], st["rew_sums"], kl_sum, self.model_optimizer.sqnorm]), None,
+                               grow)
         D = c.belief_size
         return sv.featx[1:, :, :D], sv.featx[1:, :, D:]
 
@@ -285,7 +298,7 @@ class Dreamer:
         #    weights have not changed since v_pred was computed), so it runs while the reverse
         #    rollout (which fills only ~77 CUs) and the actor backward proceed on the main stream.
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream
+        side = self._ac_side_stream
         side.wait_stream(main)  # after the value head's input-gradient pass above read the weights
         nv = (Hm - 1) * N
         with torch.cuda.stream(side):
@@ -315,22 +328,42 @@ class Dreamer:
 
     # ------------------------------------------------------------------ logging: one D2H per update
     def _log_update(self):
-        c = self.c
-        nll_sum, rew_sums, kl_sum, dual, grow = self._pending_model
+        """Gather every logged scalar of this update into one device buffer and start ONE
+        asynchronous device->host copy; the values are turned into floats (and handed to the
+        logger) when they are first needed: `last_scalars`, or the next update's log call."""
+        self._flush_log()
+        msc, dual, grow = self._pending_model   # [nll, rsq, rmask, kl, model_sqnorm] (+ dual[4])
         ret_sum, ent_sum, lat_sum, v_sums, Hm, gN = self._pending_ac
-        parts = [nll_sum, rew_sums, kl_sum, ret_sum, ent_sum, lat_sum, v_sums, self.model_optimizer.sqnorm,
-                 self.actor_optimizer.sqnorm, self.value_optimizer.sqnorm]
+        cur = torch.cuda.current_stream(self.device)
+        msc.record_stream(cur)
+        if dual is not None:
+            dual.record_stream(cur)
+        parts = [msc[:4], ret_sum, ent_sum, lat_sum, v_sums, msc[4:5], self.actor_optimizer.sqnorm,
+                 self.value_optimizer.sqnorm]
         if dual is not None:
             parts.append(dual)
         buf = torch.cat([p.reshape(-1) for p in parts])
-        self._allreduce_scalars(buf, n_sum=10)
-        h = buf.cpu().tolist()
+        self._allreduce_scalars(buf, n_sum=9)
+        n = buf.numel()
+        self._log_host[:n].copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._log_pending = (ev, n, dual is not None, grow, Hm, gN)
+
+    def _flush_log(self):
+        if self._log_pending is None:
+            return
+        ev, n, has_dual, grow, Hm, gN = self._log_pending
+        self._log_pending = None
+        ev.synchronize()
+        c = self.c
+        h = self._log_host[:n].tolist()
         nll, rsq, rmask, kl, ret, ent, lat, vsq, _vn, gm, ga_, gv_ = h[:12]
         npix = 3 * 64 * 64
         out = {}
         out["train/obs_loss"] = nll / grow + 0.5 * LOG_2PI * npix
         out["train/reward_loss"] = (rsq + 0.5 * LOG_2PI * rmask) / grow
-        if dual is not None:
+        if has_dual:
             kl_div, kl_loss, beta_loss, beta = h[12:16]
             out["train/kl_loss"] = kl_loss
             out["train/kl_div"] = kl_div
@@ -346,11 +379,23 @@ class Dreamer:
         out["train/value_loss"] = vsq / ((Hm - 1) * gN) + 0.5 * LOG_2PI
         out["train/action_entropy"] = action_entropy
         out["train/latent_entropy"] = latent_entropy
-        self.last_scalars = out
+        self._last_scalars = out
         self.last_grad_norms = {"model": math.sqrt(max(gm, 0.0)), "actor": math.sqrt(max(ga_, 0.0)),
                                 "value": math.sqrt(max(gv_, 0.0))}
         for k, v in out.items():
             self.logger.record(k, v)
+
+    @property
+    def last_scalars(self):
+        """Logged scalars of the most recent update (waits for it to finish on the device)."""
+        self._flush_log()
+        return self._last_scalars
+
+    def synchronize(self):
+        """Join the update lanes into the current stream (before reading parameters elsewhere)."""
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self._wm_stream)
+        cur.wait_stream(self._ac_stream)
 
     def _allreduce_scalars(self, buf, n_sum):
         """Loss sums are per-rank partial sums; gradient norms (already global) are not summed."""
@@ -358,14 +403,40 @@ class Dreamer:
             self.dp.all_reduce_prefix(buf, 9)
 
     # ------------------------------------------------------------------ update loop
-    def update(self, batch):
+    def update(self, batch, join=True):
         """One iteration of the train_agent loop body on a device batch
-        (obs (L,B,3,64,64) uint8|float32, actions (L,B,A), rewards (L,B,1), dones (L,B,1))."""
+        (obs (L,B,3,64,64) uint8|float32, actions (L,B,A), rewards (L,B,1), dones (L,B,1)).
+
+        The two halves run on two streams.  train_actor_critic(k) only READS the world model and
+        train_dynamics(k+1) does not touch the actor or the critic, so the only orderings that matter
+        are: AC(k) after the model optimiser step of WM(k), and the model optimiser step of WM(k+1)
+        after AC(k).  Both are events; everything else of WM(k+1) -- encoder, scan, decoder, all of
+        the backward -- overlaps AC(k), whose rollout kernels fill less than a third of the CUs.
+        Results are identical to running the halves back to back; nothing here synchronises the
+        host (scalars are read lazily through `last_scalars`).  join=True (default) makes the
+        caller's stream wait for both lanes, so parameters can be read right after the call;
+        train_agent()'s loop passes join=False and joins once at the end, which is what lets
+        consecutive updates overlap."""
         obs, actions, rewards, dones = batch
-        nonterms = 1.0 - dones.float()
-        beliefs, post = self.train_dynamics(obs, actions, rewards, nonterms)
-        self.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
-        return self.last_scalars
+        dev = self.device
+        caller = torch.cuda.current_stream(dev)
+        wm, ac = self._wm_stream, self._ac_stream
+        wm.wait_stream(caller)  # the batch was produced on the caller's stream
+        with torch.cuda.stream(wm):
+            nonterms = 1.0 - dones.float()
+            beliefs, post = self.train_dynamics(obs, actions, rewards, nonterms)
+            ev_wm = torch.cuda.Event()
+            ev_wm.record(wm)
+        for t in (obs, actions, rewards, dones):
+            t.record_stream(wm)
+        with torch.cuda.stream(ac):
+            ac.wait_event(ev_wm)
+            beliefs.record_stream(ac)  # views of the scan's feature buffer, allocated on the WM stream
+            self.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
+            self._ev_ac_done = torch.cuda.Event()
+            self._ev_ac_done.record(ac)
+        if join:
+            self.synchronize()
 
     def train_agent(self):
         c = self.c
@@ -374,11 +445,13 @@ class Dreamer:
         for i in range(c.train_steps):
             batch = self.buffer.acquire(h, B, L, self.device)
             cur = h
-            self.update(batch)
-            self.buffer.release(cur, B, L, self.device)
+            self.update(batch, join=False)
+            with torch.cuda.stream(self._wm_stream):  # the consumer of the staged batch
+                self.buffer.release(cur, B, L, self.device)
             if i + 1 < c.train_steps:
                 # host gather + PCIe copy of the next batch overlap the update just enqueued
                 h = self.buffer.prefetch(B, L, self.device)
+        self.synchronize()
 
     # ------------------------------------------------------------------ acting
     def collect_seed_data(self):
@@ -399,6 +472,7 @@ class Dreamer:
     @torch.no_grad()
     def update_latent_and_select_action(self, belief, posterior_state, action, obs, explore=False):
         """One filtering step + policy (reference dreamer.py:175-196)."""
+        self.synchronize()
         embed = self.encoder(obs)
         outs = self.transition_model.observe(belief, posterior_state, action.unsqueeze(0), embed.unsqueeze(0))
         belief, posterior_state = outs[0].squeeze(0), outs[4].squeeze(0)
@@ -484,6 +558,8 @@ class Dreamer:
             self.buffer.save(os.path.join(self.logger.dir, "buffer.npz"))
 
     def get_param_dict(self):
+        self.synchronize()
+
         def sd(m):
             return {k: v.detach().clone() for k, v in m.state_dict().items()}
 

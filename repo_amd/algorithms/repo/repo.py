@@ -71,7 +71,8 @@ class RePo(Dreamer):
         bo.step_count += 1
         ops.dual_step(self.log_beta, bo.exp_avg, bo.exp_avg_sq, kl_global, grow, c.target_kl, bo.lr, bo.step_count,
                       betas=bo.betas, eps=bo.eps, out=self._dual_out)
-        self._pending_model = (st["nll_sum"], st["rew_sums"], kl_sum, self._dual_out, grow)
+        self._pending_model = (torch.cat([st["nll_sum"], st["rew_sums"], kl_sum, self.model_optimizer.sqnorm]),
+                               self._dual_out.clone(), grow)
         D = c.belief_size
         return sv.featx[1:, :, :D], sv.featx[1:, :, D:]
 

@@ -135,8 +135,10 @@ def test_checkpoint_roundtrip_and_reference_layout(tmp_path):
     nz, _ = dev_noise(8, 4, 5, 6, 10)
     agent.noise_source = nz
     agent2.noise_source = nz
-    s1 = dict(agent.update(batch2))
-    s2 = dict(agent2.update(batch2))
+    agent.update(batch2)
+    s1 = dict(agent.last_scalars)
+    agent2.update(batch2)
+    s2 = dict(agent2.last_scalars)
     assert s1 == s2, (s1, s2)
 
 
@@ -146,7 +148,8 @@ def test_dreamer_full_size_matches_oracle_scalars():
     agent, cfg = make_agent("dreamer", L, B, H, A)
     batch, host = dev_batch(L, B, A, 1234)
     agent.noise_source, nz = dev_noise(L, B, H, A, 77)
-    got = dict(agent.update(batch))
+    agent.update(batch)
+    got = dict(agent.last_scalars)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     want = ro.OracleAgent(cfg, A, seed=7).update(*host, nz)[2]
     for k, w in want.items():
@@ -168,8 +171,10 @@ class ThreadDP:
     def all_reduce(self, t):
         sh = self.sh
         sh["slot"][self.rank] = t
+        torch.cuda.current_stream().synchronize()  # the peer reads t from ITS stream
         sh["barrier"].wait()
         total = sh["slot"][0] + sh["slot"][1]
+        torch.cuda.current_stream().synchronize()  # before the peer overwrites its slot
         sh["barrier"].wait()
         t.copy_(total)
         return t
@@ -188,7 +193,8 @@ def test_data_parallel_two_shards_equal_full_batch():
     nz, _ = dev_noise(L, B, H, A, 22)
     full, _ = make_agent("repo", L, B, H, A)
     full.noise_source = nz
-    s_full = dict(full.update(batch))
+    full.update(batch)
+    s_full = dict(full.last_scalars)
     T, N = L - 1, (L - 1) * B
 
     def shard_noise(lo, hi):
@@ -214,7 +220,8 @@ def test_data_parallel_two_shards_equal_full_batch():
         try:
             torch.cuda.set_device(0)
             lo, hi = halves[r]
-            scal[r] = dict(agents[r].update(tuple(x[:, lo:hi].contiguous() for x in batch)))
+            agents[r].update(tuple(x[:, lo:hi].contiguous() for x in batch))
+            scal[r] = dict(agents[r].last_scalars)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
             shared["barrier"].abort()
@@ -236,3 +243,24 @@ def test_data_parallel_two_shards_equal_full_batch():
         assert e < 2e-5 and ea < 2e-5
     assert torch.equal(agents[0].model_optimizer.flat, agents[1].model_optimizer.flat)  # replicas stay identical
     assert abs(float(agents[0].log_beta) - float(full.log_beta)) < 1e-6
+
+
+def test_pipelined_updates_bitwise_equal_sequential():
+    """update(join=False) overlaps WM(k+1) with AC(k) on two streams; the parameters after K such
+    updates must be BIT-identical to K joined (back-to-back) updates."""
+    L, B, H, A, K = 10, 6, 6, 6, 4
+    agents = [make_agent("repo", L, B, H, A)[0] for _ in range(2)]
+    batches = [dev_batch(L, B, A, 600 + u, u8=(u % 2 == 0))[0] for u in range(K)]
+    noises = [dev_noise(L, B, H, A, 700 + u)[0] for u in range(K)]
+    for mode, ag in enumerate(agents):
+        for u in range(K):
+            ag.noise_source = noises[u]
+            ag.update(batch=batches[u], join=(mode == 0))
+        ag.synchronize()
+    torch.cuda.synchronize()
+    a, b = agents
+    for name in ("model_optimizer", "actor_optimizer", "value_optimizer"):
+        pa, pb = getattr(a, name).flat, getattr(b, name).flat
+        assert torch.equal(pa, pb), (name, (pa - pb).abs().max().item())
+    assert a.last_scalars == b.last_scalars
+    assert float(a.log_beta) == float(b.log_beta)

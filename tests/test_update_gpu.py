@@ -166,7 +166,8 @@ def test_full_size_update_properties():
     agent, cfg = make_agent("repo", L, B, H, A)
     batch, _ = dev_batch(L, B, A, 1234)
     p0 = agent.model_optimizer.flat.clone()
-    s1 = dict(agent.update(batch))
+    agent.update(batch)
+    s1 = dict(agent.last_scalars)
     assert all(np.isfinite(v) for v in s1.values()), s1
     # sanity anchors observed on the reference with uniform-random frames
     assert 13000 < s1["train/obs_loss"] < 13800
@@ -182,7 +183,8 @@ def test_full_size_update_properties():
     for _ in range(2):
         ag, _ = make_agent("repo", L, B, H, A)
         ag.noise_source = noise
-        outs.append(dict(ag.update(batch)))
+        ag.update(batch)
+        outs.append(dict(ag.last_scalars))
     assert outs[0] == outs[1], (outs[0], outs[1])
 
 
