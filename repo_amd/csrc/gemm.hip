@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include "igemm.h"
+#include "vgemm.h"
 
 namespace repo {
 
@@ -54,6 +55,67 @@ struct GemmOp {
   }
   __device__ void finish() {}
 };
+
+// The same product on the vector-load engine (vgemm.h): operands as raw-buffer 2-D arrays.
+template <bool TA, bool TB, int VW_>
+struct VGemmOp {
+  static constexpr bool A_VK = !TA;  // A[m][k]: k contiguous
+  static constexpr bool B_VK = TB;   // B[n][k]: k contiguous
+  static constexpr int VW = VW_;
+  Dense2D A, B;
+  const float* bias;
+  const float* aux;
+  float* C;
+  int ldc, ldaux, bias_div;
+  int M_, N_, K_;
+  int epi, accumulate;
+
+  __device__ void init(int) {}
+  __device__ int M() const { return M_; }
+  __device__ int N() const { return N_; }
+  __device__ int kbeg() const { return 0; }
+  __device__ int kend() const { return K_; }
+  template <class V>
+  __device__ void fix_b(V&, int) const {}
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
+    const float bv = bias ? bias[bias_div == 1 ? n : n / bias_div] : 0.f;
+    float* c = C + mb * ldc + n;
+    const float* ax = aux ? aux + mb * ldaux + n : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) {
+        float v = acc[r] + bv;
+        if (epi == REPO_EPI_ELU) v = elu(v);
+        else if (epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
+        else if (epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(ax[dm * ldaux]);
+        else if (epi == REPO_EPI_MUL_DRELU) v = ax[dm * ldaux] > 0.f ? v : 0.f;
+        if (accumulate) v += c[dm * ldc];
+        c[dm * ldc] = v;
+      }
+    }
+  }
+  __device__ void finish() {}
+};
+
+template <class Op>
+static int vgemm_dispatch(const Op& op, long M, long N, hipStream_t s) {
+  static const int force = getenv("REPO_GEMM_TILE") ? atoi(getenv("REPO_GEMM_TILE")) : 0;  // experiments only
+  switch (force) {
+    case 1: return launch_vgemm<T64x64>(op, M, N, 1, s);
+    case 5: return launch_vgemm<T64x128>(op, M, N, 1, s);
+    case 6: return launch_vgemm<T128x128>(op, M, N, 1, s);
+    case 7: return launch_vgemm<T128x128s1>(op, M, N, 1, s);
+    case 8: return launch_vgemm<T128x64>(op, M, N, 1, s);
+    default: break;
+  }
+  // large products: 128x128 tiles with ONE register staging set (148 VGPRs -> 3 waves per SIMD; the
+  // two-set variant needs > 256 and drops to one wave per SIMD: 102 vs 124-131 TFLOP/s at 4096^3)
+  const long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  if (M >= 512 && N >= 512 && t128 >= 192) return launch_vgemm<T128x128s1>(op, M, N, 1, s);
+  if (M <= 32) return launch_vgemm<T32x128>(op, M, N, 1, s);
+  return launch_vgemm<T64x64>(op, M, N, 1, s);
+}
 
 template <bool TA, bool TB>
 static int gemm_dispatch(const GemmOp<TA, TB>& op, long M, long N, hipStream_t s) {
@@ -121,6 +183,41 @@ struct WgradOp {
   __device__ void finish() {}
 };
 
+// Same split-K product on the vector-load engine: both operands are contiguous along m'/n'.
+struct VWgradOp {
+  static constexpr bool A_VK = false;  // A(m'=n, k'=row) = dY[row][n]
+  static constexpr bool B_VK = false;  // B(k'=row, n'=k) = X[row][k]
+  static constexpr int VW = 4;
+  Dense2D A, B;
+  float* slab;  // [splits][N][K+1]
+  int rows, N_, K_, rows_per_split;
+  int z, kb, ke;
+
+  __device__ void init(int zz) {
+    z = zz;
+    kb = zz * rows_per_split;
+    ke = min(rows, kb + rows_per_split);
+  }
+  __device__ int M() const { return N_; }
+  __device__ int N() const { return K_ + 1; }
+  __device__ int kbeg() const { return kb; }
+  __device__ int kend() const { return ke; }
+  template <class V>
+  __device__ void fix_b(V& v, int n0) const {  // column K_ of B is the ones column (bias gradient)
+#pragma unroll
+    for (int i = 0; i < VW; ++i) v[i] = (n0 + i == K_) ? 1.f : v[i];
+  }
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
+    float* c = slab + ((size_t)z * N_ + mb) * (K_ + 1) + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) c[dm * (K_ + 1)] = acc[r];
+    }
+  }
+  __device__ void finish() {}
+};
+
 // out[m][n] (+)= sum_z slab[z][m][n] for n < K ; db[m] (+)= sum_z slab[z][m][K]
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, int Mrows, int Kcols,
                                    float* __restrict__ dW, int lddw, float* __restrict__ db,
@@ -170,6 +267,32 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
     REPO_REQUIRE(ea < kMaxIdx && eb < kMaxIdx && M * ldc < kMaxIdx && M * ldaux < kMaxIdx, REPO_E_SHAPE);
   }
   if (bias_div <= 0) bias_div = 1;
+  // vector-load engine whenever the k-contiguous operands (A if !transa, B if transb) have K % VW == 0
+  static const bool old_engine = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
+  const bool kvec = !transa || transb;
+  const int vw = (!kvec || K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 0);
+  if (vw && !old_engine) {
+    const unsigned abytes = 4u * (unsigned)(transa ? (K - 1) * lda + M : (M - 1) * lda + K);
+    const unsigned bbytes = 4u * (unsigned)(transb ? (N - 1) * ldb + K : (K - 1) * ldb + N);
+#define REPO_VGEMM_CASE(TA, TB, VW)                                                                            \
+  {                                                                                                            \
+    VGemmOp<TA, TB, VW> op{Dense2D{A, abytes, (int)lda}, Dense2D{B, bbytes, (int)ldb}, bias, aux, C, (int)ldc, \
+                           (int)ldaux, (int)bias_div, (int)M, (int)N, (int)K, epi, accumulate};                \
+    return vgemm_dispatch(op, M, N, stream);                                                                   \
+  }
+    if (vw == 4) {
+      if (!transa && !transb) REPO_VGEMM_CASE(false, false, 4)
+      if (!transa && transb) REPO_VGEMM_CASE(false, true, 4)
+      if (transa && !transb) REPO_VGEMM_CASE(true, false, 4)
+      REPO_VGEMM_CASE(true, true, 4)
+    } else {
+      if (!transa && !transb) REPO_VGEMM_CASE(false, false, 2)
+      if (!transa && transb) REPO_VGEMM_CASE(false, true, 2)
+      if (transa && !transb) REPO_VGEMM_CASE(true, false, 2)
+      REPO_VGEMM_CASE(true, true, 2)
+    }
+#undef REPO_VGEMM_CASE
+  }
 #define REPO_GEMM_CASE(TA, TB)                                                                   \
   {                                                                                              \
     GemmOp<TA, TB> op{A,        B,        bias,           aux,    C,      (int)lda, (int)ldb, (int)ldc, \
@@ -206,8 +329,17 @@ extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY,
   const int splits = wgrad_splits(M, N, K);
   REPO_REQUIRE(ws && ws_bytes >= repo_gemm_wgrad_workspace_bytes(M, N, K), REPO_E_WS_TOO_SMALL);
   const int rps = (int)((M + splits - 1) / splits);
-  WgradOp op{dY, X, (float*)ws, (int)lddy, (int)ldx, (int)M, (int)N, (int)K, rps, 0, 0, 0};
-  int rc = launch_igemm<T64x64>(op, N, K + 1, splits, stream);
+  static const bool old_engine = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
+  int rc;
+  if (old_engine) {
+    WgradOp op{dY, X, (float*)ws, (int)lddy, (int)ldx, (int)M, (int)N, (int)K, rps, 0, 0, 0};
+    rc = launch_igemm<T64x64>(op, N, K + 1, splits, stream);
+  } else {
+    VWgradOp op{Dense2D{dY, 4u * (unsigned)((M - 1) * lddy + N), (int)lddy},
+                Dense2D{X, 4u * (unsigned)((M - 1) * ldx + K), (int)ldx},
+                (float*)ws, (int)M, (int)N, (int)K, rps, 0, 0, 0};
+    rc = launch_vgemm<T64x64>(op, N, K + 1, splits, stream);
+  }
   if (rc) return rc;
   const int total = (int)(N * (K + 1));
   const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;

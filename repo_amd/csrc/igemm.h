@@ -37,6 +37,23 @@ namespace repo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DREPO_IGEMM_STAMPS (tools/probe/igemm_stamps.hip only): per-phase cycle totals of the K loop,
+// summed over waves: [0] load issue  [1] MFMA phase  [2] LDS write (incl. wait for the loads)
+// [3] barrier  [4] epilogue  [5] prologue  [6] waves  [7] slices
+#ifdef REPO_IGEMM_STAMPS
+static __device__ unsigned long long g_igemm_stamps[8];
+#define REPO_STAMP_DECL unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_readcyclecounter(); unsigned st_n = 0;
+#define REPO_STAMP(i)                                            \
+  do {                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    st_[i] += now_ - st_t;                                       \
+    st_t = now_;                                                 \
+  } while (0)
+#else
+#define REPO_STAMP_DECL
+#define REPO_STAMP(i)
+#endif
+
 template <int WM_, int WN_, int TM_, int TN_, int BK_ = 16, int SETS_ = 2>
 struct TileCfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
@@ -253,18 +270,24 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
     // later counted wait collapse to vmcnt(0) and drains the prefetch.  Re-loading the last
     // slice once or twice at the tail is cheaper than losing the overlap everywhere.
     auto slice_k = [&](int t) __attribute__((always_inline)) { return kbeg + min(t, nt - 1) * BK; };
+    REPO_STAMP_DECL
     if (nt > 0 && T::SETS == 1) {
       gload_any(slice_k(0), S0{});
       lstore(0, S0{});
       __syncthreads();
+      REPO_STAMP(5);
       int buf = 0;
       for (int t = 0; t < nt; ++t) {
         gload_any(slice_k(t + 1), S0{});
         __builtin_amdgcn_sched_barrier(0);
+        REPO_STAMP(0);
         compute(buf);
         __builtin_amdgcn_sched_barrier(0);
+        REPO_STAMP(1);
         lstore(buf ^ 1, S0{});
+        REPO_STAMP(2);
         __syncthreads();
+        REPO_STAMP(3);
         buf ^= 1;
       }
     } else if (nt > 0) {
@@ -272,24 +295,33 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
       lstore(0, S0{});
       gload_any(slice_k(1), S1{});
       __syncthreads();
+      REPO_STAMP(5);
       for (int t = 0; t < nt; t += 2) {
         // even slice t: LDS buffer 0; slice t+1 is in set 1; issue slice t+2 into set 0
         gload_any(slice_k(t + 2), S0{});
         // coarse fences: keep the LDS-write selects of the landed set BEHIND the MFMA phase and
         // the new loads AHEAD of it (hipcc otherwise hoists the selects above the load issue)
         __builtin_amdgcn_sched_barrier(0);
+        REPO_STAMP(0);
         compute(0);
         __builtin_amdgcn_sched_barrier(0);
+        REPO_STAMP(1);
         lstore(1, S1{});
+        REPO_STAMP(2);
         __syncthreads();
+        REPO_STAMP(3);
         if (t + 1 >= nt) break;
         // odd slice t+1: LDS buffer 1; slice t+2 is in set 0; issue slice t+3 into set 1
         gload_any(slice_k(t + 3), S1{});
         __builtin_amdgcn_sched_barrier(0);
+        REPO_STAMP(0);
         compute(1);
         __builtin_amdgcn_sched_barrier(0);
+        REPO_STAMP(1);
         lstore(0, S0{});
+        REPO_STAMP(2);
         __syncthreads();
+        REPO_STAMP(3);
       }
     }
 
@@ -306,6 +338,14 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
         const int mb = m0 + (wm * T::TM + i) * 32 + 4 * lh;
         if (n < N && mb < M) op.store_col(mb, n, acc[i][j], M);
       }
+#ifdef REPO_IGEMM_STAMPS
+    REPO_STAMP(4);
+    if (lane == 0) {
+      for (int i = 0; i < 6; ++i) atomicAdd(&g_igemm_stamps[i], st_[i]);
+      atomicAdd(&g_igemm_stamps[6], 1ull);
+      atomicAdd(&g_igemm_stamps[7], (unsigned long long)nt);
+    }
+#endif
   }
   op.finish();
 }
