@@ -15,9 +15,12 @@
 //   wgrad: dw[cs][cb][ky][kx] = sum_{img,sy,sx} small[img][cs][sy][sx] big[img][cb][2sy+ky][2sx+kx]
 //          M = CS, N = CB*KS*KS (+1 column of ones = bias gradient of `small`), K = nimg*HS*WS
 //          split over images into slabs, reduced in fixed order.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "igemm.h"
+#include "dconv.h"
 
 namespace repo {
 
@@ -464,10 +467,27 @@ struct TileFor {
   using Wgrad = typename std::conditional<(G::CS <= 32), T32x128, T64x64>::type;
 };
 
+// direct-conv tiles per layer: <BM, BN, CK, WM, WN>
+template <class G>
+struct DTileFor;
+template <> struct DTileFor<GEnc1> { using Down = DTile<32, 256, 3, 1, 4>; };
+template <> struct DTileFor<GEnc2> { using Down = DTile<64, 128, 2, 2, 2>; };
+template <> struct DTileFor<GEnc3> { using Down = DTile<128, 128, 2, 2, 2>; };
+template <> struct DTileFor<GEnc4> { using Down = DTile<128, 128, 2, 2, 2>; };
+template <> struct DTileFor<GDec2> { using Down = DTile<64, 128, 4, 2, 2>; };
+template <> struct DTileFor<GDec3> { using Down = DTile<64, 128, 2, 2, 2>; };
+template <> struct DTileFor<GDec4> { using Down = DTile<32, 256, 3, 1, 4>; };
+
 template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
                        const float* aux, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
+  if (!old_engine) {
+    DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
+               (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
+    return launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
+  }
   ConvDownOp<G, BigT> op{big, w, bias, aux, small, (int)nimg, epi};
   return launch_igemm<typename TileFor<G>::Down>(op, G::CS, nimg * G::PS, 1, s);
 }

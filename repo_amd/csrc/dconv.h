@@ -1,0 +1,256 @@
+// Direct (patch-resident) stride-2 convolutions on the fp32 matrix cores of gfx950.
+//
+// igemm.h stages an im2col slice per K step: every input element is fetched (KS/2)^2 times by
+// dword-granular gathers, and in-kernel stamps show those gathers -- not the MFMAs -- set the pace
+// (the CU's vector-memory front end needs 30-80 cycles per wave-level gather instruction).  Here the
+// workgroup copies the RAW input rows its output pixels need into LDS once per channel chunk, with
+// 16-byte buffer loads of contiguous memory, and the MFMA operand fragments are read straight from
+// that patch:   LDS address = base(pixel of this lane) + offset(k = channel, ky, kx)
+// is separable, the offset part is a compile-time constant of the unrolled K loop, so a fragment
+// read is one ds_read_b32 with an immediate offset and no address arithmetic.
+//
+//   down : small[img][cs][sy][sx] = sum_{cb,ky,kx} big[img][cb][2sy+ky][2sx+kx] w[cs][cb][ky][kx]
+//          M = CS (weights: A operand, [k][m] slice in LDS), N = pixels (img,sy,sx), K = (cb,ky,kx)
+//
+// Pipeline: one register staging set, two LDS buffers, one barrier per channel chunk (the loads of
+// chunk t+1 are in flight during the MFMAs of chunk t); occupancy (3-5 workgroups per CU) hides the rest.
+#pragma once
+#include "vgemm.h"
+
+namespace repo {
+
+template <int BM_, int BN_, int CK_, int WM_, int WN_>
+struct DTile {
+  static constexpr int BM = BM_, BN = BN_, CK = CK_, WM = WM_, WN = WN_;
+  static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  static constexpr int NT = WM * WN * 64;
+  static_assert(TM >= 1 && TN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave grid mismatch");
+};
+
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// 4 consecutive input elements as floats (fp32 frames: one 16-byte load; uint8 frames: one dword).
+template <class InT>
+struct Patch4;
+template <>
+struct Patch4<float> {
+  typedef f32x4 raw_t;
+  static constexpr int BYTES = 4;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  }
+  static __device__ __forceinline__ f32x4 cvt(raw_t v) { return v; }
+};
+template <>
+struct Patch4<uint8_t> {
+  typedef unsigned raw_t;
+  static constexpr int BYTES = 1;
+  static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 cvt(raw_t v) {
+    f32x4 o;
+    o[0] = pix_norm((uint8_t)(v & 0xff));
+    o[1] = pix_norm((uint8_t)((v >> 8) & 0xff));
+    o[2] = pix_norm((uint8_t)((v >> 16) & 0xff));
+    o[3] = pix_norm((uint8_t)(v >> 24));
+    return o;
+  }
+};
+
+struct DownArgs {
+  const void* big;
+  const float* w;
+  const float* bias;
+  const float* aux;
+  float* out;
+  int nimg, epi;
+  unsigned big_bytes, w_bytes;
+};
+
+template <class G, class BigT, class T>
+__global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
+  constexpr int BM = T::BM, BN = T::BN, CK = T::CK, NT = T::NT, TM = T::TM, TN = T::TN;
+  constexpr int KSL = CK * G::KK;  // k per chunk
+  constexpr int NSL = G::CB / CK;
+  static_assert(G::CB % CK == 0 && KSL % 4 == 0, "channel chunk must divide CB and give k % 4 == 0");
+  constexpr int LDW = BM + 2;
+  // ---- patch geometry: a tile is BN consecutive pixels of (img, sy, sx); image i of the tile needs
+  // input rows [2*f_i, 2*l_i + KS) -- full width, hence ONE contiguous span per (image, channel)
+  constexpr int ROWS_FULL = 2 * (G::HS - 1) + G::KS;
+  constexpr int LENFULL = (ROWS_FULL * G::WB + 3) & ~3;
+  constexpr int NIMG_MAX = (BN - 1) / G::PS + 2;
+  constexpr int PLMAX = cmin(NIMG_MAX * LENFULL,
+                             ((2 * (BN / G::WS + 2) + NIMG_MAX * (G::KS - 2)) * G::WB + 4 * NIMG_MAX + 3) & ~3);
+  constexpr int PLV = PLMAX / 4;
+  constexpr int W_NV = BM * KSL / 4, W_KV = KSL / 4;  // weight vectors per chunk / per row
+  constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * PLV + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float lds[2 * KSL * LDW + 2 * CK * PLMAX];
+  float* Wl = lds;
+  float* Pl = lds + 2 * KSL * LDW;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / T::WN, wn = wid % T::WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int Ntot = p.nimg * G::PS;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int nlast = min(n0 + BN, Ntot) - 1;
+  const int ia = n0 / G::PS, ib = nlast / G::PS;
+  const int fa = (n0 % G::PS) / G::WS, lb = (nlast % G::PS) / G::WS;
+  // span of image i: rows [2*f_i, 2*l_i+KS); LDS start S_i (floats, multiple of 4)
+  const int la_ = (ia == ib) ? lb : G::HS - 1;
+  const int lenA = ((2 * (la_ - fa) + G::KS) * G::WB + 3) & ~3;
+  auto span_start = [&](int i) __attribute__((always_inline)) { return i == ia ? 0 : lenA + (i - ia - 1) * LENFULL; };
+  const int PL = span_start(ib) + (ib == ia ? lenA : ((2 * lb + G::KS) * G::WB + 3) & ~3);
+
+  const __amdgpu_buffer_rsrc_t rbig = make_rsrc(p.big, p.big_bytes), rw = make_rsrc(p.w, p.w_bytes);
+
+  // ---- staging roles
+  unsigned woff[W_PER];
+  int wlds[W_PER];
+#pragma unroll
+  for (int j = 0; j < W_PER; ++j) {
+    const int v = tid + j * NT, kv = v % W_KV, m = v / W_KV;
+    const bool act = (W_NV % NT == 0) || v < W_NV;
+    woff[j] = act ? 4u * (unsigned)(min(m0 + m, G::CS - 1) * (G::CB * G::KK) + kv * 4) : kOobOffset;
+    wlds[j] = act ? (kv * 4) * LDW + m : -1;
+  }
+  unsigned poff[P_PER];
+  int plds[P_PER];
+#pragma unroll
+  for (int j = 0; j < P_PER; ++j) {
+    const int v = tid + j * NT, c = v / PLV, q = (v % PLV) * 4;
+    const bool act = c < CK && q < PL;
+    int i, rel;
+    if (q < lenA) {
+      i = ia;
+      rel = q;
+    } else {
+      i = ia + 1 + (q - lenA) / LENFULL;
+      rel = (q - lenA) % LENFULL;
+    }
+    const int f = (i == ia) ? fa : 0;
+    poff[j] = act ? (unsigned)Patch4<BigT>::BYTES * (unsigned)((i * G::CB + c) * G::PB + 2 * f * G::WB + rel)
+                  : kOobOffset;
+    plds[j] = act ? c * PLMAX + q : -1;
+  }
+  constexpr unsigned W_STEP = 4u * KSL, P_STEP = (unsigned)Patch4<BigT>::BYTES * CK * G::PB;
+
+  // ---- per-lane LDS bases of the B (pixel) fragments
+  int bbase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = min(n0 + (wn * TN + j) * 32 + li, Ntot - 1);
+    const int i = n / G::PS, pix = n % G::PS;
+    const int f = (i == ia) ? fa : 0;
+    bbase[j] = span_start(i) + 2 * (pix / G::WS - f) * G::WB + 2 * (pix % G::WS);
+  }
+  int bbase1[TN];  // + lh: the two k of an MFMA step are horizontally adjacent taps (always, for even KS)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bbase1[j] = bbase[j] + lh;
+  const int abase = lh * LDW + wm * (TM * 32) + li;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 rwv[W_PER];
+  typename Patch4<BigT>::raw_t rpv[P_PER];
+  auto gload = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < W_PER; ++j)
+      rwv[j] = VecLoad<4>::load(rw, woff[j] == kOobOffset ? kOobOffset : woff[j] + (unsigned)t * W_STEP);
+#pragma unroll
+    for (int j = 0; j < P_PER; ++j)
+      rpv[j] = Patch4<BigT>::load(rbig, poff[j] == kOobOffset ? kOobOffset : poff[j] + (unsigned)t * P_STEP);
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    float* wl = Wl + buf * KSL * LDW;
+    float* pl = Pl + buf * CK * PLMAX;
+#pragma unroll
+    for (int j = 0; j < W_PER; ++j)
+      if ((W_NV % NT == 0) || wlds[j] >= 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wl[wlds[j] + e * LDW] = rwv[j][e];
+      }
+#pragma unroll
+    for (int j = 0; j < P_PER; ++j)
+      if (plds[j] >= 0) *reinterpret_cast<f32x4*>(pl + plds[j]) = Patch4<BigT>::cvt(rpv[j]);
+  };
+  auto koff = [](int k) constexpr { return (k / G::KK) * PLMAX + ((k % G::KK) / G::KS) * G::WB + (k % G::KK) % G::KS; };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const float* wl = Wl + buf * KSL * LDW + abase;
+    const float* pl = Pl + buf * CK * PLMAX;
+#pragma unroll
+    for (int ks = 0; ks < KSL / 2; ++ks) {
+      const int o0 = koff(2 * ks), o1 = koff(2 * ks + 1);
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = wl[2 * ks * LDW + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = (o1 == o0 + 1) ? pl[bbase1[j] + o0] : pl[bbase[j] + (lh ? o1 : o0)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int t = 0; t < NSL; ++t) {
+    gload(min(t + 1, NSL - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    compute(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: lane = pixel column, 16 channel rows per accumulator tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + li;
+      const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
+      if (n < Ntot && mb < G::CS) {
+        const int img = n / G::PS, pix = n % G::PS;
+        const int o0 = (img * G::CS + mb) * G::PS + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = (r & 3) + 8 * (r >> 2);
+          if (mb + dm < G::CS) {
+            const int o = o0 + dm * G::PS;
+            float v = acc[i][j][r];
+            if (p.bias) v += p.bias[mb + dm];
+            if (p.epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
+            else if (p.epi == REPO_EPI_MUL_DRELU) v = p.aux[o] > 0.f ? v : 0.f;
+            p.out[o] = v;
+          }
+        }
+      }
+    }
+}
+
+template <class G, class BigT, class T>
+inline int launch_dconv_down(const DownArgs& a, hipStream_t s) {
+  const long gx = ((long)a.nimg * G::PS + T::BN - 1) / T::BN, gy = (G::CS + T::BM - 1) / T::BM;
+  hipLaunchKernelGGL((dconv_down_kernel<G, BigT, T>), dim3((unsigned)gx, (unsigned)gy), dim3(T::NT), 0, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+}  // namespace repo
