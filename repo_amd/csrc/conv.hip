@@ -504,6 +504,14 @@ template <class G>
 static int conv_up_t(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
                      const float* aux, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
+  if constexpr (G::CB % 32 == 0) {
+    if (!old_engine) {
+      UpArgs a{small, w, bias, aux, big, (int)nimg, epi, (unsigned)(nimg * G::CS * G::PS * sizeof(float)),
+               (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
+      return launch_dconv_up<G, UTile<128, 2>>(a, s);
+    }
+  }
   // All four output parity classes read the same (J x J) input taps, so for even kernels
   // (no zero taps) they are merged on M: one pass over `small`, 4x fewer operand loads per
   // MFMA and the four interleaved output pixels are written by the same workgroup.
