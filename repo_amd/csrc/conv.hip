@@ -509,6 +509,10 @@ static int conv_up_t(int64_t nimg, const float* small, const float* w, const flo
     if (!old_engine) {
       UpArgs a{small, w, bias, aux, big, (int)nimg, epi, (unsigned)(nimg * G::CS * G::PS * sizeof(float)),
                (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
+      static const int ut = getenv("REPO_UP_TILE") ? atoi(getenv("REPO_UP_TILE")) : 0;  // experiments only
+      if (ut == 1) return launch_dconv_up<G, UTile<256, 2>>(a, s);
+      if (ut == 2) return launch_dconv_up<G, UTile<128, 4>>(a, s);
+      if (ut == 3) return launch_dconv_up<G, UTile<256, 4>>(a, s);
       return launch_dconv_up<G, UTile<128, 2>>(a, s);
     }
   }

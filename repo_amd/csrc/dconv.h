@@ -27,6 +27,20 @@ struct DTile {
   static_assert(TM >= 1 && TN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave grid mismatch");
 };
 
+#ifdef REPO_IGEMM_STAMPS
+#define REPO_STAMP_FLUSH(nslices)                                              \
+  do {                                                                         \
+    REPO_STAMP(4);                                                             \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x % 16 == 0) {                     \
+      for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_igemm_stamps[i_], st_[i_]);  \
+      atomicAdd(&g_igemm_stamps[6], 1ull);                                     \
+      atomicAdd(&g_igemm_stamps[7], (unsigned long long)(nslices));            \
+    }                                                                          \
+  } while (0)
+#else
+#define REPO_STAMP_FLUSH(nslices)
+#endif
+
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -205,17 +219,23 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
     }
   };
 
+  REPO_STAMP_DECL
   gload(0);
   lstore(0);
   __syncthreads();
+  REPO_STAMP(5);
   int buf = 0;
   for (int t = 0; t < NSL; ++t) {
     gload(min(t + 1, NSL - 1));
     __builtin_amdgcn_sched_barrier(0);
+    REPO_STAMP(0);
     compute(buf);
     __builtin_amdgcn_sched_barrier(0);
+    REPO_STAMP(1);
     lstore(buf ^ 1);
+    REPO_STAMP(2);
     __syncthreads();
+    REPO_STAMP(3);
     buf ^= 1;
   }
 
@@ -243,6 +263,7 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
         }
       }
     }
+  REPO_STAMP_FLUSH(NSL);
 }
 
 template <class G, class BigT, class T>
@@ -414,18 +435,24 @@ __global__ __launch_bounds__(256) void dconv_up_kernel(UpArgs p) {
         }
   };
 
+  REPO_STAMP_DECL
   gload(0);
   __syncthreads();  // zero fill complete before the first interior writes
   lstore(0);
   __syncthreads();
+  REPO_STAMP(5);
   int buf = 0;
   for (int t = 0; t < NSL; ++t) {
     gload(min(t + 1, NSL - 1));
     __builtin_amdgcn_sched_barrier(0);
+    REPO_STAMP(0);
     compute(buf);
     __builtin_amdgcn_sched_barrier(0);
+    REPO_STAMP(1);
     lstore(buf ^ 1);
+    REPO_STAMP(2);
     __syncthreads();
+    REPO_STAMP(3);
     buf ^= 1;
   }
 
@@ -470,6 +497,7 @@ __global__ __launch_bounds__(256) void dconv_up_kernel(UpArgs p) {
       }
     }
   }
+  REPO_STAMP_FLUSH(NSL);
 }
 
 template <class G, class T>

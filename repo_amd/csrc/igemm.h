@@ -340,7 +340,7 @@ __global__ __launch_bounds__(T::NT) void igemm_kernel(Op op) {
       }
 #ifdef REPO_IGEMM_STAMPS
     REPO_STAMP(4);
-    if (lane == 0) {
+    if (lane == 0 && blockIdx.x % 16 == 0) {
       for (int i = 0; i < 6; ++i) atomicAdd(&g_igemm_stamps[i], st_[i]);
       atomicAdd(&g_igemm_stamps[6], 1ull);
       atomicAdd(&g_igemm_stamps[7], (unsigned long long)nt);
