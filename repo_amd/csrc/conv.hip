@@ -470,13 +470,14 @@ struct TileFor {
 // direct-conv tiles per layer: <BM, BN, CK, WM, WN>
 template <class G>
 struct DTileFor;
-template <> struct DTileFor<GEnc1> { using Down = DTile<32, 256, 3, 1, 4>; };
-template <> struct DTileFor<GEnc2> { using Down = DTile<64, 128, 2, 2, 2>; };
-template <> struct DTileFor<GEnc3> { using Down = DTile<128, 128, 2, 2, 2>; };
-template <> struct DTileFor<GEnc4> { using Down = DTile<128, 128, 2, 2, 2>; };
-template <> struct DTileFor<GDec2> { using Down = DTile<64, 128, 4, 2, 2>; };
-template <> struct DTileFor<GDec3> { using Down = DTile<64, 128, 2, 2, 2>; };
-template <> struct DTileFor<GDec4> { using Down = DTile<32, 256, 3, 1, 4>; };
+// wgrad tiles: <BM, BN, WM, WN, images per chunk, small rows per chunk>
+template <> struct DTileFor<GEnc1> { using Down = DTile<32, 256, 3, 1, 4>;   using Wgrad = WTile<32, 64, 1, 2, 1, 8>; };
+template <> struct DTileFor<GEnc2> { using Down = DTile<64, 128, 2, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 1, 7>; };
+template <> struct DTileFor<GEnc3> { using Down = DTile<128, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 2, 6>; };
+template <> struct DTileFor<GEnc4> { using Down = DTile<128, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 16, 2>; };
+template <> struct DTileFor<GDec2> { using Down = DTile<64, 128, 4, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 4, 5>; };
+template <> struct DTileFor<GDec3> { using Down = DTile<64, 128, 2, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 1, 7>; };
+template <> struct DTileFor<GDec4> { using Down = DTile<32, 256, 3, 1, 4>;   using Wgrad = WTile<32, 128, 1, 4, 1, 6>; };
 
 template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
@@ -547,13 +548,58 @@ static int conv_wgrad_splits(int64_t nimg) {
   return (int)((nimg + ips - 1) / ips);
 }
 
+// direct wgrad: images per split (a multiple of the chunk's image group) for ~1500 workgroups
+template <class G>
+static int dwgrad_ips(int64_t nimg) {
+  using T = typename DTileFor<G>::Wgrad;
+  const long tiles = ((G::CS + T::BM - 1) / T::BM) * ((G::CB * G::KK + T::BN - 1) / T::BN);
+  long want = (1536 + tiles - 1) / tiles;
+  long ips = (nimg + want - 1) / want;
+  const long min_ips = T::GI * ((G::PS >= 512) ? 1 : (G::PS >= 64 ? 2 : 4));
+  if (ips < min_ips) ips = min_ips;
+  ips = (ips + T::GI - 1) / T::GI * T::GI;
+  return (int)ips;
+}
+template <class G>
+static int dwgrad_splits(int64_t nimg) {
+  const long ips = dwgrad_ips<G>(nimg);
+  return (int)((nimg + ips - 1) / ips);
+}
+template <class G>
+static size_t wgrad_ws_bytes(int64_t nimg) {
+  const long sp = conv_wgrad_splits<G>(nimg) > dwgrad_splits<G>(nimg) ? conv_wgrad_splits<G>(nimg) : dwgrad_splits<G>(nimg);
+  return (size_t)sp * G::CS * (G::CB * G::KK + 1) * sizeof(float);
+}
+
+static void launch_conv_slab_reduce(const float* ws, int splits, int cs, int nw, float* dw, float* db, int accumulate,
+                                    hipStream_t s) {
+  const int total = cs * (nw + 1);
+  if (splits >= 64 && total <= 65536) {
+    hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(total, 4)), dim3(256), 0, s, ws, splits, cs, nw, dw, db,
+                       accumulate);
+  } else {
+    const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
+    hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, splits, cs, nw, dw, db, accumulate);
+  }
+}
+
 template <class G, class BigT>
 static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float* dw, float* db, int accumulate,
                         void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  if (!ws || ws_bytes < wgrad_ws_bytes<G>(nimg)) return REPO_E_WS_TOO_SMALL;
+  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
+  if (!old_engine) {
+    const int dips = dwgrad_ips<G>(nimg), dsplits = dwgrad_splits<G>(nimg);
+    WgradArgs a{small, big, (float*)ws, (int)nimg, dips, db != nullptr,
+                (unsigned)(nimg * G::CS * G::PS * sizeof(float)), (unsigned)(nimg * G::CB * G::PB * sizeof(BigT))};
+    int rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
+    if (rc) return rc;
+    launch_conv_slab_reduce((const float*)ws, dsplits, G::CS, G::CB * G::KK, dw, db, accumulate, s);
+    REPO_CHECK_LAUNCH();
+    return REPO_OK;
+  }
   const int splits = conv_wgrad_splits<G>(nimg);
-  const size_t need = (size_t)splits * G::CS * (G::CB * G::KK + 1) * sizeof(float);
-  if (!ws || ws_bytes < need) return REPO_E_WS_TOO_SMALL;
   const int ips = (int)((nimg + splits - 1) / splits);
   ConvWgradOp<G, BigT> op{small, big, (float*)ws, (int)nimg, ips, 0, 0, 0};
   int rc = launch_igemm<typename TileFor<G>::Wgrad>(op, G::CS, G::CB * G::KK + 1, splits, s);
@@ -611,8 +657,7 @@ extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const f
 
 extern "C" size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg) {
   if (nimg <= 0) return 0;
-  REPO_LAYER_SWITCH(layer,
-                    return ((size_t)conv_wgrad_splits<G>(nimg) * G::CS * (G::CB * G::KK + 1) * sizeof(float)))
+  REPO_LAYER_SWITCH(layer, return (wgrad_ws_bytes<G>(nimg)))
 }
 
 extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big, int big_is_u8,

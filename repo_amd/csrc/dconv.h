@@ -509,4 +509,217 @@ inline int launch_dconv_up(const UpArgs& a, hipStream_t s) {
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
+// ---------------------------------------------------------------------------------------- wgrad
+//   dw[cs][cb][ky][kx] = sum_{img,sy,sx} small[img][cs][sy][sx] * big[img][cb][2sy+ky][2sx+kx]
+//   M = cs (A = small), N = (cb,ky,kx) (B = big), K = (img, sy, sx), split over image groups into slabs
+//   [z][CS][NW+1] (column NW = bias gradient of `small`), reduced in fixed order by the caller.
+// A chunk is GI images x RB rows of `small` (and the 2*RB+KS-2 rows of `big` under them): per (image,
+// channel) both are ONE contiguous run, copied to LDS as they lie in memory with 16-byte loads.  Both
+// MFMA operands are then read straight from those copies:
+//   A(m, k=(g,sy,sx))  = Al[(g*BM + m)*AP + sy*WS + sx]               lane: m, +1 for the odd k
+//   B(k, n=(cb,ky,kx)) = Bl[(g*CBT + cb)*BP + (2sy+ky)*WB + 2sx + kx]  lane: (cb,ky,kx), +2 for the odd k
+// k runs over sx pairs of a row; for odd WS the second k of a row's last pair does not exist and the
+// odd lanes' A value is forced to zero there.
+struct WgradArgs {
+  const float* small;
+  const void* big;
+  float* slab;
+  int nimg, imgs_per_split, want_db;
+  unsigned small_bytes, big_bytes;
+};
+
+template <int BM_, int BN_, int WM_, int WN_, int GI_, int RB_>
+struct WTile {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, GI = GI_, RB = RB_;
+  static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN), NT = WM * WN * 64;
+  static_assert(TM >= 1 && TN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave grid mismatch");
+};
+
+constexpr int pitch4(int len) {  // >= len, multiple of 4, == 4 (mod 8): at most 2-way conflicts for row-strided lanes
+  int p = (len + 3) & ~3;
+  return (p / 4) % 2 ? p : p + 4;
+}
+
+template <class G, class BigT, class T>
+__global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
+  constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN, NT = T::NT, GI = T::GI, RB = T::RB;
+  constexpr int NW = G::CB * G::KK;
+  constexpr int NB = (G::HS + RB - 1) / RB;  // row bands per image
+  constexpr int BR = 2 * RB + G::KS - 2;     // big rows under a band
+  constexpr int ALEN = RB * G::WS, BLEN = BR * G::WB;
+  constexpr int AP = pitch4(ALEN), BP = pitch4(BLEN);
+  constexpr int CBT = cmin(G::CB, (BN + G::KK - 2) / G::KK + 1);  // big channels an N tile can touch
+  constexpr int A_NV = GI * BM * (AP / 4), B_NV = GI * CBT * (BP / 4);
+  constexpr int A_PER = (A_NV + NT - 1) / NT, B_PER = (B_NV + NT - 1) / NT;
+  constexpr int SXP = (G::WS + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float lds[GI * BM * AP + GI * CBT * BP + 64];
+  float* Al = lds;
+  float* Bl = lds + GI * BM * AP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / T::WN, wn = wid % T::WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+  const int img_beg = z * p.imgs_per_split, img_end = min(p.nimg, img_beg + p.imgs_per_split);
+  const int cbf = n0 / G::KK;
+  const int ngrp = (img_end - img_beg + GI - 1) / GI;
+  const int nch = ngrp * NB;
+
+  const __amdgpu_buffer_rsrc_t rsm = make_rsrc(p.small, p.small_bytes), rbg = make_rsrc(p.big, p.big_bytes);
+
+  // ---- staging roles: element offsets at (image 0, row band 0); g = image within the group
+  int aoff[A_PER], boff[B_PER], ag[A_PER], bg[B_PER];
+  int alds[A_PER], blds[B_PER];
+#pragma unroll
+  for (int j = 0; j < A_PER; ++j) {
+    const int v = tid + j * NT, e4 = v % (AP / 4), rm = v / (AP / 4);
+    const int m = rm % BM, g = rm / BM;
+    const bool act = g < GI && m0 + m < G::CS;
+    ag[j] = act ? g : 1 << 20;
+    aoff[j] = (g * G::CS + m0 + m) * G::PS + e4 * 4;
+    alds[j] = (g * BM + m) * AP + e4 * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < B_PER; ++j) {
+    const int v = tid + j * NT, e4 = v % (BP / 4), rc = v / (BP / 4);
+    const int c = rc % CBT, g = rc / CBT;
+    const bool act = g < GI && cbf + c < G::CB;
+    bg[j] = act ? g : 1 << 20;
+    boff[j] = (g * G::CB + cbf + c) * G::PB + e4 * 4;
+    blds[j] = (g * CBT + c) * BP + e4 * 4;
+  }
+
+  // ---- per-lane fragment bases
+  int abase[TM], bbase[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) abase[i] = ((wm * TM + i) * 32 + li) * AP + lh;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = min(n0 + (wn * TN + j) * 32 + li, NW - 1);
+    const int cb = n / G::KK, r = n % G::KK;
+    bbase[j] = (cb - cbf) * BP + (r / G::KS) * G::WB + r % G::KS + 2 * lh;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float dbsum = 0.f;  // bias-gradient partial: row (tid % BM), element subset (tid / BM)
+
+  f32x4 rav[A_PER];
+  typename Patch4<BigT>::raw_t rbv[B_PER];
+  auto gload = [&](int c) __attribute__((always_inline)) {
+    const int grp = c / NB, band = c % NB;
+    const int img0 = img_beg + grp * GI, r0 = band * RB;
+    const int abias = img0 * G::CS * G::PS + r0 * G::WS, bbias = img0 * G::CB * G::PB + 2 * r0 * G::WB;
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j)
+      rav[j] = VecLoad<4>::load(rsm, img0 + ag[j] < img_end ? 4u * (unsigned)(aoff[j] + abias) : kOobOffset);
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j)
+      rbv[j] = Patch4<BigT>::load(
+          rbg, img0 + bg[j] < img_end ? (unsigned)Patch4<BigT>::BYTES * (unsigned)(boff[j] + bbias) : kOobOffset);
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j)
+      if ((A_NV % NT == 0) || tid + j * NT < A_NV) *reinterpret_cast<f32x4*>(Al + alds[j]) = rav[j];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j)
+      if ((B_NV % NT == 0) || tid + j * NT < B_NV) *reinterpret_cast<f32x4*>(Bl + blds[j]) = Patch4<BigT>::cvt(rbv[j]);
+  };
+  auto compute = [&](int c) __attribute__((always_inline)) {
+    const int band = c % NB;
+    const int R = min(RB, G::HS - band * RB);
+#pragma unroll 1
+    for (int g = 0; g < GI; ++g) {
+#pragma unroll 1
+      for (int sy = 0; sy < R; ++sy) {
+        const float* ar = Al + g * BM * AP + sy * G::WS;
+        const float* br = Bl + g * CBT * BP + 2 * sy * G::WB;
+#pragma unroll
+        for (int sp = 0; sp < SXP; ++sp) {
+          float av[TM], bv[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            av[i] = ar[abase[i] + 2 * sp];
+            if (G::WS % 2 == 1 && sp == SXP - 1) av[i] = lh ? 0.f : av[i];
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bv[j] = br[bbase[j] + 4 * sp];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (p.want_db && blockIdx.x == 0) {  // bias gradient of `small`: row sums of the A chunk
+      constexpr int PARTS = NT / BM;
+      const int m = tid % BM, part = tid / BM;
+      if (part < PARTS) {
+        for (int g = 0; g < GI; ++g)
+          for (int e = part; e < R * G::WS; e += PARTS) dbsum += Al[(g * BM + m) * AP + e];
+      }
+    }
+  };
+
+  if (nch > 0) {
+    gload(0);
+    for (int c = 0; c < nch; ++c) {
+      lstore();
+      __syncthreads();
+      gload(min(c + 1, nch - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      compute(c);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: slab[z][m][n]
+  constexpr int LDS_ = NW + 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + li;
+      const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
+      if (n < NW && mb < G::CS) {
+        float* cdst = p.slab + ((size_t)z * G::CS + mb) * LDS_ + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = (r & 3) + 8 * (r >> 2);
+          if (mb + dm < G::CS) cdst[dm * LDS_] = acc[i][j][r];
+        }
+      }
+    }
+  if (p.want_db && blockIdx.x == 0) {
+    constexpr int PARTS = NT / BM;
+    float* red = lds;  // K loop is over (trailing barrier above)
+    red[tid] = dbsum;
+    __syncthreads();
+    if (tid < BM && m0 + tid < G::CS) {
+      float s = 0.f;
+      for (int q = 0; q < PARTS; ++q) s += red[q * BM + tid];
+      p.slab[((size_t)z * G::CS + m0 + tid) * LDS_ + NW] = s;
+    }
+  }
+}
+
+template <class G, class BigT, class T>
+inline int launch_dconv_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
+  constexpr int NW = G::CB * G::KK;
+  dim3 grid((NW + T::BN - 1) / T::BN, (G::CS + T::BM - 1) / T::BM, (unsigned)splits);
+  hipLaunchKernelGGL((dconv_wgrad_kernel<G, BigT, T>), grid, dim3(T::NT), 0, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
 }  // namespace repo
