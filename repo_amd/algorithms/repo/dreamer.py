@@ -68,6 +68,8 @@ class Dreamer:
         self._ac_side_stream = torch.cuda.Stream(device=self.device)
         # update(): the world-model lane and the actor-critic lane run on their own streams so
         # that WM(k+1) overlaps AC(k) (see update()); events order the only true dependencies
+        # (measured: giving the world-model lane the high-priority hardware queues is SLOWER, 13.5 vs
+        # 11.7 ms/update -- all streams stay at the default priority)
         self._wm_stream = torch.cuda.Stream(device=self.device)
         self._ac_stream = torch.cuda.Stream(device=self.device)
         self._ev_ac_done = None      # AC(k) finished reading the world-model parameters

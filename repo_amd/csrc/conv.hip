@@ -426,18 +426,37 @@ __global__ void partial_sum_kernel(const float* __restrict__ parts, int n, float
   if (threadIdx.x == 0) *out = accumulate ? *out + s : s;
 }
 
-// x[n][c][p] -> partial[s][c] over image chunk s
+// x[n][c][p] -> partial[s][c] over image chunk s.  Threads walk the flattened (image, pixel) index of
+// the chunk with an incremental (img, p) carry, so small planes (P = 25, 169) keep all lanes busy.
 __global__ void channel_sum_kernel(const float* __restrict__ x, int nimg, int C, int P, int imgs_per_split,
                                    float* __restrict__ parts) {
   __shared__ float red[16];
   const int c = blockIdx.x, s = blockIdx.y;
   const int i0 = s * imgs_per_split, i1 = min(nimg, i0 + imgs_per_split);
-  float acc = 0.f;
-  for (int img = i0; img < i1; ++img) {
-    const float* px = x + ((size_t)img * C + c) * P;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) acc += px[p];
+  const int nt = blockDim.x;
+  const int dq = nt / P, dr = nt % P;
+  int img = i0 + (int)threadIdx.x / P, p = (int)threadIdx.x % P;
+  float a0 = 0.f, a1 = 0.f;
+  const size_t cstride = (size_t)C * P;
+  const float* base = x + (size_t)c * P;
+  while (img < i1) {
+    a0 += base[img * cstride + p];
+    p += dr;
+    img += dq;
+    if (p >= P) {
+      p -= P;
+      ++img;
+    }
+    if (img >= i1) break;
+    a1 += base[img * cstride + p];
+    p += dr;
+    img += dq;
+    if (p >= P) {
+      p -= P;
+      ++img;
+    }
   }
-  acc = block_sum(acc, red);
+  const float acc = block_sum(a0 + a1, red);
   if (threadIdx.x == 0) parts[s * C + c] = acc;
 }
 __global__ void channel_sum_final_kernel(const float* __restrict__ parts, int splits, int C, float* __restrict__ out,
@@ -715,8 +734,8 @@ extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* 
 }
 
 static inline int chansum_splits(int64_t nimg, int64_t C, int64_t P) {
-  long want = (1024 + C - 1) / C;
-  long min_imgs = (4096 + P - 1) / P;
+  long want = (4096 + C - 1) / C;
+  long min_imgs = (8192 + P - 1) / P;
   long maxs = (nimg + min_imgs - 1) / min_imgs;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
