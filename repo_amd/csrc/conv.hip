@@ -696,7 +696,8 @@ extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, cons
 static inline long nll_blocks(int64_t nimg) {
   using Op = ConvUpMergedOp<GDec4, float, 1>;
   const long N = nimg * (long)Op::NY * Op::NX;
-  return (N + T32x256::BN - 1) / T32x256::BN;
+  const long old_blocks = (N + T32x256::BN - 1) / T32x256::BN;
+  return old_blocks > 1024 ? old_blocks : 1024;
 }
 
 extern "C" size_t repo_decoder_out_nll_workspace_bytes(int64_t nimg) {
@@ -708,11 +709,22 @@ static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, cons
                              float grad_scale, float* recon, float* dpre, float* loss_sum, void* ws,
                              hipStream_t stream) {
   using G = GDec4;
-  ConvUpMergedOp<G, TgtT, 1> op{h3, w, bias, nullptr, recon, (int)nimg, 0, target, dpre, (float*)ws, grad_scale, 0.f};
-  int rc = launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, stream);
-  if (rc) return rc;
+  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
+  int nparts;
+  if (!old_engine) {
+    nparts = dec4_nll_grid(nimg);
+    NllArgs a{h3, w, bias, target, recon, dpre, (float*)ws, grad_scale, (int)nimg,
+              (unsigned)(nimg * G::CS * G::PS * sizeof(float))};
+    hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
+    REPO_CHECK_LAUNCH();
+  } else {
+    ConvUpMergedOp<G, TgtT, 1> op{h3, w, bias, nullptr, recon, (int)nimg, 0, target, dpre, (float*)ws, grad_scale, 0.f};
+    int rc = launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, stream);
+    if (rc) return rc;
+    nparts = (int)((nimg * (long)op.NY * op.NX + T32x256::BN - 1) / T32x256::BN);
+  }
   if (loss_sum) {
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)ws, (int)nll_blocks(nimg),
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)ws, nparts,
                        loss_sum, 0);
     REPO_CHECK_LAUNCH();
   }

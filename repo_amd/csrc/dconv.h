@@ -722,4 +722,164 @@ inline int launch_dconv_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
+// --------------------------------------------------------------------- decoder output layer + pixel NLL
+// The last transposed convolution has 3 output channels: on 32x32 MFMA tiles nine tenths of the M rows
+// are padding.  Here M = (py, cb, px) = 12 rows sits on v_mfma_f32_16x16x4_f32 (16 rows, K = 4 input
+// channels of one tap per instruction), N = 16 class pixels.  All 32x36x3 weights live in LDS for the
+// whole kernel in FRAGMENT-READY order (one conflict-free ds_read_b32 per MFMA, rows 12..15 zero), the
+// workgroup is persistent over (image, 8 class rows) tiles, and the epilogue is the unit-variance pixel
+// likelihood: d = conv + bias - target, loss += d^2/2, dpre = d * grad_scale (8-byte stores: the two
+// px classes of a pixel are registers 2q, 2q+1 of the same lane).
+struct NllArgs {
+  const float* h3;
+  const float* w;
+  const float* bias;
+  const void* target;
+  float* recon;     // nullable
+  float* dpre;      // nullable
+  float* partials;  // one per workgroup
+  float grad_scale;
+  int nimg;
+  unsigned h3_bytes;
+};
+
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+template <class TgtT>
+__global__ __launch_bounds__(256) void dconv_dec4_nll_kernel(NllArgs p) {
+  constexpr int CS = 32, HS = 30, PS = 900, HB = 64, PP = 34, PLANE = 400, ROWS = 10;
+  constexpr int NVEC = CS * 75, P_PER = (NVEC + 255) / 256;  // 300 floats (10 rows x 30) per channel
+  __shared__ __attribute__((aligned(16))) float lds[9 * 8 * 64 + CS * PLANE];
+  __shared__ float red[16];
+  float* Wf = lds;
+  float* Pl = lds + 9 * 8 * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, lg = lane >> 4;
+  const int ntiles = p.nimg * 4;
+
+  // ---- fragment-ready weights: Wf[(tap*8 + cq)*64 + lane] = w[c = 4cq + lg][cb][py + 2ty][px + 2tx]
+  //      for m = lj = py*6 + cb*2 + px < 12 (tap = ty_*3 + tx_, ty = 2 - ty_, tx = 2 - tx_), else 0
+  for (int i = tid; i < 9 * 8 * 64; i += 256) {
+    const int l = i & 63, cq = (i >> 6) & 7, tap = i >> 9;
+    const int m = l & 15, c = 4 * cq + (l >> 4);
+    float v = 0.f;
+    if (m < 12) {
+      const int py = m / 6, cb = (m % 6) >> 1, px = m & 1;
+      const int ky = py + 2 * (2 - tap / 3), kx = px + 2 * (2 - tap % 3);
+      v = p.w[((c * 3 + cb) * 6 + ky) * 6 + kx];
+    }
+    Wf[i] = v;
+  }
+  for (int i = tid; i < CS * PLANE / 4; i += 256) reinterpret_cast<f32x4*>(Pl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- patch staging roles (identical for every tile)
+  const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.h3, p.h3_bytes);
+  int pgo[P_PER];
+  short plds[P_PER][4];
+  unsigned long long mtop = 0ull, mbot = 0ull;  // element (j,e) lies in patch rows 0..1 / 8..9
+#pragma unroll
+  for (int j = 0; j < P_PER; ++j) {
+    const int v = tid + j * 256, c = v / 75, e4 = v % 75;
+    const bool act = v < NVEC;
+    pgo[j] = act ? c * PS + e4 * 4 : -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = e4 * 4 + e, r = q / 30;
+      plds[j][e] = act ? (short)(c * PLANE + r * PP + q % 30 + 2) : (short)-1;
+      if (r < 2) mtop |= 1ull << (j * 4 + e);
+      if (r >= 8) mbot |= 1ull << (j * 4 + e);
+    }
+  }
+  // ---- per-lane B bases: wave wv owns class rows 2wv, 2wv+1 of the tile, two 16-pixel halves each
+  int bbase[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) bbase[t] = lg * PLANE + (2 * wv + (t >> 1)) * PP + 16 * (t & 1) + lj;
+
+  f32x4 rpv[P_PER];
+  auto gload = [&](int tile) __attribute__((always_inline)) {
+    const int img = tile >> 2, cy0 = (tile & 3) * 8;
+    const int bias_ = img * CS * PS + (cy0 - 2) * HS;
+#pragma unroll
+    for (int j = 0; j < P_PER; ++j)
+      rpv[j] = VecLoad<4>::load(rh, pgo[j] >= 0 ? 4u * (unsigned)(pgo[j] + bias_) : kOobOffset);
+  };
+  auto lstore = [&](int tile) __attribute__((always_inline)) {
+    const int rg = tile & 3;
+    const unsigned long long bad = (rg == 0 ? mtop : 0ull) | (rg == 3 ? mbot : 0ull);
+#pragma unroll
+    for (int j = 0; j < P_PER; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (plds[j][e] >= 0) Pl[plds[j][e]] = ((bad >> (j * 4 + e)) & 1ull) ? 0.f : rpv[j][e];
+  };
+
+  float lsum = 0.f;
+  const int G = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile < ntiles) gload(tile);
+  __syncthreads();  // weights + zero fill visible
+  for (; tile < ntiles; tile += G) {
+    lstore(tile);
+    __syncthreads();
+    if (tile + G < ntiles) gload(tile + G);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4acc acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int cq = 0; cq < 8; ++cq) {
+        const float a = Wf[(tap * 8 + cq) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float b = Pl[bbase[t] + 4 * cq * PLANE + (tap / 3) * PP + tap % 3];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+
+    // ---- epilogue
+    const int img = tile >> 2, cy0 = (tile & 3) * 8;
+    if (lg < 3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int cy = cy0 + 2 * wv + (t >> 1), cx = 16 * (t & 1) + lj;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int q = 2 * lg + pr, py = q / 3, cb = q % 3;
+          const int o = ((img * 3 + cb) * HB + 2 * cy + py) * HB + 2 * cx;
+          const float bv = p.bias ? p.bias[cb] : 0.f;
+          const float v0 = acc[t][2 * pr] + bv, v1 = acc[t][2 * pr + 1] + bv;
+          float t0, t1;
+          if (sizeof(TgtT) == 1) {
+            const unsigned short tw = *reinterpret_cast<const unsigned short*>((const uint8_t*)p.target + o);
+            t0 = pix_norm((uint8_t)(tw & 0xff));
+            t1 = pix_norm((uint8_t)(tw >> 8));
+          } else {
+            const float2 tw = *reinterpret_cast<const float2*>((const float*)p.target + o);
+            t0 = tw.x;
+            t1 = tw.y;
+          }
+          const float d0 = v0 - t0, d1 = v1 - t1;
+          lsum += 0.5f * (d0 * d0 + d1 * d1);
+          if (p.dpre) *reinterpret_cast<float2*>(p.dpre + o) = make_float2(d0 * p.grad_scale, d1 * p.grad_scale);
+          if (p.recon) *reinterpret_cast<float2*>(p.recon + o) = make_float2(v0, v1);
+        }
+      }
+    }
+    __syncthreads();  // patch reads done before the next tile overwrites it
+  }
+  const float s = block_sum(lsum, red);
+  if (tid == 0) p.partials[blockIdx.x] = s;
+}
+
+inline int dec4_nll_grid(long nimg) {
+  const long ntiles = nimg * 4;
+  return (int)(ntiles < 1024 ? ntiles : 1024);
+}
+
 }  // namespace repo
