@@ -546,10 +546,14 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
   constexpr int NW = G::CB * G::KK;
   constexpr int NB = (G::HS + RB - 1) / RB;  // row bands per image
   constexpr int BR = 2 * RB + G::KS - 2;     // big rows under a band
-  constexpr int ALEN = RB * G::WS, BLEN = BR * G::WB;
+  // rows of `big` keep their memory pitch in LDS unless that pitch is a multiple of the 64 banks (the
+  // 64-pixel frames): lanes (ky, kx) of a B fragment would then hit one bank KS times over
+  constexpr int BRP = (G::WB % 64 == 0) ? G::WB + 4 : G::WB;
+  constexpr int ALEN = RB * G::WS, BLEN = BR * BRP;
   constexpr int AP = pitch4(ALEN), BP = pitch4(BLEN);
   constexpr int CBT = cmin(G::CB, (BN + G::KK - 2) / G::KK + 1);  // big channels an N tile can touch
-  constexpr int A_NV = GI * BM * (AP / 4), B_NV = GI * CBT * (BP / 4);
+  constexpr int A_VPC = (ALEN + 3) / 4, B_VPC = (BR * G::WB + 3) / 4;  // vectors copied per (image, channel)
+  constexpr int A_NV = GI * BM * A_VPC, B_NV = GI * CBT * B_VPC;
   constexpr int A_PER = (A_NV + NT - 1) / NT, B_PER = (B_NV + NT - 1) / NT;
   constexpr int SXP = (G::WS + 1) / 2;
   __shared__ __attribute__((aligned(16))) float lds[GI * BM * AP + GI * CBT * BP + 64];
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
   int alds[A_PER], blds[B_PER];
 #pragma unroll
   for (int j = 0; j < A_PER; ++j) {
-    const int v = tid + j * NT, e4 = v % (AP / 4), rm = v / (AP / 4);
+    const int v = tid + j * NT, e4 = v % A_VPC, rm = v / A_VPC;
     const int m = rm % BM, g = rm / BM;
     const bool act = g < GI && m0 + m < G::CS;
     ag[j] = act ? g : 1 << 20;
@@ -584,12 +588,12 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
   }
 #pragma unroll
   for (int j = 0; j < B_PER; ++j) {
-    const int v = tid + j * NT, e4 = v % (BP / 4), rc = v / (BP / 4);
+    const int v = tid + j * NT, e4 = v % B_VPC, rc = v / B_VPC;
     const int c = rc % CBT, g = rc / CBT;
     const bool act = g < GI && cbf + c < G::CB;
     bg[j] = act ? g : 1 << 20;
     boff[j] = (g * G::CB + cbf + c) * G::PB + e4 * 4;
-    blds[j] = (g * CBT + c) * BP + e4 * 4;
+    blds[j] = (g * CBT + c) * BP + (BRP == G::WB ? e4 * 4 : (e4 * 4 / G::WB) * BRP + e4 * 4 % G::WB);
   }
 
   // ---- per-lane fragment bases
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
   for (int j = 0; j < TN; ++j) {
     const int n = min(n0 + (wn * TN + j) * 32 + li, NW - 1);
     const int cb = n / G::KK, r = n % G::KK;
-    bbase[j] = (cb - cbf) * BP + (r / G::KS) * G::WB + r % G::KS + 2 * lh;
+    bbase[j] = (cb - cbf) * BP + (r / G::KS) * BRP + r % G::KS + 2 * lh;
   }
 
   f32x16 acc[TM][TN];
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
 #pragma unroll 1
       for (int sy = 0; sy < R; ++sy) {
         const float* ar = Al + g * BM * AP + sy * G::WS;
-        const float* br = Bl + g * CBT * BP + 2 * sy * G::WB;
+        const float* br = Bl + g * CBT * BP + 2 * sy * BRP;
 #pragma unroll
         for (int sp = 0; sp < SXP; ++sp) {
           float av[TM], bv[TN];
