@@ -384,8 +384,16 @@ __global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, int spli
   const int total = Mrows * (Ncols + 1);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int m = i / (Ncols + 1), n = i % (Ncols + 1);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed-order independent chains
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+      s0 += slab[(size_t)z * total + i];
+      s1 += slab[(size_t)(z + 1) * total + i];
+      s2 += slab[(size_t)(z + 2) * total + i];
+      s3 += slab[(size_t)(z + 3) * total + i];
+    }
+    for (; z < splits; ++z) s0 += slab[(size_t)z * total + i];
+    const float s = (s0 + s1) + (s2 + s3);
     if (n < Ncols) {
       float* p = dw + (size_t)m * Ncols + n;
       *p = accumulate ? *p + s : s;
@@ -459,13 +467,16 @@ __global__ void channel_sum_kernel(const float* __restrict__ x, int nimg, int C,
   const float acc = block_sum(a0 + a1, red);
   if (threadIdx.x == 0) parts[s * C + c] = acc;
 }
+// one wave per channel: lanes stride over the splits, fixed-order shuffle reduction (bit-reproducible)
 __global__ void channel_sum_final_kernel(const float* __restrict__ parts, int splits, int C, float* __restrict__ out,
                                          int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += parts[z * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  for (int z = lane; z < splits; z += 64) s += parts[z * C + c];
+  s = wave_sum(s);
+  if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 __global__ void relu_mask_kernel(int64_t n, const float* __restrict__ dy, const float* __restrict__ h,
@@ -771,7 +782,7 @@ extern "C" int repo_channel_sum(int64_t nimg, int64_t C, int64_t P, const float*
   hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C, (unsigned)splits), dim3(256), 0, stream, x, (int)nimg, (int)C,
                      (int)P, ips, (float*)ws);
   REPO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, splits,
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, splits,
                      (int)C, out, accumulate);
   REPO_CHECK_LAUNCH();
   return REPO_OK;

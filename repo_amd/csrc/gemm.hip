@@ -225,8 +225,17 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, i
   const int total = Mrows * (Kcols + 1);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int m = i / (Kcols + 1), n = i % (Kcols + 1);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
+    // four independent chains (fixed order -> reproducible) so the loads of a thread overlap
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+      s0 += slab[(size_t)z * total + i];
+      s1 += slab[(size_t)(z + 1) * total + i];
+      s2 += slab[(size_t)(z + 2) * total + i];
+      s3 += slab[(size_t)(z + 3) * total + i];
+    }
+    for (; z < splits; ++z) s0 += slab[(size_t)z * total + i];
+    const float s = (s0 + s1) + (s2 + s3);
     if (n < Kcols) {
       float* p = dW + (size_t)m * lddw + n;
       *p = accumulate ? *p + s : s;
