@@ -566,7 +566,23 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
   const int wm = wid / T::WN, wn = wid % T::WN;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+  // XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its
+  // own L2).  All tiles of one split z read the same images, so they are placed on ONE XCD: within a
+  // group of 8 splits, workgroup L takes split (L % 8) and tile (L / 8) of that split.
+  int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+  {
+    const int tpz = gridDim.x * gridDim.y, gz = gridDim.z;
+    const int L = bx + gridDim.x * (by + gridDim.y * z);
+    const int full = (gz / 8) * 8 * tpz;  // workgroups covered by complete groups of 8 splits
+    if (L < full) {
+      const int grp = L / (8 * tpz), r = L % (8 * tpz);
+      const int t = r / 8;
+      z = grp * 8 + r % 8;
+      bx = t % (int)gridDim.x;
+      by = t / (int)gridDim.x;
+    }
+  }
+  const int n0 = bx * BN, m0 = by * BM;
   const int img_beg = z * p.imgs_per_split, img_end = min(p.nimg, img_beg + p.imgs_per_split);
   const int cbf = n0 / G::KK;
   const int ngrp = (img_end - img_beg + GI - 1) / GI;
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
         }
       }
     }
-    if (p.want_db && blockIdx.x == 0) {  // bias gradient of `small`: row sums of the A chunk
+    if (p.want_db && bx == 0) {  // bias gradient of `small`: row sums of the A chunk
       constexpr int PARTS = NT / BM;
       const int m = tid % BM, part = tid / BM;
       if (part < PARTS) {
@@ -704,7 +720,7 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
         }
       }
     }
-  if (p.want_db && blockIdx.x == 0) {
+  if (p.want_db && bx == 0) {
     constexpr int PARTS = NT / BM;
     float* red = lds;  // K loop is over (trailing barrier above)
     red[tid] = dbsum;
