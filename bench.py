@@ -81,8 +81,10 @@ def synthetic_batch(seed=1234):
 
 def dominant_kernel_roofline(iters=20):
     """Decoder conv3 (64x13x13 -> 32x30x30, k6 s2) as launched inside the update: the largest
-    single contraction (61.0 GFLOP of the 118.6 GFLOP decoder forward).  Its four parity-class
-    launches are timed together with HIP events on the launch stream."""
+    single launch (61.05 GFLOP; dconv_up_kernel<GDec3>, all four parity classes in one launch), timed
+    with HIP events on the launch stream.  `traffic` is that launch's HBM bytes from the rocprofv3 PMC
+    passes committed in profiles/r01_pmc_direct_conv.txt (FETCH_SIZE x2 for the gfx950 wide-read
+    under-report + WRITE_SIZE, per launch of the same nimg=2450 shape)."""
     from repo_amd import ops
 
     nimg = (L - 1) * B
@@ -105,9 +107,9 @@ def dominant_kernel_roofline(iters=20):
     achieved = flop / (ms * 1e-3) / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "igemm_kernel<ConvUpOp<GDec3>> x4 parity classes (decoder conv3 forward)",
-        "ms_per_launch_group": round(ms, 4), "flop_per_launch_group": flop,
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": 7.05e8,
+        "kernel": "dconv_up_kernel<Geo<32,64,30,6>, UTile<128,2>> (decoder conv3 forward)",
+        "ms_per_launch": round(ms, 4), "flop_per_launch": flop, "mfma_pipe_busy_pmc": 0.795,
     }
 
 
