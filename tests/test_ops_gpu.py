@@ -105,7 +105,7 @@ def _layer_tensors(ops, layer, nimg, seed):
 
 
 @pytest.mark.parametrize("layer", range(7))
-@pytest.mark.parametrize("nimg", [1, 5])
+@pytest.mark.parametrize("nimg", [1, 5, 37])  # 37: pixel tiles that straddle several images / ragged last tile
 def test_conv_down(ops, layer, nimg):
     big, small, w, rs = _layer_tensors(ops, layer, nimg, 100 + layer)
     cs = small.shape[1]
@@ -132,7 +132,7 @@ def test_conv_down_u8(ops):
 
 
 @pytest.mark.parametrize("layer", range(7))
-@pytest.mark.parametrize("nimg", [1, 5])
+@pytest.mark.parametrize("nimg", [1, 5, 37])
 def test_conv_up(ops, layer, nimg):
     big, small, w, rs = _layer_tensors(ops, layer, nimg, 200 + layer)
     cb = big.shape[1]
@@ -159,7 +159,7 @@ def test_conv_up(ops, layer, nimg):
 
 
 @pytest.mark.parametrize("layer", range(7))
-@pytest.mark.parametrize("nimg", [1, 9])
+@pytest.mark.parametrize("nimg", [1, 9, 75])  # 75: several image groups per split, ragged last group and split
 def test_conv_wgrad(ops, layer, nimg):
     big, small, w, rs = _layer_tensors(ops, layer, nimg, 300 + layer)
     bigd = big.double().requires_grad_(False)
@@ -187,10 +187,9 @@ def test_conv_wgrad_u8(ops):
     assert relerr(dw, wd.grad) < TOL
 
 
-@pytest.mark.parametrize("u8", [True, False])
-def test_decoder_out_nll(ops, u8):
+@pytest.mark.parametrize("u8,nimg", [(True, 6), (False, 6), (True, 300)])  # 300 images: persistent tile loop
+def test_decoder_out_nll(ops, u8, nimg):
     rs = np.random.RandomState(9)
-    nimg = 6
     h3 = F.relu(rnd(rs, nimg, 32, 30, 30))
     w, b = rnd(rs, 32, 3, 6, 6, scale=0.05), rnd(rs, 3)
     obs = torch.from_numpy(rs.randint(0, 256, size=(nimg, 3, 64, 64)).astype(np.uint8))
