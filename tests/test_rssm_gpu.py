@@ -38,7 +38,7 @@ def cu(d):
     return [v.detach().cuda().contiguous() for v in d.values()]
 
 
-@pytest.mark.parametrize("T,B,A", [(7, 4, 6), (5, 3, 7), (49, 16, 6), (3, 130, 6)])
+@pytest.mark.parametrize("T,B,A", [(7, 4, 6), (5, 3, 7), (49, 16, 6), (3, 130, 6), (6, 51, 6)])
 def test_observe_fwd_bwd(ops, T, B, A):
     rs = np.random.RandomState(T * 100 + B)
     D, S, E = 200, 30, 1024
