@@ -100,9 +100,10 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   constexpr int PLV = PLMAX / 4;
   constexpr int W_NV = BM * KSL / 4, W_KV = KSL / 4;  // weight vectors per chunk / per row
   constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * PLV + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) float lds[2 * KSL * LDW + 2 * CK * PLMAX];
+  constexpr int NBUF = NSL > 1 ? 2 : 1;  // a single channel chunk (the 3-channel layers) needs one buffer
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * KSL * LDW + NBUF * CK * PLMAX];
   float* Wl = lds;
-  float* Pl = lds + 2 * KSL * LDW;
+  float* Pl = lds + NBUF * KSL * LDW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -224,19 +225,23 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   lstore(0);
   __syncthreads();
   REPO_STAMP(5);
-  int buf = 0;
-  for (int t = 0; t < NSL; ++t) {
-    gload(min(t + 1, NSL - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    REPO_STAMP(0);
-    compute(buf);
-    __builtin_amdgcn_sched_barrier(0);
-    REPO_STAMP(1);
-    lstore(buf ^ 1);
-    REPO_STAMP(2);
-    __syncthreads();
-    REPO_STAMP(3);
-    buf ^= 1;
+  if (NSL == 1) {
+    compute(0);
+  } else {
+    int buf = 0;
+    for (int t = 0; t < NSL; ++t) {
+      gload(min(t + 1, NSL - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      REPO_STAMP(0);
+      compute(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      REPO_STAMP(1);
+      lstore(buf ^ 1);
+      REPO_STAMP(2);
+      __syncthreads();
+      REPO_STAMP(3);
+      buf ^= 1;
+    }
   }
 
   // ---- epilogue: lane = pixel column, 16 channel rows per accumulator tile
