@@ -771,7 +771,7 @@ struct NllArgs {
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
 template <class TgtT>
-__global__ __launch_bounds__(256) void dconv_dec4_nll_kernel(NllArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dconv_dec4_nll_kernel(NllArgs p) {
   constexpr int CS = 32, HS = 30, PS = 900, HB = 64, PP = 34, PLANE = 400, ROWS = 10;
   constexpr int NVEC = CS * 75, P_PER = (NVEC + 255) / 256;  // 300 floats (10 rows x 30) per channel
   __shared__ __attribute__((aligned(16))) float lds[9 * 8 * 64 + CS * PLANE];
@@ -803,17 +803,18 @@ __global__ __launch_bounds__(256) void dconv_dec4_nll_kernel(NllArgs p) {
   // ---- patch staging roles (identical for every tile)
   const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.h3, p.h3_bytes);
   int pgo[P_PER];
-  short plds[P_PER][4];
+  int ppk[P_PER];  // LDS address of element 0 | its column << 16 (elements 1..3 follow, +4 across a row end)
   unsigned long long mtop = 0ull, mbot = 0ull;  // element (j,e) lies in patch rows 0..1 / 8..9
 #pragma unroll
   for (int j = 0; j < P_PER; ++j) {
     const int v = tid + j * 256, c = v / 75, e4 = v % 75;
     const bool act = v < NVEC;
     pgo[j] = act ? c * PS + e4 * 4 : -1;
+    const int q0 = e4 * 4;
+    ppk[j] = (c * PLANE + (q0 / 30) * PP + q0 % 30 + 2) | ((q0 % 30) << 16);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int q = e4 * 4 + e, r = q / 30;
-      plds[j][e] = act ? (short)(c * PLANE + r * PP + q % 30 + 2) : (short)-1;
+      const int r = (q0 + e) / 30;
       if (r < 2) mtop |= 1ull << (j * 4 + e);
       if (r >= 8) mbot |= 1ull << (j * 4 + e);
     }
@@ -836,9 +837,12 @@ __global__ __launch_bounds__(256) void dconv_dec4_nll_kernel(NllArgs p) {
     const unsigned long long bad = (rg == 0 ? mtop : 0ull) | (rg == 3 ? mbot : 0ull);
 #pragma unroll
     for (int j = 0; j < P_PER; ++j)
+      if (pgo[j] >= 0) {
+        const int base = ppk[j] & 0xffff, col0 = ppk[j] >> 16;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (plds[j][e] >= 0) Pl[plds[j][e]] = ((bad >> (j * 4 + e)) & 1ull) ? 0.f : rpv[j][e];
+        for (int e = 0; e < 4; ++e)
+          Pl[base + e + (col0 + e >= 30 ? PP - 30 : 0)] = ((bad >> (j * 4 + e)) & 1ull) ? 0.f : rpv[j][e];
+      }
   };
 
   float lsum = 0.f;
