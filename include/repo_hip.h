@@ -51,6 +51,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 int repo_abi_version(void);
 const char* repo_strerror(int code);
+/* Test aid: fills every CU's LDS with NaN patterns (see tests/test_ops_gpu.py::test_no_uninitialised_lds). */
+int repo_debug_poison_lds(hipStream_t stream);
 
 /* ------------------------------------------------------------------ dense layers
  * C[m][n] (+)= epi( sum_k opA(m,k) * opB(k,n) + bias[n / bias_div] )

@@ -16,3 +16,26 @@ extern "C" const char* repo_strerror(int code) {
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "unknown error";
 }
+
+// Debug aid for the parity tests: fill the LDS of every CU with NaN bit patterns, so that a kernel which
+// reads LDS it never wrote (and, say, multiplies it by zero) shows up deterministically instead of once
+// in a dozen runs.  LDS contents persist until a later workgroup on that CU overwrites them.
+namespace repo {
+__global__ __launch_bounds__(256) void poison_lds_kernel(int words, unsigned* sink) {
+  extern __shared__ unsigned plds[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) plds[i] = 0x7fc00000u + (unsigned)i;
+  __syncthreads();
+  if (plds[(threadIdx.x * 7919) % words] == 0u && sink) *sink = 1u;  // keep the stores alive
+}
+}  // namespace repo
+
+extern "C" int repo_debug_poison_lds(hipStream_t stream) {
+  const int bytes = 160 * 1024;
+  hipError_t e = hipFuncSetAttribute((const void*)repo::poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     bytes);
+  if (e != hipSuccess) return (int)e;
+  // one workgroup occupies a whole CU's LDS; several waves of workgroups cover all 256 CUs
+  hipLaunchKernelGGL(repo::poison_lds_kernel, dim3(1024), dim3(256), bytes, stream, bytes / 4, (unsigned*)nullptr);
+  e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}

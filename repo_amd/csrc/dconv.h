@@ -677,7 +677,12 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
             if (G::WS % 2 == 1 && sp == SXP - 1) av[i] = lh ? 0.f : av[i];
           }
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bv[j] = br[bbase[j] + 4 * sp];
+          for (int j = 0; j < TN; ++j) {
+            bv[j] = br[bbase[j] + 4 * sp];
+            // the non-existent second k of an odd row's last pair reads past the row (for the band's last
+            // row: past the copy, i.e. uninitialised LDS); 0 * NaN would poison the sum, so zero both sides
+            if (G::WS % 2 == 1 && sp == SXP - 1) bv[j] = lh ? 0.f : bv[j];
+          }
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll

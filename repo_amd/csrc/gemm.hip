@@ -276,6 +276,10 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
     REPO_REQUIRE(ea < kMaxIdx && eb < kMaxIdx && M * ldc < kMaxIdx && M * ldaux < kMaxIdx, REPO_E_SHAPE);
   }
   if (bias_div <= 0) bias_div = 1;
+  // K == 1 (outer products, e.g. the gradient through a scalar output layer): a contiguous M x 1 / N x 1
+  // operand is its own transpose, which turns its k-vectors (K % 2 != 0: gather engine) into m/n-vectors
+  if (K == 1 && !transa && lda == 1) { transa = 1; lda = M; }
+  if (K == 1 && transb && ldb == 1) { transb = 0; ldb = N; }
   // vector-load engine whenever the k-contiguous operands (A if !transa, B if transb) have K % VW == 0
   static const bool old_engine = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
   const bool kvec = !transa || transb;

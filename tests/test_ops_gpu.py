@@ -29,7 +29,7 @@ def dev(t):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(50, 200, 36), (2450, 200, 230), (784, 1024, 230), (33, 60, 200), (700, 640, 130), (1, 1, 1), (65, 129, 17)])
+@pytest.mark.parametrize("M,N,K", [(50, 200, 36), (2450, 200, 230), (784, 1024, 230), (33, 60, 200), (700, 640, 130), (1, 1, 1), (65, 129, 17), (3000, 200, 1), (300, 7, 1)])
 def test_gemm_layouts(ops, ta, tb, M, N, K):
     rs = np.random.RandomState(M * 7 + N * 3 + K)
     A = rnd(rs, K, M) if ta else rnd(rs, M, K)
@@ -212,3 +212,50 @@ def test_channel_sum_relu_mask(ops):
     assert relerr(acc, x.double().sum((0, 2)) + 1) < TOL
     dy, h = rnd(rs, 1000, 33), F.relu(rnd(rs, 1000, 33))
     assert float((ops.relu_mask(dev(dy), dev(h)).cpu() - dy * (h > 0)).abs().max()) == 0
+
+
+def test_no_uninitialised_lds(ops):
+    """Every direct-conv / GEMM kernel must give the same bits after the LDS of all CUs has been filled
+    with NaN patterns: a kernel that reads LDS it did not write (even to multiply it by zero) fails here
+    deterministically instead of once in a dozen runs."""
+    from repo_amd._lib import lib
+
+    def poison():
+        assert lib().repo_debug_poison_lds(torch.cuda.current_stream().cuda_stream) == 0
+
+    rs = np.random.RandomState(77)
+    for layer in range(7):
+        for nimg in (3, 37):
+            big, small, w, _ = _layer_tensors(ops, layer, nimg, 900 + layer)
+            big, small, w = dev(big), dev(small), dev(w)
+            outs = []
+            for p in (False, True):
+                if p:
+                    poison()
+                d = ops.conv_down(layer, big, w)
+                if p:
+                    poison()
+                u = ops.conv_up(layer, small, w)
+                if p:
+                    poison()
+                dw, db = ops.conv_wgrad(layer, small, big)
+                outs.append((d, u, dw, db))
+            for a, b in zip(*outs):
+                assert torch.isfinite(b).all(), (layer, nimg)
+                assert torch.equal(a, b), (layer, nimg)
+    h3, w4, b4 = dev(rnd(rs, 9, 32, 30, 30)), dev(rnd(rs, 32, 3, 6, 6, scale=0.05)), dev(rnd(rs, 3))
+    tgt = dev(torch.from_numpy(rs.randint(0, 256, size=(9, 3, 64, 64)).astype(np.uint8)))
+    ref = ops.decoder_out_nll(h3, w4, b4, tgt, 0.5)
+    poison()
+    got = ops.decoder_out_nll(h3, w4, b4, tgt, 0.5)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    for (M, N, K) in ((333, 200, 230), (70, 1024, 36), (500, 7, 1)):
+        A, B = dev(rnd(rs, M, K)), dev(rnd(rs, K, N))
+        ref = ops.gemm(A, B)
+        poison()
+        assert torch.equal(ref, ops.gemm(A, B))
+        dy = dev(rnd(rs, M, N))
+        r1 = ops.gemm_wgrad(dy, A)
+        poison()
+        r2 = ops.gemm_wgrad(dy, A)
+        assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
