@@ -17,6 +17,15 @@ from tests.util import l2err, log, relerr, rnd
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _poison_lds():
+    """Start every test from NaN-filled LDS on all CUs: reads of never-written LDS cannot hide."""
+    from repo_amd._lib import lib
+
+    assert lib().repo_debug_poison_lds(torch.cuda.current_stream().cuda_stream) == 0
+    yield
+
 FTOL = 1e-5
 GTOL = 1e-4
 
