@@ -509,6 +509,14 @@ template <> struct DTileFor<GDec2> { using Down = DTile<64, 128, 4, 2, 2>;   usi
 template <> struct DTileFor<GDec3> { using Down = DTile<64, 128, 2, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 1, 7>; };
 template <> struct DTileFor<GDec4> { using Down = DTile<32, 256, 3, 1, 4>;   using Wgrad = WTile<32, 128, 1, 4, 1, 6>; };
 
+// A handful of frames (the acting path encodes ONE per environment step): the throughput tiles leave 1-2
+// workgroups walking 16-64 dependent channel chunks (enc4: 147 us for one frame).  Latency tiles use 32
+// output channels per workgroup (4-8x more workgroups) and 4x larger channel chunks (4x fewer barriers).
+template <class G> struct DLatTile { using type = typename DTileFor<G>::Down; };
+template <> struct DLatTile<GEnc2> { using type = DTile<32, 128, 4, 1, 4>; };
+template <> struct DLatTile<GEnc3> { using type = DTile<32, 128, 8, 1, 4>; };
+template <> struct DLatTile<GEnc4> { using type = DTile<32, 128, 8, 1, 4>; };
+
 template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
                        const float* aux, hipStream_t s) {
@@ -517,6 +525,7 @@ static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const floa
   if (!old_engine) {
     DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
                (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
+    if (nimg * (int64_t)G::PS <= 512) return launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s);
     return launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
   }
   ConvDownOp<G, BigT> op{big, w, bias, aux, small, (int)nimg, epi};

@@ -98,6 +98,61 @@ struct VGemmOp {
   __device__ void finish() {}
 };
 
+// M <= 8 rows (the acting path: one frame per environment step): a tile engine spends its time in the
+// 13-77 dependent K slices (14 us per 200x230 layer); here one wave owns an output column and its lanes
+// split K (k-contiguous weights) or one thread owns a column and walks K with coalesced rows.
+template <bool TB>
+__global__ __launch_bounds__(256) void gemv_small_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                         const float* __restrict__ B, int ldb,
+                                                         const float* __restrict__ bias, int bias_div,
+                                                         float* __restrict__ C, int ldc, int epi,
+                                                         const float* __restrict__ aux, int ldaux, int accumulate) {
+  constexpr int MR = 8;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  int n;
+  bool writer;
+  if (TB) {  // B[n][k]: one wave per column, lanes over k
+    const int lane = threadIdx.x & 63;
+    n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    for (int k = lane; k < K; k += 64) {
+      const float b = B[(size_t)n * ldb + k];
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+        if (m < M) acc[m] = fmaf(A[(size_t)m * lda + k], b, acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = wave_sum(acc[m]);
+    writer = lane == 0;
+  } else {  // B[k][n]: one thread per column
+    n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    for (int k = 0; k < K; ++k) {
+      const float b = B[(size_t)k * ldb + n];
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+        if (m < M) acc[m] = fmaf(A[(size_t)m * lda + k], b, acc[m]);
+    }
+    writer = true;
+  }
+  if (!writer) return;
+  const float bv = bias ? bias[bias_div == 1 ? n : n / bias_div] : 0.f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+    if (m < M) {
+      float v = acc[m] + bv;
+      if (epi == REPO_EPI_ELU) v = elu(v);
+      else if (epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
+      else if (epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(aux[(size_t)m * ldaux + n]);
+      else if (epi == REPO_EPI_MUL_DRELU) v = aux[(size_t)m * ldaux + n] > 0.f ? v : 0.f;
+      float* c = C + (size_t)m * ldc + n;
+      if (accumulate) v += *c;
+      *c = v;
+    }
+}
+
 template <class Op>
 static int vgemm_dispatch(const Op& op, long M, long N, hipStream_t s) {
   static const int force = getenv("REPO_GEMM_TILE") ? atoi(getenv("REPO_GEMM_TILE")) : 0;  // experiments only
@@ -259,6 +314,11 @@ static int wgrad_splits(long rows, long N, long K) {
 
 using namespace repo;
 
+static bool old_engine_gemv() {
+  static const bool v = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
+  return v;
+}
+
 extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K, const float* A,
                          int64_t lda, const float* B, int64_t ldb, const float* bias, int64_t bias_div,
                          float* C, int64_t ldc, int epi, const float* aux, int64_t ldaux, int accumulate,
@@ -280,6 +340,17 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
   // operand is its own transpose, which turns its k-vectors (K % 2 != 0: gather engine) into m/n-vectors
   if (K == 1 && !transa && lda == 1) { transa = 1; lda = M; }
   if (K == 1 && transb && ldb == 1) { transb = 0; ldb = N; }
+  if (M <= 8 && !transa && !old_engine_gemv()) {
+    if (transb) {
+      hipLaunchKernelGGL((gemv_small_kernel<true>), dim3(cdiv(N, 4)), dim3(256), 0, stream, (int)M, (int)N, (int)K, A,
+                         (int)lda, B, (int)ldb, bias, (int)bias_div, C, (int)ldc, epi, aux, (int)ldaux, accumulate);
+    } else {
+      hipLaunchKernelGGL((gemv_small_kernel<false>), dim3(cdiv(N, 256)), dim3(256), 0, stream, (int)M, (int)N, (int)K,
+                         A, (int)lda, B, (int)ldb, bias, (int)bias_div, C, (int)ldc, epi, aux, (int)ldaux, accumulate);
+    }
+    REPO_CHECK_LAUNCH();
+    return REPO_OK;
+  }
   // vector-load engine whenever the k-contiguous operands (A if !transa, B if transb) have K % VW == 0
   static const bool old_engine = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
   const bool kvec = !transa || transb;

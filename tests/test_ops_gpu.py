@@ -29,7 +29,7 @@ def dev(t):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(50, 200, 36), (2450, 200, 230), (784, 1024, 230), (33, 60, 200), (700, 640, 130), (1, 1, 1), (65, 129, 17), (3000, 200, 1), (300, 7, 1)])
+@pytest.mark.parametrize("M,N,K", [(50, 200, 36), (2450, 200, 230), (784, 1024, 230), (33, 60, 200), (700, 640, 130), (1, 1, 1), (65, 129, 17), (3000, 200, 1), (300, 7, 1), (1, 200, 230), (5, 60, 200), (8, 600, 1224)])
 def test_gemm_layouts(ops, ta, tb, M, N, K):
     rs = np.random.RandomState(M * 7 + N * 3 + K)
     A = rnd(rs, K, M) if ta else rnd(rs, M, K)
