@@ -187,7 +187,9 @@ def main():
     set_gpu_mode(True, local_rank)
     dev = torch.device("cuda", local_rank)
     dp = None
-    if world > 1:
+    # REPO_FORCE_DP=1: take the RCCL path with a single rank too (exercises process-group init and the
+    # collectives on the update's lane streams on a 1-GPU box)
+    if world > 1 or os.environ.get("REPO_FORCE_DP") == "1":
         import torch.distributed as dist
 
         from repo_amd.parallel import DataParallel

@@ -63,9 +63,16 @@ class Dreamer:
             obs_type=np.uint8 if config.pixel_obs else np.float32,
         )
         self.free_nats = torch.full((1,), float(config.free_nats), device=self.device)
-        self._side_stream = torch.cuda.Stream(device=self.device)
-        self._wgrad_stream = torch.cuda.Stream(device=self.device)
-        self._ac_side_stream = torch.cuda.Stream(device=self.device)
+        # Intra-lane overlaps: w = weight-gradient kernels beside the data-gradient chain, s = reverse scan
+        # beside the decoder backward, c = critic update beside the actor backward.  HIP multiplexes streams
+        # onto 4 hardware queues (GPU_MAX_HW_QUEUES); measured over {4, 8} queues x {with, without RCCL's own
+        # stream} (tools/ovl_sweep.sh) "ws" gives 93.5-95.6 updates/s in all four, while adding "c" swings
+        # between 81.6 and 96.6 depending on which streams happen to share a queue -- so the critic stays on
+        # the actor-critic lane's own stream.
+        ovl = os.environ.get("REPO_OVL", "ws")
+        self._side_stream = torch.cuda.Stream(device=self.device) if "s" in ovl else None
+        self._wgrad_stream = torch.cuda.Stream(device=self.device) if "w" in ovl else None
+        self._ac_side_stream = torch.cuda.Stream(device=self.device) if "c" in ovl else None
         # update(): the world-model lane and the actor-critic lane run on their own streams so
         # that WM(k+1) overlaps AC(k) (see update()); events order the only true dependencies
         # (measured: giving the world-model lane the high-priority hardware queues is SLOWER, 13.5 vs
@@ -212,7 +219,7 @@ class Dreamer:
         # that occupies ~50 CUs; running it on a side stream lets the compute-bound decoder
         # backward fill the other ~200 CUs instead of waiting for it.
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream
+        side = self._side_stream or main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
@@ -302,7 +309,7 @@ class Dreamer:
         #    weights have not changed since v_pred was computed), so it runs while the reverse
         #    rollout (which fills only ~77 CUs) and the actor backward proceed on the main stream.
         main = torch.cuda.current_stream(dev)
-        side = self._ac_side_stream
+        side = self._ac_side_stream or main
         side.wait_stream(main)  # after the value head's input-gradient pass above read the weights
         nv = (Hm - 1) * N
         with torch.cuda.stream(side):
