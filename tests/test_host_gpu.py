@@ -158,6 +158,25 @@ def test_dreamer_full_size_matches_oracle_scalars():
         assert r < 1e-3, (k, got[k], w)
 
 
+def test_repo_config0_b16_matches_oracle_scalars_two_updates():
+    """BASELINE config 0 shapes (B=16, L=50, H=15, full RePo): two consecutive updates against the CPU
+    oracle -- every logged loss, the KL and the dual variable within 1e-3 relative (north_star)."""
+    L, B, H, A = 50, 16, 15, 6
+    agent, cfg = make_agent("repo", L, B, H, A)
+    oracle = ro.OracleAgent(cfg, A, seed=7)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    for u in range(2):
+        batch, host = dev_batch(L, B, A, 4321 + u, u8=(u == 0))
+        agent.noise_source, nz = dev_noise(L, B, H, A, 88 + u)
+        agent.update(batch)
+        got = dict(agent.last_scalars)
+        want = oracle.update(*host, nz)[2]
+        for k, w in want.items():
+            r = abs(got[k] - w) / (abs(w) + 1e-12)
+            log(f"[repo C0 B=16 update {u}] {k}: got {got[k]:.7g} oracle {w:.7g} rel {r:.2e}")
+            assert r < 1e-3, (u, k, got[k], w)
+
+
 class ThreadDP:
     """Stands in for repo_amd.parallel.DataParallel with world_size 2 on ONE GPU: the two 'ranks'
     run in two host threads; all_reduce meets at a barrier and sums the two tensors."""
