@@ -62,6 +62,10 @@ class Dreamer:
             env.action_space.shape,
             obs_type=np.uint8 if config.pixel_obs else np.float32,
         )
+        # batches are gathered on the GPU from a device mirror of the ring (common/buffers.py): the host-side
+        # gather of 2500 scattered frames costs more than the update it feeds (14.4 vs 10.6 ms)
+        if self.device.type == "cuda" and getattr(config, "replay_on_device", True):
+            self.buffer.enable_device_mirror(self.device)
         self.free_nats = torch.full((1,), float(config.free_nats), device=self.device)
         # Intra-lane overlaps: w = weight-gradient kernels beside the data-gradient chain, s = reverse scan
         # beside the decoder backward, c = critic update beside the actor backward.  HIP multiplexes streams

@@ -7,11 +7,17 @@ builds a (B, L) index matrix, transposes it to time-major, rotates by the write 
 the ring is full so a sequence never straddles the head (:156-166); save/load as .npz of the
 instance dict, marking the last stored transition done on load (:193-202).
 
-MI355X addition: `sample_to_device` gathers straight into one of
-two page-locked staging slots and issues the copies on a side HIP stream
-(hipMemcpyAsync under torch's non_blocking copy), so the 30.7 MB uint8 batch of update k+1
-crosses PCIe while update k computes.  Frames stay uint8 on the device; normalisation is
-fused into the first convolution's loader.
+MI355X additions:
+ * `prefetch/acquire/release` gather a batch into one of two page-locked staging slots and issue
+   the copies on a side HIP stream (hipMemcpyAsync under torch's non_blocking copy), so the 30.7 MB
+   uint8 batch of update k+1 crosses PCIe while update k computes.
+ * `enable_device_mirror(device)`: with 288 GB of HBM the whole ring (1e6 frames x 12 KB = 12.3 GB)
+   fits on the GPU many times over, and the host-side gather of 2500 scattered 12 KB frames (10+ ms,
+   single-threaded) is slower than the update it feeds.  The mirror keeps a device copy of the ring
+   that is topped up with the frames pushed since the last batch (one or two contiguous H2D copies),
+   and a batch becomes ONE device gather kernel per field driven by the same host-drawn indices.
+   The host arrays stay the source of truth (save/load, reference semantics unchanged).
+Frames stay uint8 on the device; normalisation is fused into the first convolution's loader.
 """
 import numpy as np
 import torch
@@ -26,6 +32,8 @@ class SequenceReplayBuffer:
         self.dones = np.zeros((self.capacity, 1), dtype=np.float32)
         self.pos = 0
         self.full = False
+        self._pushed_total = 0  # monotonic count of stored transitions (device mirror bookkeeping)
+        self._mirror = None
 
     _DATA_KEYS = ("capacity", "observations", "actions", "rewards", "dones", "pos", "full")
 
@@ -37,6 +45,7 @@ class SequenceReplayBuffer:
         self.actions[self.pos] = np.array(act).copy()
         self.rewards[self.pos] = np.array(rew).copy()
         self.dones[self.pos] = np.array(done).copy()
+        self._pushed_total += 1
         self.pos += 1
         if self.pos == self.capacity:
             self.pos = 0
@@ -89,6 +98,44 @@ class SequenceReplayBuffer:
         self.full = bool(self.full)
         if self.pos > 0 or self.full:
             self.dones[self.pos - 1] = 1
+        self.invalidate_mirror()
+
+    # ------------------------------------------------------------------ device-resident mirror
+    def enable_device_mirror(self, device):
+        """Ask for batches to be gathered on `device` from a device copy of the ring (allocated and
+        filled lazily at the first prefetch)."""
+        self._mirror = {"device": torch.device(device), "bufs": None, "synced": 0}
+
+    def _mirror_on(self, device):
+        m = getattr(self, "_mirror", None)
+        return m is not None and m["device"] == torch.device(device)
+
+    def invalidate_mirror(self):
+        """Call after writing the host arrays directly (load(), tests): forces a full re-upload."""
+        self._pushed_total = getattr(self, "_pushed_total", 0) + self.capacity
+        if getattr(self, "_mirror", None) is not None:
+            self._mirror["synced"] = self._pushed_total - self.capacity - 1  # => everything is stale
+
+    def _mirror_flush(self, stream):
+        m = self._mirror
+        srcs = (self.observations, self.actions, self.rewards, self.dones)
+        if m["bufs"] is None:
+            m["bufs"] = tuple(torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype, device=m["device"]) for a in srcs)
+            m["synced"] = self._pushed_total - self.capacity - 1
+        stale = self._pushed_total - m["synced"]
+        if stale <= 0:
+            return
+        if stale >= self.capacity:
+            pieces = [(0, len(self))]
+        else:  # the last `stale` ring slots ending at the write head
+            a = (self.pos - stale) % self.capacity
+            pieces = [(a, self.pos)] if a < self.pos else [(a, self.capacity), (0, self.pos)]
+        with torch.cuda.stream(stream):
+            for lo, hi in pieces:
+                if hi > lo:
+                    for d, src in zip(m["bufs"], srcs):
+                        d[lo:hi].copy_(torch.from_numpy(src[lo:hi]))
+        m["synced"] = self._pushed_total
 
     # ------------------------------------------------------------------ device staging
     def _staging(self, batch_size, seq_len, device):
@@ -111,9 +158,11 @@ class SequenceReplayBuffer:
                     host((n, 1), torch.float32),
                 )
                 d = tuple(torch.empty(t.shape, dtype=t.dtype, device=device) for t in h)
-                slots.append({"host": h, "dev": d, "event": None})
+                slots.append({"host": h, "dev": d, "event": None,
+                              "idx_host": host((n,), torch.int64),
+                              "idx_dev": torch.empty(n, dtype=torch.int64, device=device)})
             st = {"key": key, "slots": slots, "next": 0,
-                  "stream": torch.cuda.Stream(device=device) if pin else None}
+                  "stream": torch.cuda.Stream(device=device) if pin and not self._mirror_on(device) else None}
             self._stage = st
         return st
 
@@ -126,6 +175,16 @@ class SequenceReplayBuffer:
         st["next"] ^= 1
         slot = st["slots"][idx]
         inds = self._sample_inds(batch_size, seq_len)
+        if self._mirror_on(device):
+            # Device-mirror mode: the batch is gathered by acquire() ON THE CONSUMER'S STREAM (a ~30 us
+            # kernel), so no staging stream exists at all -- an extra stream costs more than it hides here
+            # (HIP shares 4 hardware queues among all streams).  prefetch only draws the
+            # indices into this slot's pinned vector.
+            if slot["event"] is not None:
+                slot["event"].synchronize()  # this slot's index upload of two batches ago
+            slot["idx_host"].copy_(torch.from_numpy(inds.astype(np.int64)))
+            slot["pending"] = True
+            return idx
         if slot["event"] is not None:
             slot["event"].synchronize()  # previous copy out of this pinned slot has finished
         srcs = (self.observations, self.actions, self.rewards, self.dones)
@@ -153,6 +212,18 @@ class SequenceReplayBuffer:
         (obs uint8 (L,B,C,H,W), actions (L,B,A), rewards (L,B,1), dones (L,B,1))."""
         st = self._staging(batch_size, seq_len, device)
         slot = st["slots"][handle]
+        if self._mirror_on(device):
+            if slot.get("pending"):
+                cur = torch.cuda.current_stream(device)
+                self._mirror_flush(cur)
+                slot["idx_dev"].copy_(slot["idx_host"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                slot["event"] = ev
+                for src, d in zip(self._mirror["bufs"], slot["dev"]):
+                    torch.index_select(src, 0, slot["idx_dev"], out=d)
+                slot["pending"] = False
+            return tuple(d.view(seq_len, batch_size, *d.shape[1:]) for d in slot["dev"])
         if slot["event"] is not None and st["stream"] is not None:
             torch.cuda.current_stream(device).wait_event(slot["event"])
         return tuple(d.view(seq_len, batch_size, *d.shape[1:]) for d in slot["dev"])
@@ -160,6 +231,8 @@ class SequenceReplayBuffer:
     def release(self, handle, batch_size, seq_len, device):
         """Record that everything enqueued so far on the current stream has consumed the slot."""
         st = self._staging(batch_size, seq_len, device)
+        if self._mirror_on(device):
+            return  # the gather ran on the consumer's own stream: reuse is already stream-ordered
         if st["stream"] is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))

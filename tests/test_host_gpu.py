@@ -51,6 +51,48 @@ def test_replay_buffer_pinned_prefetch_matches_host_sample():
     assert np.array_equal(got[0].cpu().numpy(), want[0])  # first slot untouched
 
 
+def test_device_mirror_batches_equal_host_sampling():
+    """enable_device_mirror: batches gathered on the GPU from the device copy of the ring equal the
+    reference's host-side sample() for the same np.random state -- after the initial upload, after
+    incremental pushes (partial flush), across the ring's wrap-around and after load()."""
+    from repo_amd.common.buffers import SequenceReplayBuffer
+
+    dev = torch.device("cuda", 0)
+    B, L, cap = 5, 7, 60
+    buf = SequenceReplayBuffer(cap, (3, 64, 64), (6,), obs_type=np.uint8)
+    buf.enable_device_mirror(dev)
+    rs = np.random.RandomState(11)
+
+    def push(n):
+        for _ in range(n):
+            buf.push(rs.randint(0, 256, (3, 64, 64)).astype(np.uint8), rs.uniform(-1, 1, 6), rs.uniform(), rs.uniform() < 0.1)
+
+    def check(seed):
+        np.random.seed(seed)
+        want = buf.sample(B, L)
+        np.random.seed(seed)
+        h = buf.prefetch(B, L, dev)
+        got = buf.acquire(h, B, L, dev)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert tuple(g.shape) == w.shape
+            assert np.array_equal(g.cpu().numpy(), w.astype(g.cpu().numpy().dtype))
+        buf.release(h, B, L, dev)
+
+    push(25)
+    check(1)          # first use: full upload of what is stored
+    push(9)
+    check(2)          # incremental top-up
+    check(3)          # nothing new
+    push(40)          # wraps the ring (74 > 60): two-piece top-up
+    check(4)
+    push(70)          # more than a full ring since the last batch: full re-upload
+    check(5)
+    buf.observations[3] = 7
+    buf.invalidate_mirror()
+    check(6)
+
+
 def test_train_agent_runs_from_buffer():
     agent, cfg = make_agent("repo", 8, 4, 5, 6)
     cfg.train_steps = 3
