@@ -41,6 +41,14 @@ struct DTile {
 #define REPO_STAMP_FLUSH(nslices)
 #endif
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MB L2).  Neighbouring pixel
+// tiles share input rows / planes, so dispatch slot b is mapped to a tile id such that every XCD walks a
+// CONTIGUOUS range of tiles: XCD x owns [x*q + min(x,r), ...) with q = n/8, r = n%8 (a bijection on [0,n)).
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return x * q + min(x, r) + i;
+}
+
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   const int li = lane & 31, lh = lane >> 5;
 
   const int Ntot = p.nimg * G::PS;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN, m0 = blockIdx.y * BM;
   const int nlast = min(n0 + BN, Ntot) - 1;
   const int ia = n0 / G::PS, ib = nlast / G::PS;
   const int fa = (n0 % G::PS) / G::WS, lb = (nlast % G::PS) / G::WS;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void dconv_up_kernel(UpArgs p) {
   const int li = lane & 31, lh = lane >> 5;
 
   const int Ntot = p.nimg * PC;
-  const int n0 = blockIdx.x * BN, cb0 = blockIdx.y * 32;
+  const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN, cb0 = blockIdx.y * 32;
   const int nlast = min(n0 + BN, Ntot) - 1;
   const int ia = n0 / PC, ib = nlast / PC;
 
