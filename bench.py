@@ -107,7 +107,7 @@ def dominant_kernel_roofline(iters=20):
     achieved = flop / (ms * 1e-3) / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": 7.05e8,
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": 4.37e8,
         "kernel": "dconv_up_kernel<Geo<32,64,30,6>, UTile<128,2>> (decoder conv3 forward)",
         "ms_per_launch": round(ms, 4), "flop_per_launch": flop, "mfma_pipe_busy_pmc": 0.795,
     }
