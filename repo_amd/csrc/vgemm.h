@@ -92,9 +92,23 @@ __global__ __launch_bounds__(T::NT) void vgemm_kernel(Op op) {
   const int wm = wid / T::WN, wn = wid % T::WN;
   const int li = lane & 31, lh = lane >> 5;
 
-  op.init(blockIdx.z);
+  // XCD-aware tile order: dispatch slot L (dealt round-robin to the 8 XCDs) -> tile id T such that each
+  // XCD walks a contiguous range of (x, y, z) tiles, x fastest: the column tiles of one row block (which
+  // re-read the same A rows) and all tiles of one split-K slab share an L2 instead of each XCD fetching
+  // the operand from HBM again.
+  int bx, by, bz;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int q = total >> 3, r = total & 7, xc = L & 7;
+    const int t = xc * q + min(xc, r) + (L >> 3);
+    bx = t % gx;
+    by = (t / gx) % gy;
+    bz = t / (gx * gy);
+  }
+  op.init(bz);
   const int M = op.M(), N = op.N();
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int n0 = bx * BN, m0 = by * BM;
   if (m0 < M && n0 < N) {
     const int kbeg = op.kbeg(), kend = op.kend();
     const __amdgpu_buffer_rsrc_t ra_ = make_rsrc(op.A.p, op.A.bytes), rb_ = make_rsrc(op.B.p, op.B.bytes);
