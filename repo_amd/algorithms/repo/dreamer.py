@@ -212,11 +212,21 @@ class Dreamer:
         dembeds = torch.empty(rows, self.c.embedding_size, device=dev)
         dpm, dps, dqm, dqs = kl_grads
         if decoder_attached:
-            # Dreamer: the decoder's input gradient feeds the reverse scan -> strictly serial
-            Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, dfeat=dfeat, accumulate_dfeat=True)
-            ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
-                                 min_std=self.transition_model.min_std_dev)
-            Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge)
+            # Dreamer: the decoder's INPUT gradient feeds the reverse scan, so the data-gradient chain runs
+            # first; the decoder's weight gradients feed nothing downstream and are issued afterwards,
+            # beside the reverse scan (a latency-bound kernel on ~25 CUs) which hides them.
+            wgrads = []
+            Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, dfeat=dfeat, accumulate_dfeat=True, deferred=wgrads)
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream or main
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
+                                     min_std=self.transition_model.min_std_dev)
+            for fn in wgrads:
+                fn()
+            main.wait_stream(side)
+            Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
             return
         # RePo: the decoder is a probe on detached latents (repo.py:46-48), so its backward is
         # independent of the RSSM/encoder backward.  The reverse scan is a latency-bound chain

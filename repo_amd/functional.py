@@ -27,11 +27,15 @@ class _Fork:
     kernels leaves the matrix pipe ~40% idle (barrier / load phases), and two resident kernels
     fill each other's gaps."""
 
-    def __init__(self, side):
+    def __init__(self, side, deferred=None):
         self.side = side
         self.main = torch.cuda.current_stream() if side is not None else None
+        self.deferred = deferred  # a list: collect the independent work instead of running it
 
     def run(self, fn):
+        if self.deferred is not None:
+            self.deferred.append(fn)
+            return
         if self.side is None:
             fn()
             return
@@ -88,12 +92,15 @@ def decoder_fwd_nll(p, feat, target, grad_scale):
     return loss_sum, (h0, h1, h2, h3, dpre4)
 
 
-def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None):
+def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None, deferred=None):
     """Backward from d recon (= saved[4]) to all ten decoder tensors (into g) and, if dfeat is
-    given (Dreamer's attached decoder, dreamer.py:262), to the [belief|state] input."""
+    given (Dreamer's attached decoder, dreamer.py:262), to the [belief|state] input.
+    deferred: a list that receives the weight-gradient launches as closures instead of running them, so
+    the caller can issue them beside a later latency-bound kernel (they depend only on tensors kept
+    alive by the closures)."""
     h0, h1, h2, h3, d4 = saved
     rows = feat.shape[0]
-    fk = _Fork(side)
+    fk = _Fork(side, deferred)
 
     def w4():
         ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
