@@ -1,90 +1,96 @@
-"""Device selection and host<->device helpers.
-
-Mirrors the surface of the reference's common/utils.py (set_gpu_mode :10-19, get_device
-:22-24, to_torch :27-30, to_np :33-34, FreezeParameters :47-58, lambda_return :61-71,
-preprocess :74-80, postprocess :83-89) so scripts written against it keep working.  On a
-ROCm build of PyTorch the "cuda:<id>" device string IS the HIP device.
+"""Device selection and host<->device helpers with the call surface scripts written against the
+reference expect (reference common/utils.py: set_gpu_mode :10-19, get_device :22-24, to_torch :27-30,
+to_np :33-34, FreezeParameters :47-58, lambda_return :61-71, preprocess :74-80, postprocess :83-89).
+On a ROCm build of PyTorch the "cuda:<id>" device string IS the HIP device.
 """
+import contextlib
+
 import numpy as np
 import torch
 
-_GPU_ID = 0
-_USE_GPU = False
-_DEVICE = None
+
+class _Selected:
+    """Process-wide device choice.  Unlike the reference, selecting a device does not touch torch's
+    default tensor type (deprecated global state): every tensor this package creates names its device."""
+
+    device = None
+
+    @classmethod
+    def choose(cls, use_gpu, index):
+        cls.device = torch.device("cuda", int(index)) if use_gpu else torch.device("cpu")
+        if cls.device.type == "cuda":
+            torch.cuda.set_device(cls.device)
+        return cls.device
 
 
 def set_gpu_mode(mode, gpu_id=0):
-    """Select the device.  Unlike the reference this does not change torch's default tensor
-    type (deprecated global state); every tensor the package creates names its device."""
-    global _GPU_ID, _USE_GPU, _DEVICE
-    _GPU_ID = gpu_id
-    _USE_GPU = bool(mode)
-    _DEVICE = torch.device(("cuda:" + str(_GPU_ID)) if _USE_GPU else "cpu")
-    if _USE_GPU:
-        torch.cuda.set_device(_DEVICE)
+    _Selected.choose(bool(mode), gpu_id)
 
 
 def get_device():
-    global _DEVICE
-    if _DEVICE is None:
-        set_gpu_mode(torch.cuda.is_available())
-    return _DEVICE
+    return _Selected.device or _Selected.choose(torch.cuda.is_available(), 0)
 
 
 def to_torch(x, dtype=None, device=None):
-    if device is None:
-        device = get_device()
-    return torch.as_tensor(x, dtype=dtype, device=device)
+    return torch.as_tensor(x, dtype=dtype, device=get_device() if device is None else device)
 
 
 def to_np(x):
     return x.detach().cpu().numpy()
 
 
-class FreezeParameters:
-    """Context manager turning requires_grad off for a parameter list (common/utils.py:47-58)."""
+class FreezeParameters(contextlib.AbstractContextManager):
+    """`with FreezeParameters(params):` -- requires_grad off inside, restored (per parameter) on exit."""
 
     def __init__(self, params):
-        self.params = list(params)
-        self.param_states = [p.requires_grad for p in self.params]
+        self._saved = [(p, p.requires_grad) for p in params]
 
     def __enter__(self):
-        for p in self.params:
-            p.requires_grad = False
+        for p, _ in self._saved:
+            p.requires_grad_(False)
+        return self
 
-    def __exit__(self, exc_type, exc_val, exc_tb):
-        for p, s in zip(self.params, self.param_states):
-            p.requires_grad = s
+    def __exit__(self, *exc):
+        for p, flag in self._saved:
+            p.requires_grad_(flag)
+        return False
 
 
 def lambda_return(rewards, values, discounts, bootstrap, lambda_=0.95):
-    """TD(lambda) returns (common/utils.py:61-71) on the HIP kernel.  The kernel takes a
-    constant discount (dreamer.py:342 builds gamma*ones); a non-constant tensor raises."""
+    """TD(lambda) returns on the HIP kernel (repo_lambda_return).  The kernel takes ONE discount
+    (dreamer.py:342 builds gamma*ones); a tensor that is not constant raises."""
     from .. import ops
 
     gamma = float(discounts.reshape(-1)[0])
     if not bool((discounts == gamma).all()):
         raise NotImplementedError("lambda_return kernel supports a constant discount only")
-    r = torch.cat([rewards, torch.zeros_like(bootstrap)[None]], 0).contiguous()
-    v = torch.cat([values, bootstrap[None]], 0).contiguous()
-    returns, _, _, _ = ops.lambda_return(r, v, gamma, lambda_, want_grads=False)
-    return returns
+    pad = torch.zeros_like(bootstrap).unsqueeze(0)
+    out = ops.lambda_return(torch.cat([rewards, pad]).contiguous(), torch.cat([values, bootstrap.unsqueeze(0)]).contiguous(),
+                            gamma, lambda_, want_grads=False)
+    return out[0]
+
+
+def _is_image_batch(a):
+    if a.ndim not in (2, 4):
+        raise AssertionError("expected a batch: (n, features) or (n, C, H, W)")
+    return a.ndim == 4
 
 
 def preprocess(obs):
-    """uint8 pixels -> float32 in [-1, 1] on the host (common/utils.py:74-80).  The training
-    path does NOT use this: it ships uint8 frames to the device and normalises inside the
-    first convolution's loader; this is kept for the acting path and for API parity."""
-    ndims = len(obs.shape)
-    assert ndims == 2 or ndims == 4, "preprocess accepts a batch of observations"
-    if ndims == 4:
-        obs = ((obs.astype(np.float32) / 255) * 2) - 1.0
-    return obs
+    """uint8 frames -> float32 in [-1, 1] on the HOST, rounding exactly like x/255*2-1.  The training path
+    does not use this (it ships uint8 frames and normalises inside the first convolution's loader); the
+    acting path and API parity do.  Feature batches pass through."""
+    if not _is_image_batch(obs):
+        return obs
+    x = obs.astype(np.float32)
+    x /= 255
+    x *= 2
+    x -= 1.0
+    return x
 
 
 def postprocess(obs):
-    ndims = len(obs.shape)
-    assert ndims == 2 or ndims == 4, "postprocess accepts a batch of observations"
-    if ndims == 4:
-        obs = np.floor((obs + 1.0) / 2 * 255).clip(0, 255).astype(np.uint8)
-    return obs
+    """[-1, 1] frames -> uint8 (floor, clipped); feature batches pass through."""
+    if not _is_image_batch(obs):
+        return obs
+    return np.clip(np.floor((obs + 1.0) / 2 * 255), 0, 255).astype(np.uint8)
