@@ -48,9 +48,41 @@ static int transpose_to(const float* src, int rows, int cols, int ld, float* dst
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
+// k4-interleaved weights for the scan's GEMV stages: dst[(kg*N + n)*4 + u] = W(n, k = 4kg + u), 0 for k >= K,
+// with W(n, k) = src[n*sn + k*sk].  Thread n of a stage then reads FOUR consecutive k of its output with one
+// coalesced 16-byte load (1 KB per wave) instead of four dword loads: the scan was bound by the CU's
+// vector-memory issue rate (~5.5k wave-level dword loads per step, ~12 cycles each), not by L2 latency.
+__global__ void pack_k4_kernel(const float* __restrict__ src, int N, int K, int sn, int sk, int total,
+                               float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int u = i & 3, q = i >> 2;
+    const int n = q % N, kg = q / N;
+    const int k = 4 * kg + u;
+    dst[i] = k < K ? src[(size_t)n * sn + (size_t)k * sk] : 0.f;
+  }
+}
+
+static size_t packed_k4_floats(int64_t N, int64_t K) { return (size_t)((K + 3) / 4) * 4 * N; }
+
+static int pack_k4(const float* src, int N, int K, int sn, int sk, float* dst, hipStream_t s) {
+  const int total = (int)packed_k4_floats(N, K);
+  const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+  hipLaunchKernelGGL(pack_k4_kernel, dim3(blocks), dim3(256), 0, s, src, N, K, sn, sk, total, dst);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+__device__ __forceinline__ float fma4(const float4 w, const float* __restrict__ x, float acc) {
+  const float4 v = *reinterpret_cast<const float4*>(x);  // same address in every lane: LDS broadcast
+  acc = fmaf(w.x, v.x, acc);
+  acc = fmaf(w.y, v.y, acc);
+  acc = fmaf(w.z, v.z, acc);
+  return fmaf(w.w, v.w, acc);
+}
+
 struct ObsFwdArgs {
   ObsDims d;
-  // transposed weights [k][feature] and biases
+  // k4-interleaved weights (pack_k4_kernel) and biases
   const float *WsaT, *bsa, *WihT, *WhhT, *bih, *bhh, *WbpT, *bbp, *WspT, *bsp, *WbqT, *bbq, *WsqT, *bsq;
   const float *prev_belief, *prev_state;  // (B,D), (B,S)
   const float *actions, *nonterms;        // (T,B,A), (T,B)
@@ -70,11 +102,11 @@ template <int R, int KQ>
 __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
   const int T = p.d.T, B = p.d.B, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
   const int X = S + A, F = D + S;
-  __shared__ float xs[R][kMaxX];
-  __shared__ float es[R][kMaxW];
-  __shared__ float hs[2][R][kMaxW];
-  __shared__ float hps[R][kMaxW];
-  __shared__ float hqs[R][kMaxW];
+  __shared__ __attribute__((aligned(16))) float xs[R][kMaxX];
+  __shared__ __attribute__((aligned(16))) float es[R][kMaxW];
+  __shared__ __attribute__((aligned(16))) float hs[2][R][kMaxW];
+  __shared__ __attribute__((aligned(16))) float hps[R][kMaxW];
+  __shared__ __attribute__((aligned(16))) float hqs[R][kMaxW];
   __shared__ float outs[R][2 * kMaxS2];  // [0,2S) prior raw, [2S,4S) posterior raw
   __shared__ float st[R][kMaxS2];
   __shared__ float part[KQ][6][R][kMaxW];  // k-split partial sums
@@ -85,11 +117,22 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
   const int b0 = blockIdx.x * R;
   int nr = B - b0;
   if (nr > R) nr = R;
-  auto krange = [&](int K, int& k0, int& k1) {
-    const int per = (K + KQ - 1) / KQ;
-    k0 = kq * per;
-    k1 = min(K, k0 + per);
+  // this thread group's range of k GROUPS (4 consecutive k each) of a K-long reduction
+  auto krange = [&](int K, int& g0, int& g1) {
+    const int KG = (K + 3) >> 2, per = (KG + KQ - 1) / KQ;
+    g0 = kq * per;
+    g1 = min(KG, g0 + per);
   };
+  // rows of the operand vectors beyond their width are read by the zero-padded last k group
+  for (int i = tid; i < R * kMaxX; i += blockDim.x) (&xs[0][0])[i] = 0.f;
+  for (int i = tid; i < R * kMaxW; i += blockDim.x) {
+    (&es[0][0])[i] = 0.f;
+    (&hs[0][0][0])[i] = 0.f;
+    (&hs[1][0][0])[i] = 0.f;
+    (&hps[0][0])[i] = 0.f;
+    (&hqs[0][0])[i] = 0.f;
+  }
+  __syncthreads();
 
   // slot 0 of featx and the carried state
   for (int i = tid; i < R * D; i += blockDim.x) {
@@ -127,11 +170,12 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       for (int r = 0; r < R; ++r) acc[r] = 0.f;
       int k0, k1;
       krange(X, k0, k1);
-#pragma unroll 4
-      for (int k = k0; k < k1; ++k) {
-        const float w = p.WsaT[k * D + j];
+      const float4* W4 = reinterpret_cast<const float4*>(p.WsaT);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4 w = W4[g * D + j];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, xs[r][k], acc[r]);
+        for (int r = 0; r < R; ++r) acc[r] = fma4(w, &xs[r][4 * g], acc[r]);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
@@ -159,21 +203,24 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       const float* hc = &hs[cur][0][0];
       int k0, k1;
       krange(D, k0, k1);
-#pragma unroll 8
-      for (int k = k0; k < k1; ++k) {
-        const float* wi = p.WihT + (size_t)k * 3 * D + j;
-        const float* wh = p.WhhT + (size_t)k * 3 * D + j;
-        const float wi0 = wi[0], wi1 = wi[D], wi2 = wi[2 * D];
-        const float wh0 = wh[0], wh1 = wh[D], wh2 = wh[2 * D];
+      const float4* Wi4 = reinterpret_cast<const float4*>(p.WihT);
+      const float4* Wh4 = reinterpret_cast<const float4*>(p.WhhT);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4* wi = Wi4 + (size_t)g * 3 * D + j;
+        const float4* wh = Wh4 + (size_t)g * 3 * D + j;
+        const float4 wi0 = wi[0], wi1 = wi[D], wi2 = wi[2 * D];
+        const float4 wh0 = wh[0], wh1 = wh[D], wh2 = wh[2 * D];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const float ev = es[r][k], hv = hc[r * kMaxW + k];
-          gi[0][r] = fmaf(wi0, ev, gi[0][r]);
-          gi[1][r] = fmaf(wi1, ev, gi[1][r]);
-          gi[2][r] = fmaf(wi2, ev, gi[2][r]);
-          gh[0][r] = fmaf(wh0, hv, gh[0][r]);
-          gh[1][r] = fmaf(wh1, hv, gh[1][r]);
-          gh[2][r] = fmaf(wh2, hv, gh[2][r]);
+          const float* ev = &es[r][4 * g];
+          const float* hv = hc + r * kMaxW + 4 * g;
+          gi[0][r] = fma4(wi0, ev, gi[0][r]);
+          gi[1][r] = fma4(wi1, ev, gi[1][r]);
+          gi[2][r] = fma4(wi2, ev, gi[2][r]);
+          gh[0][r] = fma4(wh0, hv, gh[0][r]);
+          gh[1][r] = fma4(wh1, hv, gh[1][r]);
+          gh[2][r] = fma4(wh2, hv, gh[2][r]);
         }
       }
 #pragma unroll
@@ -222,15 +269,17 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       const float* hc = &hs[cur][0][0];
       int k0, k1;
       krange(D, k0, k1);
-#pragma unroll 4
-      for (int k = k0; k < k1; ++k) {
-        const float wp = p.WbpT[(size_t)k * Hd + j];
-        const float wq = p.WbqT[(size_t)k * Hd + j];
+      const float4* Wp4 = reinterpret_cast<const float4*>(p.WbpT);
+      const float4* Wq4 = reinterpret_cast<const float4*>(p.WbqT);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4 wp = Wp4[(size_t)g * Hd + j];
+        const float4 wq = Wq4[(size_t)g * Hd + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const float hv = hc[r * kMaxW + k];
-          ap[r] = fmaf(wp, hv, ap[r]);
-          aq[r] = fmaf(wq, hv, aq[r]);
+          const float* hv = hc + r * kMaxW + 4 * g;
+          ap[r] = fma4(wp, hv, ap[r]);
+          aq[r] = fma4(wq, hv, aq[r]);
         }
       }
 #pragma unroll
@@ -270,11 +319,12 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       for (int r = 0; r < R; ++r) acc[r] = 0.f;
       int k0, k1;
       krange(Hd, k0, k1);
-#pragma unroll 4
-      for (int k = k0; k < k1; ++k) {
-        const float w = Wt[(size_t)k * 2 * S + o];
+      const float4* W4 = reinterpret_cast<const float4*>(Wt);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4 w = W4[(size_t)g * 2 * S + o];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, hsrc[r * kMaxW + k], acc[r]);
+        for (int r = 0; r < R; ++r) acc[r] = fma4(w, hsrc + r * kMaxW + 4 * g, acc[r]);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
@@ -322,8 +372,8 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
 
 struct ObsBwdArgs {
   ObsDims d;
-  int ldbq;  // row stride of W_bq (= D + E)
-  // weights in their native [out][in] layout
+  // k4-interleaved weights (pack_k4_kernel) with the reduction over the layer's OUTPUT index:
+  // W(n = input index, k = output index) = native[k*ld + n]
   const float *Wsa, *Wih, *Whh, *Wbp, *Wsp, *Wbq, *Wsq;
   // saved by forward
   const float *featx, *nonterms, *e, *gates, *hp, *hq, *prior_std, *post_std, *eps_prior, *eps_post;
@@ -345,12 +395,12 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
   __shared__ float dh[R][kMaxW];      // carried d belief
   __shared__ float dst[R][kMaxS2];    // carried d posterior state
   __shared__ float dbel[R][kMaxW];
-  __shared__ float douts[R][2 * kMaxS2];
-  __shared__ float dhps[R][kMaxW];
-  __shared__ float dhqs[R][kMaxW];
-  __shared__ float dgis[R][3 * kMaxW];
-  __shared__ float dghs[R][3 * kMaxW];
-  __shared__ float des[R][kMaxW];
+  __shared__ __attribute__((aligned(16))) float douts[R][2 * kMaxS2];
+  __shared__ __attribute__((aligned(16))) float dhps[R][kMaxW];
+  __shared__ __attribute__((aligned(16))) float dhqs[R][kMaxW];
+  __shared__ __attribute__((aligned(16))) float dgis[R][3 * kMaxW];
+  __shared__ __attribute__((aligned(16))) float dghs[R][3 * kMaxW];
+  __shared__ __attribute__((aligned(16))) float des[R][kMaxW];
   __shared__ float part[KQ][2][R][kMaxW];  // k-split partial sums
 
   const int tid = threadIdx.x;
@@ -359,11 +409,22 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
   const int b0 = blockIdx.x * R;
   int nr = B - b0;
   if (nr > R) nr = R;
-  auto krange = [&](int K, int& k0, int& k1) {
-    const int per = (K + KQ - 1) / KQ;
-    k0 = kq * per;
-    k1 = min(K, k0 + per);
+  // this thread group's range of k GROUPS (4 consecutive k each) of a K-long reduction
+  auto krange = [&](int K, int& g0, int& g1) {
+    const int KG = (K + 3) >> 2, per = (KG + KQ - 1) / KQ;
+    g0 = kq * per;
+    g1 = min(KG, g0 + per);
   };
+  for (int i = tid; i < R * kMaxW; i += blockDim.x) {
+    (&dhps[0][0])[i] = 0.f;
+    (&dhqs[0][0])[i] = 0.f;
+    (&des[0][0])[i] = 0.f;
+  }
+  for (int i = tid; i < R * 3 * kMaxW; i += blockDim.x) {
+    (&dgis[0][0])[i] = 0.f;
+    (&dghs[0][0])[i] = 0.f;
+  }
+  for (int i = tid; i < R * 2 * kMaxS2; i += blockDim.x) (&douts[0][0])[i] = 0.f;
   for (int i = tid; i < R * kMaxW; i += blockDim.x) (&dh[0][0])[i] = 0.f;
   for (int i = tid; i < R * kMaxS2; i += blockDim.x) (&dst[0][0])[i] = 0.f;
   __syncthreads();
@@ -420,14 +481,16 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       for (int r = 0; r < R; ++r) ap[r] = aq[r] = 0.f;
       int k0, k1;
       krange(2 * S, k0, k1);
-#pragma unroll 4
-      for (int o = k0; o < k1; ++o) {
-        const float wp = p.Wsp[(size_t)o * Hd + j];
-        const float wq = p.Wsq[(size_t)o * Hd + j];
+      const float4* Wp4 = reinterpret_cast<const float4*>(p.Wsp);
+      const float4* Wq4 = reinterpret_cast<const float4*>(p.Wsq);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4 wp = Wp4[(size_t)g * Hd + j];
+        const float4 wq = Wq4[(size_t)g * Hd + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          ap[r] = fmaf(wp, douts[r][o], ap[r]);
-          aq[r] = fmaf(wq, douts[r][2 * S + o], aq[r]);
+          ap[r] = fma4(wp, &douts[r][4 * g], ap[r]);
+          aq[r] = fma4(wq, &douts[r][2 * S + 4 * g], aq[r]);
         }
       }
 #pragma unroll
@@ -465,12 +528,14 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       for (int r = 0; r < R; ++r) acc[r] = 0.f;
       int k0, k1;
       krange(Hd, k0, k1);
-#pragma unroll 4
-      for (int jj = k0; jj < k1; ++jj) {
-        const float wp = p.Wbp[(size_t)jj * D + j];
-        const float wq = p.Wbq[(size_t)jj * p.ldbq + j];
+      const float4* Wp4 = reinterpret_cast<const float4*>(p.Wbp);
+      const float4* Wq4 = reinterpret_cast<const float4*>(p.Wbq);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4 wp = Wp4[(size_t)g * D + j];
+        const float4 wq = Wq4[(size_t)g * D + j];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fmaf(wp, dhps[r][jj], fmaf(wq, dhqs[r][jj], acc[r]));
+        for (int r = 0; r < R; ++r) acc[r] = fma4(wp, &dhps[r][4 * g], fma4(wq, &dhqs[r][4 * g], acc[r]));
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
@@ -521,14 +586,16 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       for (int r = 0; r < R; ++r) ah[r] = ae[r] = 0.f;
       int k0, k1;
       krange(3 * D, k0, k1);
-#pragma unroll 8
-      for (int jj = k0; jj < k1; ++jj) {
-        const float wh = p.Whh[(size_t)jj * D + j];
-        const float wi = p.Wih[(size_t)jj * D + j];
+      const float4* Wh4 = reinterpret_cast<const float4*>(p.Whh);
+      const float4* Wi4 = reinterpret_cast<const float4*>(p.Wih);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4 wh = Wh4[(size_t)g * D + j];
+        const float4 wi = Wi4[(size_t)g * D + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          ah[r] = fmaf(wh, dghs[r][jj], ah[r]);
-          ae[r] = fmaf(wi, dgis[r][jj], ae[r]);
+          ah[r] = fma4(wh, &dghs[r][4 * g], ah[r]);
+          ae[r] = fma4(wi, &dgis[r][4 * g], ae[r]);
         }
       }
 #pragma unroll
@@ -564,11 +631,12 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       for (int r = 0; r < R; ++r) acc[r] = 0.f;
       int k0, k1;
       krange(D, k0, k1);
-#pragma unroll 4
-      for (int jj = k0; jj < k1; ++jj) {
-        const float w = p.Wsa[(size_t)jj * X + j];
+      const float4* W4 = reinterpret_cast<const float4*>(p.Wsa);
+#pragma unroll 2
+      for (int g = k0; g < k1; ++g) {
+        const float4 w = W4[(size_t)g * S + j];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fmaf(w, des[r][jj], acc[r]);
+        for (int r = 0; r < R; ++r) acc[r] = fma4(w, &des[r][4 * g], acc[r]);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) part[kq][0][r][j] = acc[r];
@@ -596,8 +664,15 @@ static bool dims_ok(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int6
          4 * S <= 256 && S + A <= kMaxX && T * B * 4 * D < kMaxIdx;
 }
 
+static size_t bwd_pack_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  (void)A;
+  return 2 * packed_k4_floats(Hd, 2 * S) + 2 * packed_k4_floats(D, Hd) + 2 * packed_k4_floats(D, 3 * D) +
+         packed_k4_floats(S, D);
+}
+
 static size_t fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
-  return (size_t)((S + A) * D + 2 * D * 3 * D + 2 * D * Hd + 2 * Hd * 2 * S);
+  return packed_k4_floats(D, S + A) + 2 * packed_k4_floats(3 * D, D) + 2 * packed_k4_floats(Hd, D) +
+         2 * packed_k4_floats(2 * S, Hd);
 }
 
 }  // namespace repo
@@ -626,21 +701,23 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   REPO_REQUIRE(ws && ws_bytes >= fwd_ws_floats(A, D, Hd, S) * sizeof(float), REPO_E_WS_TOO_SMALL);
   const float* const* P = params;
   float* w = (float*)ws;
-  float* WsaT = w;  w += (S + A) * D;
-  float* WihT = w;  w += D * 3 * D;
-  float* WhhT = w;  w += D * 3 * D;
-  float* WbpT = w;  w += D * Hd;
-  float* WbqT = w;  w += D * Hd;
-  float* WspT = w;  w += Hd * 2 * S;
+  // W(n, k) = P[n*ld + k] (native (out, in) layout) -> k4-interleaved [k/4][n][4]
+  const int X = (int)(S + A), d = (int)D, h = (int)Hd, s2 = (int)(2 * S);
+  float* WsaT = w;  w += packed_k4_floats(d, X);
+  float* WihT = w;  w += packed_k4_floats(3 * d, d);
+  float* WhhT = w;  w += packed_k4_floats(3 * d, d);
+  float* WbpT = w;  w += packed_k4_floats(h, d);
+  float* WbqT = w;  w += packed_k4_floats(h, d);
+  float* WspT = w;  w += packed_k4_floats(s2, h);
   float* WsqT = w;
   int rc;
-  if ((rc = transpose_to(P[0], (int)D, (int)(S + A), (int)(S + A), WsaT, stream))) return rc;
-  if ((rc = transpose_to(P[2], (int)(3 * D), (int)D, (int)D, WihT, stream))) return rc;
-  if ((rc = transpose_to(P[3], (int)(3 * D), (int)D, (int)D, WhhT, stream))) return rc;
-  if ((rc = transpose_to(P[6], (int)Hd, (int)D, (int)D, WbpT, stream))) return rc;
-  if ((rc = transpose_to(P[10], (int)Hd, (int)D, (int)(D + E), WbqT, stream))) return rc;
-  if ((rc = transpose_to(P[8], (int)(2 * S), (int)Hd, (int)Hd, WspT, stream))) return rc;
-  if ((rc = transpose_to(P[12], (int)(2 * S), (int)Hd, (int)Hd, WsqT, stream))) return rc;
+  if ((rc = pack_k4(P[0], d, X, X, 1, WsaT, stream))) return rc;
+  if ((rc = pack_k4(P[2], 3 * d, d, d, 1, WihT, stream))) return rc;
+  if ((rc = pack_k4(P[3], 3 * d, d, d, 1, WhhT, stream))) return rc;
+  if ((rc = pack_k4(P[6], h, d, d, 1, WbpT, stream))) return rc;
+  if ((rc = pack_k4(P[10], h, d, (int)(D + E), 1, WbqT, stream))) return rc;
+  if ((rc = pack_k4(P[8], s2, h, h, 1, WspT, stream))) return rc;
+  if ((rc = pack_k4(P[12], s2, h, h, 1, WsqT, stream))) return rc;
   if (T == 0) return REPO_OK;
   // hoisted: eemb = embeds @ W_bq[:, D:]^T
   if ((rc = repo_gemm(0, 1, T * B, Hd, E, embeds, E, P[10] + D, D + E, nullptr, 1, eemb, Hd, REPO_EPI_NONE, nullptr, 0,
@@ -683,6 +760,8 @@ extern "C" size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, in
     size_t b = repo_gemm_wgrad_workspace_bytes(T * B, s[0], s[1]);
     if (b > slab) slab = b;
   }
+  const size_t packs = bwd_pack_floats(A, D, Hd, S) * sizeof(float);  // live only during the scan kernel
+  if (packs > slab) slab = packs;
   return deltas * sizeof(float) + slab + 256;
 }
 
@@ -717,8 +796,24 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
   const float* const* P = params;
   ObsBwdArgs a;
   a.d = ObsDims{(int)T, (int)B, (int)A, (int)D, (int)Hd, (int)S};
-  a.ldbq = (int)(D + E);
-  a.Wsa = P[0]; a.Wih = P[2]; a.Whh = P[3]; a.Wbp = P[6]; a.Wsp = P[8]; a.Wbq = P[10]; a.Wsq = P[12];
+  {  // packed weights at the head of the slab region: dead before the first weight-gradient GEMM uses it
+    float* pw = (float*)slab;
+    const int d = (int)D, h = (int)Hd, s2 = (int)(2 * S), X_ = (int)(S + A);
+    int rc0;
+    auto put = [&](const float* src, int N, int K, int ld, const float** dstp) {
+      *dstp = pw;
+      const int rc_ = pack_k4(src, N, K, 1, ld, pw, stream);
+      pw += packed_k4_floats(N, K);
+      return rc_;
+    };
+    if ((rc0 = put(P[8], h, s2, h, &a.Wsp))) return rc0;
+    if ((rc0 = put(P[12], h, s2, h, &a.Wsq))) return rc0;
+    if ((rc0 = put(P[6], d, h, d, &a.Wbp))) return rc0;
+    if ((rc0 = put(P[10], d, h, (int)(D + E), &a.Wbq))) return rc0;
+    if ((rc0 = put(P[3], d, 3 * d, d, &a.Whh))) return rc0;
+    if ((rc0 = put(P[2], d, 3 * d, d, &a.Wih))) return rc0;
+    if ((rc0 = put(P[0], (int)S, d, X_, &a.Wsa))) return rc0;
+  }
   a.featx = featx; a.nonterms = nonterms; a.e = e; a.gates = gates; a.hp = hp; a.hq = hq;
   a.prior_std = prior_std; a.post_std = post_std; a.eps_prior = eps_prior; a.eps_post = eps_post;
   a.dfeat = dfeat; a.dprior_state = dprior_state; a.dpm = dpm; a.dps = dps; a.dqm = dqm; a.dqs = dqs;
