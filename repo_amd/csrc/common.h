@@ -20,6 +20,9 @@ namespace repo {
 
 constexpr float kLog2Pi = 1.8378770664093453f;  // ln(2*pi)
 constexpr int kMaxIdx = 0x7fffffff;
+// Operands addressed through raw buffer descriptors (32-bit num_records / byte offsets, with 0x80000000 as
+// the "out of range" offset) must stay below 2 GiB: 2^29 floats.
+constexpr int64_t kMaxBufElems = (int64_t)1 << 29;
 
 // Activation math on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp
 // each) instead of libm's expm1f/log1pf/tanhf call sequences, which cost 20-40 VALU instructions per

@@ -520,7 +520,7 @@ template <> struct DLatTile<GEnc4> { using type = DTile<32, 128, 8, 1, 4>; };
 template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
                        const float* aux, hipStream_t s) {
-  if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
   if (!old_engine) {
     DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
@@ -543,7 +543,7 @@ static int conv_up_class(int64_t nimg, const float* small, const float* w, const
 template <class G>
 static int conv_up_t(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
                      const float* aux, hipStream_t s) {
-  if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
   if constexpr (G::CB % 32 == 0) {
     if (!old_engine) {
@@ -625,7 +625,7 @@ static void launch_conv_slab_reduce(const float* ws, int splits, int cs, int nw,
 template <class G, class BigT>
 static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float* dw, float* db, int accumulate,
                         void* ws, size_t ws_bytes, hipStream_t s) {
-  if (nimg * (int64_t)G::CB * G::PB >= kMaxIdx || nimg * (int64_t)G::CS * G::PS >= kMaxIdx) return REPO_E_SHAPE;
+  if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   if (!ws || ws_bytes < wgrad_ws_bytes<G>(nimg)) return REPO_E_WS_TOO_SMALL;
   static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
   if (!old_engine) {
@@ -756,7 +756,7 @@ extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* 
                                     float* loss_sum, void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
   REPO_REQUIRE(h3 && w && target, REPO_E_BADARG);
-  REPO_REQUIRE(nimg * (int64_t)GDec4::CS * GDec4::PS < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(nimg * (int64_t)GDec4::CS * GDec4::PS < kMaxBufElems, REPO_E_SHAPE);
   REPO_REQUIRE(ws && ws_bytes >= repo_decoder_out_nll_workspace_bytes(nimg), REPO_E_WS_TOO_SMALL);
   if (target_is_u8)
     return decoder_out_nll_t<uint8_t>(nimg, h3, w, bias, (const uint8_t*)target, grad_scale, recon, dpre, loss_sum, ws,

@@ -333,7 +333,7 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
   {  // operand offsets are 32-bit inside the kernel
     const int64_t ea = transa ? (K - 1) * lda + M : (M - 1) * lda + K;
     const int64_t eb = transb ? (N - 1) * ldb + K : (K - 1) * ldb + N;
-    REPO_REQUIRE(ea < kMaxIdx && eb < kMaxIdx && M * ldc < kMaxIdx && M * ldaux < kMaxIdx, REPO_E_SHAPE);
+    REPO_REQUIRE(ea < kMaxBufElems && eb < kMaxBufElems && M * ldc < kMaxIdx && M * ldaux < kMaxIdx, REPO_E_SHAPE);
   }
   if (bias_div <= 0) bias_div = 1;
   // K == 1 (outer products, e.g. the gradient through a scalar output layer): a contiguous M x 1 / N x 1
@@ -402,7 +402,7 @@ extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY,
   if (N == 0 || K == 0) return REPO_OK;
   REPO_REQUIRE(dY && X && dW, REPO_E_BADARG);
   REPO_REQUIRE(M < kMaxIdx && N < kMaxIdx && K < kMaxIdx - 1, REPO_E_SHAPE);
-  REPO_REQUIRE(M * lddy < kMaxIdx && M * ldx < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(M * lddy < kMaxBufElems && M * ldx < kMaxBufElems, REPO_E_SHAPE);
   if (M == 0) {
     if (!accumulate) {
       for (int64_t n = 0; n < N; ++n) (void)hipMemsetAsync(dW + n * lddw, 0, K * sizeof(float), stream);
