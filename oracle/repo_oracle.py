@@ -360,9 +360,9 @@ class OracleAgent:
         self.last["returns"] = returns.detach()
         return {
             "train/actor_loss": float(actor_loss.detach()),
-            "train/value_loss": float(value_loss),
-            "train/action_entropy": float(action_entropy),
-            "train/latent_entropy": float(latent_entropy),
+            "train/value_loss": float(value_loss.detach()),
+            "train/action_entropy": float(action_entropy.detach()),
+            "train/latent_entropy": float(latent_entropy.detach()),
         }
 
     # -- one full update on a uint8 replay batch -----------------------------------------

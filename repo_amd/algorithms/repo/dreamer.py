@@ -27,18 +27,30 @@ import torch
 from ... import functional as Fn
 from ... import ops
 from ...common.buffers import SequenceReplayBuffer
-from ...common.utils import get_device, postprocess, preprocess, to_np, to_torch
+from ...common.utils import get_device, postprocess, to_np
 from .models.actor_critic import ActorModel, ValueModel
 from .models.decoder import ObservationModel, RewardModel
 from .models.encoder import Encoder
 from .models.rssm import TransitionModel
 from .models.utils import FlatAdam
+from .rollout import EpisodeDriver
 
 LOG_2PI = math.log(2.0 * math.pi)
 
 
 def _d(ts):
     return [t.detach() for t in ts]
+
+
+def _as_video(frames, fps):
+    """The logger's video holder: the host application's `common.logger.Video` when this package runs
+    inside the reference's scripts (its logger dispatches on that class, common/logger.py:26-35), else
+    a plain (frames, fps) record."""
+    try:
+        from common.logger import Video  # the application's own logger module, if any
+    except Exception:  # noqa: BLE001
+        from ...common.utils import Video
+    return Video(frames, fps)
 
 
 class Dreamer:
@@ -480,22 +492,26 @@ class Dreamer:
                 # host gather + PCIe copy of the next batch overlap the update just enqueued
                 h = self.buffer.prefetch(B, L, self.device)
         self.synchronize()
+        # hand the LAST update's scalars to the logger too (the reference records every update before its
+        # next logger.dump); the acting step that follows synchronises with the device anyway
+        self._flush_log()
 
     # ------------------------------------------------------------------ acting
     def collect_seed_data(self):
-        obs = self.env.reset()
-        done = False
-        while len(self.buffer) < self.c.prefill or not done:
-            action = self.env.action_space.sample()
-            next_obs, reward, done, _ = self.env.step(action)
-            self.buffer.push(obs, action, reward, done)
-            obs = next_obs if not done else self.env.reset()
+        """Random-policy prefill of the replay ring; stops only at an episode boundary once `prefill`
+        transitions are stored (reference dreamer.py:159-167)."""
+        env, ring = self.env, self.buffer
+        obs, mid_episode = env.reset(), True
+        while mid_episode or len(ring) < self.c.prefill:
+            action = env.action_space.sample()
+            following, reward, done, _ = env.step(action)
+            ring.push(obs, action, reward, done)
+            mid_episode = not done
+            obs = env.reset() if done else following
 
     def init_latent_and_action(self):
-        belief = torch.zeros(1, self.c.belief_size, device=self.device)
-        posterior_state = torch.zeros(1, self.c.state_size, device=self.device)
-        action = torch.zeros(1, int(np.prod(self.env.action_space.shape)), device=self.device)
-        return belief, posterior_state, action
+        shapes = (self.c.belief_size, self.c.state_size, self.action_size)
+        return tuple(torch.zeros(1, n, device=self.device) for n in shapes)
 
     @torch.no_grad()
     def _act_eager(self, belief, posterior_state, action, obs, explore):
@@ -546,74 +562,53 @@ class Dreamer:
             sout = self._act_eager(*sin, explore)
         return graph, sin, tuple(sout)
 
+    def _dump_log(self):
+        self.logger.record("train/step", self.step)
+        self.logger.dump(step=self.step)
+
     def train(self):
-        if self.c.load_checkpoint:
+        """Interleave environment steps with agent updates (reference dreamer.py:403-455): every
+        environment step stores one transition; training, evaluation, checkpointing and log dumps fire
+        on their own periods of the step counter, in that order."""
+        c = self.c
+        if c.load_checkpoint:
             self.load_checkpoint()
         if len(self.buffer) == 0:
             self.collect_seed_data()
-        belief, posterior_state, action_tensor = self.init_latent_and_action()
-        obs = self.env.reset()
-        episode_reward = 0
-        episode_success = 0
-        while self.step < self.c.num_steps:
-            obs_tensor = to_torch(preprocess(obs[None]))
-            belief, posterior_state, action_tensor = self.update_latent_and_select_action(
-                belief, posterior_state, action_tensor, obs_tensor, True
-            )
-            action = to_np(action_tensor)[0]
-            next_obs, reward, done, info = self.env.step(action)
-            self.buffer.push(obs, action, reward, done)
-            obs = next_obs
-            episode_reward += reward
-            episode_success += info.get("success", 0)
-            if done:
-                self.logger.record("train/return", episode_reward)
-                self.logger.record("train/success", float(episode_success > 0))
-                belief, posterior_state, action_tensor = self.init_latent_and_action()
-                obs = self.env.reset()
-                episode_reward = 0
-                episode_success = 0
-            if self.step % self.c.train_every == 0:
-                self.train_agent()
-            if self.step % self.c.eval_every == 0:
-                self.eval_agent()
-            if self.step % self.c.checkpoint_every == 0:
-                self.save_checkpoint()
-            if self.step % self.c.log_every == 0:
-                self.logger.record("train/step", self.step)
-                self.logger.dump(step=self.step)
+        periodic = ((c.train_every, self.train_agent), (c.eval_every, self.eval_agent),
+                    (c.checkpoint_every, self.save_checkpoint), (c.log_every, self._dump_log))
+        driver = EpisodeDriver(self, self.env, explore=True)
+        driver.begin()
+        while self.step < c.num_steps:
+            tr = driver.advance()
+            self.buffer.push(tr.obs, tr.action, tr.reward, tr.done)
+            if tr.done:
+                driver.report("train")
+                driver.begin()
+            for period, job in periodic:
+                if self.step % period == 0:
+                    job()
             self.step += 1
 
     def eval_agent(self):
+        """One deterministic-policy episode on eval_env; logs return, success and a side-by-side video of
+        observed and reconstructed frames (reference dreamer.py:457-490)."""
         self.toggle_train(False)
-        belief, posterior_state, action_tensor = self.init_latent_and_action()
-        obs = self.eval_env.reset()
-        done = False
-        episode_reward = 0
-        episode_success = 0
-        frames = []
-        with torch.no_grad():
-            while not done:
-                obs_tensor = to_torch(preprocess(obs[None]))
-                belief, posterior_state, action_tensor = self.update_latent_and_select_action(
-                    belief, posterior_state, action_tensor, obs_tensor, False
-                )
-                action = to_np(action_tensor)[0]
-                next_obs, reward, done, info = self.eval_env.step(action)
-                if self.c.pixel_obs:
-                    obs_hat = postprocess(to_np(self.obs_model(belief, posterior_state)))[0]
-                    frames.append([obs, obs_hat])
-                obs = next_obs
-                episode_reward += reward
-                episode_success += info.get("success", 0)
-        self.logger.record("test/return", episode_reward)
-        self.logger.record("test/success", float(episode_success > 0))
-        if self.c.pixel_obs and frames:
-            video = np.stack(frames).transpose(1, 0, 2, 3, 4)
-            try:
-                self.logger.record("test/video", video, exclude="stdout")
-            except TypeError:
-                self.logger.record("test/video", video)
+        driver = EpisodeDriver(self, self.eval_env, explore=False)
+        driver.begin()
+        pairs = []
+        finished = False
+        while not finished:
+            tr = driver.advance()
+            if self.c.pixel_obs:
+                with torch.no_grad():
+                    recon = self.obs_model(driver.latent[0], driver.latent[1])
+                pairs.append([tr.obs, postprocess(to_np(recon))[0]])
+            finished = tr.done
+        driver.report("test")
+        if pairs:
+            clip = np.stack(pairs).transpose(1, 0, 2, 3, 4)  # (T, 2, C, H, W) -> (2, T, C, H, W)
+            self.logger.record("test/video", _as_video(clip, fps=30), exclude="stdout")
         self.toggle_train(True)
 
     # ------------------------------------------------------------------ checkpoints (reference key layout)
@@ -673,26 +668,9 @@ class Dreamer:
         self.value_optimizer.load_state_dict(params["value_optimizer"])
 
     def load_offline_data(self):
+        """Replace the replay ring by the concatenation of every `buffer*.npz` under c.offline_dir
+        (reference dreamer.py:566-596); the work is host-only: common/buffers.py."""
         paths = list(glob.glob(os.path.join(self.c.offline_dir, "buffer*.npz")))
-        keys = ["observations", "actions", "rewards", "dones"]
-        buffers = {k: [] for k in keys}
+        self.buffer.adopt_offline(paths, self.c.offline_truncate_size)
         for path in paths:
-            with np.load(path) as buf:
-                data = {k: buf[k] for k in keys}
-                pos, full = int(buf["pos"]), bool(buf["full"])
-            if full:
-                data = {k: np.concatenate((v[pos:], v[:pos])) for k, v in data.items()}
-            else:
-                data = {k: v[:pos] for k, v in data.items()}
-            size = min(len(data["observations"]), self.c.offline_truncate_size)
-            data = {k: v[:size] for k, v in data.items()}
-            data["dones"][-1, :] = 1
-            for k in keys:
-                buffers[k].append(data[k])
             print(f"Loaded buffer from {path}")
-        merged = {k: np.concatenate(v) for k, v in buffers.items()}
-        for k, v in merged.items():
-            setattr(self.buffer, k, v)
-        self.buffer.capacity = len(merged["observations"])
-        self.buffer.pos = 0
-        self.buffer.full = True

@@ -22,6 +22,17 @@ def bottle(f, xs):
     return ys.reshape(horizon, batch_size, *ys.shape[1:])
 
 
+def adam_param_group(lr, betas, eps, n_params):
+    """The `param_groups[0]` entry torch.optim.Adam of THIS torch build would write for these
+    hyper-parameters: key set and key order come from a throw-away torch.optim.Adam instance, so a
+    checkpoint written here has the layout the reference's `Adam.state_dict()` has on the same install
+    (tests/golden/checkpoint_manifest.json pins it for the build container's torch)."""
+    probe = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=float(lr), betas=tuple(betas), eps=float(eps))
+    group = dict(probe.state_dict()["param_groups"][0])
+    group["params"] = list(range(n_params))
+    return group
+
+
 class FlatAdam:
     """Adam over a flat parameter buffer with fused global-norm clipping."""
 
@@ -80,10 +91,7 @@ class FlatAdam:
                     "exp_avg": self.exp_avg[o : o + n].view(p.shape).clone(),
                     "exp_avg_sq": self.exp_avg_sq[o : o + n].view(p.shape).clone(),
                 }
-        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
-                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                 "params": list(range(len(self.params)))}
-        return {"state": state, "param_groups": [group]}
+        return {"state": state, "param_groups": [adam_param_group(self.lr, self.betas, self.eps, len(self.params))]}
 
     def load_state_dict(self, sd):
         g = sd["param_groups"][0]

@@ -11,6 +11,7 @@ import torch
 
 from ... import ops
 from .dreamer import Dreamer
+from .models.utils import adam_param_group
 
 
 class _ScalarAdam:
@@ -28,10 +29,7 @@ class _ScalarAdam:
         if self.step_count > 0:
             state[0] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg.reshape(()).clone(),
                         "exp_avg_sq": self.exp_avg_sq.reshape(()).clone()}
-        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
-                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                 "params": [0]}
-        return {"state": state, "param_groups": [group]}
+        return {"state": state, "param_groups": [adam_param_group(self.lr, self.betas, self.eps, 1)]}
 
     def load_state_dict(self, sd):
         g = sd["param_groups"][0]
@@ -78,7 +76,9 @@ class RePo(Dreamer):
 
     def get_param_dict(self):
         params = super().get_param_dict()
-        params["log_beta"] = self.log_beta.detach().clone()
+        # a leaf that requires grad, like the reference's (repo.py:17-22): its load_param_dict REBINDS
+        # self.log_beta to this tensor and differentiates through it on the next dual step
+        params["log_beta"] = self.log_beta.detach().clone().requires_grad_(True)
         params["beta_optimizer"] = self.beta_optimizer.state_dict()
         return params
 

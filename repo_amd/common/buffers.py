@@ -23,81 +23,103 @@ import numpy as np
 import torch
 
 
+_FIELDS = ("observations", "actions", "rewards", "dones")
+
+
+def _time_major_indices(starts, seq_len):
+    """Flat (seq_len * batch) ring indices of `batch` windows, time-major: entry t*batch + b is
+    starts[b] + t (the reference stacks (B, L) aranges and transposes: common/buffers.py:159-160)."""
+    return (np.asarray(starts)[None, :] + np.arange(seq_len)[:, None]).reshape(-1)
+
+
 class SequenceReplayBuffer:
     def __init__(self, capacity, obs_shape, act_shape, obs_type=np.float32, act_type=np.float32):
         self.capacity = capacity
-        self.observations = np.zeros((self.capacity,) + tuple(obs_shape), dtype=obs_type)
-        self.actions = np.zeros((self.capacity,) + tuple(act_shape), dtype=act_type)
-        self.rewards = np.zeros((self.capacity, 1), dtype=np.float32)
-        self.dones = np.zeros((self.capacity, 1), dtype=np.float32)
-        self.pos = 0
-        self.full = False
+        self.observations = np.zeros((capacity,) + tuple(obs_shape), dtype=obs_type)
+        self.actions = np.zeros((capacity,) + tuple(act_shape), dtype=act_type)
+        self.rewards = np.zeros((capacity, 1), dtype=np.float32)
+        self.dones = np.zeros((capacity, 1), dtype=np.float32)
+        self.pos = 0        # write head
+        self.full = False   # the head has wrapped at least once
         self._pushed_total = 0  # monotonic count of stored transitions (device mirror bookkeeping)
         self._mirror = None
 
-    _DATA_KEYS = ("capacity", "observations", "actions", "rewards", "dones", "pos", "full")
+    # exactly the keys the reference's save() writes (its instance dict, common/buffers.py:193-194)
+    _DATA_KEYS = ("capacity",) + _FIELDS + ("pos", "full")
 
     def __len__(self):
         return self.capacity if self.full else self.pos
 
     def push(self, obs, act, rew, done):
-        self.observations[self.pos] = np.array(obs).copy()
-        self.actions[self.pos] = np.array(act).copy()
-        self.rewards[self.pos] = np.array(rew).copy()
-        self.dones[self.pos] = np.array(done).copy()
+        """Store one transition at the write head and advance it (wraps; reference :146-154)."""
+        at = self.pos
+        for ring, value in zip((self.observations, self.actions, self.rewards, self.dones), (obs, act, rew, done)):
+            ring[at] = np.asarray(value)
         self._pushed_total += 1
-        self.pos += 1
-        if self.pos == self.capacity:
-            self.pos = 0
-            self.full = True
+        self.pos = (at + 1) % self.capacity
+        self.full = self.full or self.pos == 0
+
+    def _unrotate(self, flat_inds):
+        """Window offsets are drawn relative to the OLDEST stored transition; once the ring has wrapped
+        that is the write head, so no window straddles it (reference :161-163)."""
+        return (flat_inds + self.pos) % len(self) if self.full else flat_inds
 
     def _sample_inds(self, batch_size, seq_len):
-        start_inds = np.random.choice(len(self) - seq_len, size=batch_size)
-        batch_inds = start_inds[None, :] + np.arange(seq_len)[:, None]  # (L, B): already time-major
-        batch_inds = batch_inds.reshape(-1)
-        if self.full:
-            batch_inds = (batch_inds + self.pos) % len(self)
-        return batch_inds
+        starts = np.random.choice(len(self) - seq_len, size=batch_size)  # the reference's ONE RNG draw (:158)
+        return self._unrotate(_time_major_indices(starts, seq_len))
 
     def sample(self, batch_size, seq_len):
         """-> (obs, act, rew, done), each (seq_len, batch_size, ...), host arrays."""
-        inds = self._sample_inds(batch_size, seq_len)
-        batch = self._get_samples(inds)
-        return tuple(d.reshape(seq_len, batch_size, *d.shape[1:]) for d in batch)
+        picked = self._get_samples(self._sample_inds(batch_size, seq_len))
+        return tuple(a.reshape(seq_len, batch_size, *a.shape[1:]) for a in picked)
 
     def iterate(self, batch_size, seq_len):
-        all_start = np.arange(0, len(self) - seq_len, seq_len)
-        if self.full:
-            all_start = (all_start + self.pos) % len(self)
-        np.random.shuffle(all_start)
-        for i in range(0, len(all_start) - batch_size, batch_size):
-            starts = all_start[i : i + batch_size]
-            inds = (starts[None, :] + np.arange(seq_len)[:, None]).reshape(-1)
-            if self.full:
-                inds = (inds + self.pos) % len(self)
-            batch = self._get_samples(inds)
-            yield [d.reshape(seq_len, batch_size, *d.shape[1:]) for d in batch]
+        """One shuffled pass over non-overlapping windows (reference :168-184, including its quirks: the
+        window starts are rotated by the write head before shuffling AND the gathered indices once more,
+        and a trailing group of exactly `batch_size` windows is dropped by the exclusive range)."""
+        starts = np.arange(0, len(self) - seq_len, seq_len)
+        starts = self._unrotate(starts)
+        np.random.shuffle(starts)
+        for first in range(0, len(starts) - batch_size, batch_size):
+            inds = self._unrotate(_time_major_indices(starts[first:first + batch_size], seq_len))
+            yield [a.reshape(seq_len, batch_size, *a.shape[1:]) for a in self._get_samples(inds)]
 
     def _get_samples(self, batch_inds):
-        return (
-            self.observations[batch_inds],
-            self.actions[batch_inds],
-            self.rewards[batch_inds],
-            self.dones[batch_inds],
-        )
+        return tuple(getattr(self, f)[batch_inds] for f in _FIELDS)
 
     def save(self, path):
         np.savez(path, **{k: getattr(self, k) for k in self._DATA_KEYS})
 
     def load(self, path):
-        with np.load(path) as buffer:
+        """Adopt a saved ring; the transition just behind the write head is marked terminal because the
+        episode it belonged to was cut by the save (reference :196-202)."""
+        with np.load(path) as z:
             for key in self._DATA_KEYS:
-                setattr(self, key, buffer[key])
-        self.capacity = int(self.capacity)
-        self.pos = int(self.pos)
-        self.full = bool(self.full)
-        if self.pos > 0 or self.full:
+                setattr(self, key, z[key])
+        self.capacity, self.pos, self.full = int(self.capacity), int(self.pos), bool(self.full)
+        if len(self) > 0:
             self.dones[self.pos - 1] = 1
+        self.invalidate_mirror()
+
+    def adopt_offline(self, paths, truncate_size):
+        """Offline datasets (reference algorithms/repo/dreamer.py:566-596): every file is a saved ring;
+        read each in chronological order, keep its first `truncate_size` transitions, end it with a
+        terminal, and make the concatenation THE ring (capacity = total, full, head at 0)."""
+        parts = {f: [] for f in _FIELDS}
+        for path in paths:
+            with np.load(path) as z:
+                head, wrapped = int(z["pos"]), bool(z["full"])
+                n_stored = len(z["observations"]) if wrapped else head
+                oldest = head if wrapped else 0
+                order = (oldest + np.arange(min(n_stored, int(truncate_size)))) % max(len(z["observations"]), 1)
+                piece = {f: z[f][order] for f in _FIELDS}
+            piece["dones"][-1, :] = 1
+            for f in _FIELDS:
+                parts[f].append(piece[f])
+        for f in _FIELDS:
+            setattr(self, f, np.concatenate(parts[f]))
+        self.capacity = len(self.observations)
+        self.pos, self.full = 0, True
         self.invalidate_mirror()
 
     # ------------------------------------------------------------------ device-resident mirror
@@ -216,6 +238,11 @@ class SequenceReplayBuffer:
             if slot.get("pending"):
                 cur = torch.cuda.current_stream(device)
                 self._mirror_flush(cur)
+                consumed = slot.get("consumed")
+                if consumed is not None:
+                    # the update that last READ this slot's device tensors may run on other streams
+                    # (the agent's world-model lane and its weight-gradient side stream)
+                    cur.wait_event(consumed)
                 slot["idx_dev"].copy_(slot["idx_host"], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(cur)
@@ -231,9 +258,10 @@ class SequenceReplayBuffer:
     def release(self, handle, batch_size, seq_len, device):
         """Record that everything enqueued so far on the current stream has consumed the slot."""
         st = self._staging(batch_size, seq_len, device)
-        if self._mirror_on(device):
-            return  # the gather ran on the consumer's own stream: reuse is already stream-ordered
-        if st["stream"] is not None:
+        if self._mirror_on(device) or st["stream"] is not None:
+            # call this on the stream that joins every reader of the slot (Dreamer.train_agent records it on
+            # the world-model lane after the update is enqueued); the next gather / copy INTO the slot waits
+            # for it, whichever stream that gather runs on
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
             st["slots"][handle]["consumed"] = ev

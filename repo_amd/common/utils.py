@@ -94,3 +94,12 @@ def postprocess(obs):
     if not _is_image_batch(obs):
         return obs
     return np.clip(np.floor((obs + 1.0) / 2 * 255), 0, 255).astype(np.uint8)
+
+
+class Video:
+    """(frames, fps) record handed to `logger.record("test/video", ...)` when the host application
+    has no `common.logger.Video` of its own (reference common/logger.py:26-35)."""
+
+    def __init__(self, frames, fps):
+        self.frames = frames
+        self.fps = fps

@@ -13,6 +13,8 @@ same reduced gradient.  The reference has no distributed code; this is new.
 xGMI is point-to-point (7 links per GPU): the 20.7 MB gradient is a single bucket so RCCL can
 use all links at once instead of serialising many small rings.
 """
+from fractions import Fraction
+
 import torch
 import torch.distributed as dist
 
@@ -30,7 +32,8 @@ class DataParallel:
         self.group = group if group is not None else dist.group.WORLD
         self.world_size = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
-        self._counts = {}
+        self._ratio = None        # global rows / this rank's rows (exact), set by the first global_count()
+        self.shard_counts = None
 
     # ---- collectives -------------------------------------------------------------------
     def all_reduce(self, t):
@@ -54,14 +57,34 @@ class DataParallel:
         return float(t.item())
 
     def global_count(self, local_count):
-        """Sum of `local_count` over ranks; cached per value so the steady state has no sync."""
-        g = self._counts.get(local_count)
-        if g is None:
-            t = torch.tensor([float(local_count)], dtype=torch.float64, device=self._dev)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            g = int(round(t.item()))
-            self._counts[local_count] = g
-        return g
+        """Sum of `local_count` over ranks, with NO communication in the steady state.
+
+        Every count the update asks about (T*B rows, the N = T*B imagination starts) is a fixed multiple
+        of the rank's batch shard, so the first call all-gathers the ranks' counts ONCE and keeps the exact
+        ratio global/local; later calls scale by it.  This is collective-free on every rank alike -- a
+        per-value cache would issue its all-reduce only on the ranks that miss, and hang the others.
+        Shard sizes are therefore fixed for the lifetime of this object; call `reset_counts()` on ALL
+        ranks together before changing them."""
+        local_count = int(local_count)
+        if self._ratio is None:
+            mine = torch.tensor([local_count], dtype=torch.int64, device=self._dev)
+            everyone = [torch.zeros_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(everyone, mine, group=self.group)
+            counts = [int(t.item()) for t in everyone]
+            if counts[self.rank] != local_count or local_count <= 0:
+                raise RuntimeError(f"global_count: bad shard sizes {counts} (rank {self.rank} has {local_count})")
+            self._ratio = Fraction(sum(counts), local_count)
+            self.shard_counts = counts
+        total = self._ratio * local_count
+        if total.denominator != 1:
+            raise RuntimeError(f"global_count({local_count}): not a multiple of this rank's shard "
+                               f"(global/local = {self._ratio}); call reset_counts() on all ranks first")
+        return int(total)
+
+    def reset_counts(self):
+        """Collective by convention: every rank forgets the shard ratio; the next global_count() re-gathers."""
+        self._ratio = None
+        self.shard_counts = None
 
     _dev = torch.device("cpu")
 

@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu`-marked tests need a HIP device: skip (not fail) them where there is none, so a plain
+    `pytest tests` on a CPU-only box runs the host-side suite to the end."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no HIP device visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
