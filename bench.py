@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: RePo world-model + imagination updates per second.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
 
-Workload (BASELINE.json configs[1]): algo=repo, B=50 sequences per GPU,
-L=50, H=15, A=6, 64x64x3 uint8 frames, synthetic replay batch from RandomState(1234) already
-resident in HBM, parameters at torch default init under torch.manual_seed(0), fp32 arithmetic.
-One step = one train_dynamics + one train_actor_critic (all four optimiser steps included,
-noise generated inside the timed region).  N > 1 (launched by torch.distributed.run, one rank
-per GPU): data parallel over batch rows, weak scaling (B=50 per GPU, global batch 50*N), RCCL
-all-reduce of the flat gradient buffers.
+Workload (default `--config c2` = BASELINE.json configs[1]): algo=repo, B=50
+sequences per GPU, L=50, H=15, A=6, 64x64x3 uint8 frames, parameters at torch default init under
+torch.manual_seed(0), fp32 arithmetic.  One step = ONE iteration of the reference's train_agent() loop body
+(dreamer.py:385-401): draw a fresh batch from the replay ring, train_dynamics, train_actor_critic -- all
+four optimiser steps and the noise generation inside the timed region.  The synthetic replay ring
+(RandomState(1234+rank)) is mirrored in HBM before the timed region starts (repo_amd/common/buffers.py:
+the sampler draws indices on the host exactly like the reference, the 30.7 MB batch is gathered on the
+device), so `value` is the rate with inputs resident in HBM; the same K steps on ONE resident batch are
+timed afterwards and reported as `resident_batch_ms` (what round 1's line measured).
 
-Rank 0 prints ONE JSON line.  `value` = B=50-equivalent updates per second of the whole job
-(N * K / t).  `roofline` is for the dominant kernel (the fp32-MFMA implicit-GEMM engine on its
-largest launch, the decoder's 64->32 transposed convolution): algorithmic FLOPs of that launch
-divided by its average duration measured here with HIP events on the launch stream.
-`cpu_baseline` is the CPU oracle (PyTorch fp32 restatement of the reference) timed on this
-box's host cores on a bounded sample (rank 0, N=1 only).
+N > 1: data parallel over batch rows, weak scaling (B=50 per GPU, global batch 50*N), RCCL all-reduce of
+the flat gradient buffers.  `python bench.py --gpus N` starts its own ranks (one child process per GPU via
+torch.distributed.run, before this process touches the GPU); when an external launcher already set
+RANK/WORLD_SIZE it runs as that rank.  Rank 0 prints ONE JSON line; `n_gpus` is the number of ranks the
+process group saw.
+
+`roofline` is for the dominant kernel (the largest single launch: the decoder's 64->32 transposed
+convolution, `dconv_up_kernel<GDec3>`): algorithmic FLOPs of that launch / its average duration measured
+with HIP events recorded on its launch stream INSIDE the timed updates.  `traffic` comes from the
+rocprofv3 --pmc summary committed under profiles/ (named in `traffic_source`), never from this run.
+`cpu_baseline` is the CPU oracle (PyTorch fp32 restatement of the reference) timed on this box's host
+cores on the full 50-sequence batch, 2 warm-up + 3 timed updates (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +41,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B, L, H, A = 50, 50, 15, 6
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-FLOP_PER_UPDATE = 740.4e9      # SURVEY.md 8d, autograd-counted on the reference at B=50 L=50 H=15
+L, H = 50, 15
+# per-config: (algo, B, A, label); FLOPs scale with rows (SURVEY.md 8d scaling law)
+CONFIGS = {
+    "c2": ("repo", 50, 6, "dmc_distracted-walker-walk shapes (BASELINE configs[1])"),
+    "c4": ("repo", 32, 7, "maniskill-PushCubeMatterport shapes at the reference's 64x64 frames, A=7 (BASELINE configs[3] pin)"),
+    "c5": ("dreamer", 50, 6, "algo=dreamer on dmc_distracted-walker-walk shapes (BASELINE configs[4])"),
+}
+FLOP_PER_UPDATE_B50 = 740.4e9  # SURVEY.md 8d, autograd-counted on the reference at B=50 L=50 H=15 A=6
+RING_FRAMES = 6000             # synthetic replay ring per rank (72 MB of frames; 120 windows of 50)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")
 
 
 class Space:
@@ -42,8 +60,9 @@ class Space:
 
 
 class Env:
-    observation_space = Space((3, 64, 64))
-    action_space = Space((A,))
+    def __init__(self, A=6):
+        self.observation_space = Space((3, 64, 64))
+        self.action_space = Space((A,))
 
 
 class NullLogger:
@@ -56,7 +75,7 @@ class NullLogger:
         pass
 
 
-def config(algo="repo"):
+def config(algo="repo", B=50):
     from types import SimpleNamespace
 
     # defaults of experiments/train_repo.py:8-76 (hot-path keys)
@@ -70,7 +89,7 @@ def config(algo="repo"):
     )
 
 
-def synthetic_batch(seed=1234):
+def synthetic_batch(seed=1234, B=50, A=6):
     rs = np.random.RandomState(seed)
     obs = rs.randint(0, 256, (L, B, 3, 64, 64)).astype(np.uint8)
     actions = rs.uniform(-1, 1, (L, B, A)).astype(np.float32)
@@ -79,15 +98,62 @@ def synthetic_batch(seed=1234):
     return obs, actions, rewards, dones
 
 
-def dominant_kernel_roofline(iters=20):
-    """Decoder conv3 (64x13x13 -> 32x30x30, k6 s2) as launched inside the update: the largest
-    single launch (61.05 GFLOP; dconv_up_kernel<GDec3>, all four parity classes in one launch), timed
-    with HIP events on the launch stream.  `traffic` is that launch's HBM bytes from the rocprofv3 PMC
-    passes committed in profiles/r01_pmc_direct_conv.txt (FETCH_SIZE x2 for the gfx950 wide-read
-    under-report + WRITE_SIZE, per launch of the same nimg=2450 shape)."""
+def synthetic_ring(buffer_cls, seed, A, device):
+    """A full replay ring of RING_FRAMES synthetic transitions (same distributions as synthetic_batch:
+    uniform u8 frames, uniform actions / rewards, episode ends with probability 1/500), mirrored in HBM."""
+    rs = np.random.RandomState(seed)
+    ring = buffer_cls(RING_FRAMES, (3, 64, 64), (A,), obs_type=np.uint8)
+    ring.observations[:] = rs.randint(0, 256, size=ring.observations.shape, dtype=np.uint8)
+    ring.actions[:] = rs.uniform(-1, 1, ring.actions.shape)
+    ring.rewards[:] = rs.uniform(0, 1, ring.rewards.shape)
+    ring.dones[:] = rs.uniform(size=ring.dones.shape) < 1 / 500
+    ring.pos, ring.full = 0, True
+    ring.enable_device_mirror(device)
+    ring.invalidate_mirror()
+    return ring
+
+
+class LaunchTimer:
+    """HIP-event pairs around every launch of one conv layer, recorded on the launch stream while the
+    timed updates run (repo_amd.ops.conv_up is wrapped for the duration of the `with` block)."""
+
+    def __init__(self, layer):
+        self.layer, self.pairs = layer, []
+
+    def __enter__(self):
+        from repo_amd import functional as Fn
+        from repo_amd import ops
+
+        self._ops, self._orig = ops, ops.conv_up
+        timer = self
+
+        def timed_conv_up(layer, *a, **k):
+            if layer != timer.layer:
+                return timer._orig(layer, *a, **k)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = timer._orig(layer, *a, **k)
+            e1.record(s)
+            timer.pairs.append((e0, e1))
+            return out
+
+        ops.conv_up = timed_conv_up
+        assert Fn.ops is ops
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.conv_up = self._orig
+        return False
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+
+
+def dominant_kernel_isolated(nimg, iters=20):
+    """The same launch alone on an idle GPU (no other stream running): the kernel's own speed."""
     from repo_amd import ops
 
-    nimg = (L - 1) * B
     dev = torch.device("cuda")
     small = torch.randn(nimg, 64, 13, 13, device=dev).relu_()
     w = torch.randn(64, 32, 6, 6, device=dev) * 0.05
@@ -102,19 +168,36 @@ def dominant_kernel_roofline(iters=20):
         ops.conv_up(ops.DEC3, small, w, bias, epi=ops.EPI_RELU, out=out)
     e1.record(stream)
     e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flop = 2.0 * nimg * 169 * 64 * 32 * 36  # every (input pixel, cin, cout, tap) MAC once
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline(timer, nimg):
+    """Decoder conv3 (64x13x13 -> 32x30x30, k6 s2): the largest single launch of the update (61.05 GFLOP at
+    nimg=2450: every (input pixel, cin, cout, tap) MAC once)."""
+    flop = 2.0 * nimg * 169 * 64 * 32 * 36
+    ms = timer.mean_ms()
+    iso = dominant_kernel_isolated(nimg)
     achieved = flop / (ms * 1e-3) / 1e12
-    return {
+    out = {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": 4.37e8,
-        "kernel": "dconv_up_kernel<Geo<32,64,30,6>, UTile<128,2>> (decoder conv3 forward)",
-        "ms_per_launch": round(ms, 4), "flop_per_launch": flop, "mfma_pipe_busy_pmc": 0.795,
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "kernel": "dconv_up_kernel<Geo<32,64,30,6>> (decoder conv3 forward)",
+        "ms_per_launch": round(ms, 4), "launches_timed": len(timer.pairs), "flop_per_launch": flop,
+        "timing": "HIP events on the launch stream inside the timed updates (other streams of the update run beside it)",
+        "isolated_ms_per_launch": round(iso, 4),
+        "isolated_frac": round(flop / (iso * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
     }
+    if os.path.exists(PMC_SUMMARY):
+        pmc = json.load(open(PMC_SUMMARY))
+        if pmc.get("nimg") == nimg:
+            out["traffic"] = pmc.get("traffic_bytes_per_launch")
+            out["traffic_source"] = "profiles/dominant_kernel_pmc.json <- " + str(pmc.get("source"))
+            out["mfma_pipe_busy_pmc"] = pmc.get("mfma_pipe_busy")
+    return out
 
 
-def _cpu_baseline_worker(q, nb, threads):
-    """Child process: the CPU oracle on the first `nb` sequences of the synthetic batch."""
+def _cpu_baseline_worker(q, threads, warm, timed):
+    """Child process: the CPU oracle on the full synthetic batch."""
     import time as _t
 
     import torch as _torch
@@ -123,46 +206,80 @@ def _cpu_baseline_worker(q, nb, threads):
     from oracle import fixtures as fx
     from oracle.repo_oracle import OracleAgent
 
-    obs, act, rew, done = synthetic_batch(1234)
-    batch = (obs[:, :nb], act[:, :nb], rew[:, :nb], done[:, :nb])
-    cfg = fx.default_config(algo="repo", batch_size=nb, chunk_size=L, horizon=H)
+    B, A = 50, 6
+    batch = synthetic_batch(1234, B, A)
+    cfg = fx.default_config(algo="repo", batch_size=B, chunk_size=L, horizon=H)
     agent = OracleAgent(cfg, A, seed=7)
-    noise = fx.make_noise(L, nb, H, A, seed=1)
-    agent.update(*batch, noise)  # warm-up (thread pools, oneDNN primitive caches)
+    noise = fx.make_noise(L, B, H, A, seed=1)
+    for _ in range(warm):
+        agent.update(*batch, noise)  # thread pools, oneDNN primitive caches
     t0 = _t.perf_counter()
-    agent.update(*batch, noise)
-    q.put(_t.perf_counter() - t0)
+    for _ in range(timed):
+        agent.update(*batch, noise)
+    q.put((_t.perf_counter() - t0) / timed)
 
 
-def cpu_baseline(nb=10, threads=None, timeout_s=150.0):
-    """The CPU oracle (PyTorch fp32 restatement of the reference update) on a BOUNDED sample:
-    the first `nb` of the 50 sequences of the same synthetic batch, full L and H, 1 warm-up +
-    1 timed update, in a child process that is killed after `timeout_s`.  Reported in
-    B=50-equivalent updates/s (= nb/50 / seconds); every term of the update is linear in B."""
+def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0):
+    """the CPU oracle (PyTorch fp32 restatement of the reference update, validated against the
+    reference's goldens) on the SAME full workload -- B=50, L=50, H=15 -- 2 warm-up + 3 timed updates on
+    this box's host cores, in a child process that is killed after `timeout_s`."""
     import multiprocessing as mp
 
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = threads or max(1, min(avail, 32))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_cpu_baseline_worker, args=(q, nb, threads))
+    p = ctx.Process(target=_cpu_baseline_worker, args=(q, threads, warm, timed))
     p.start()
     p.join(timeout_s)
+    base = {"value": None, "unit": "updates/s", "cores": threads, "kind": "port"}
     if p.is_alive():
         p.kill()
         p.join()
-        return {"value": None, "unit": "updates/s", "cores": threads, "kind": "port",
-                "sample": f"timed out after {timeout_s:.0f} s on {nb}/{B} sequences"}
+        return {**base, "sample": f"timed out after {timeout_s:.0f} s ({warm}+{timed} full-batch updates)"}
     try:
         dt = q.get(timeout=5)
     except Exception:
-        return {"value": None, "unit": "updates/s", "cores": threads, "kind": "port",
-                "sample": f"oracle child exited with code {p.exitcode} before reporting"}
+        return {**base, "sample": f"oracle child exited with code {p.exitcode} before reporting"}
     return {
-        "value": round((nb / B) / dt, 5), "unit": "updates/s", "cores": threads, "kind": "port",
-        "sample": f"1 timed update after 1 warm-up on {nb} of the {B} sequences (L={L}, H={H}), {dt:.2f} s, "
-                  f"scaled by {nb}/{B}; PyTorch {torch.__version__} CPU, {threads} threads of {avail} available cores",
+        **base, "value": round(1.0 / dt, 5),
+        "sample": f"{timed} timed updates after {warm} warm-up on the full batch (B=50, L={L}, H={H}, A=6), "
+                  f"{dt:.2f} s per update; PyTorch {torch.__version__} CPU, {threads} threads of {avail} available cores",
     }
+
+
+# ----------------------------------------------------------------------------- self-launch (N > 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """Start one child process per GPU with torch.distributed.run and hand back its exit code.  This process
+    has not touched the GPU (no HIP call has been made), and it never replaces itself: the ranks are children."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(world, rank):
+    """--rendezvous-only: the launcher / process-group plumbing without the workload (gloo when there is no
+    GPU), so the self-launch path is testable on a CPU-only box."""
+    import torch.distributed as dist
+
+    dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    t = torch.ones(1, device="cuda" if torch.cuda.is_available() else "cpu")
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"rendezvous_ranks": int(t.item()), "world_size": dist.get_world_size()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -170,23 +287,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--algo", default="repo")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--algo", default=None, help="override the config's algorithm (repo | dreamer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--join", action="store_true", help="join the two update lanes after every update (no overlap)")
     ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: ONE global batch of 50 sequences sharded over the ranks (7,7,6,...) "
-                         "instead of 50 per GPU; not the contract's default")
+                    help="strong scaling: ONE global batch of B sequences sharded over the ranks (7,7,6,...) "
+                         "instead of B per GPU; resident batch only; not the contract's default")
+    ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.rendezvous_only:
+        return rendezvous_only(world, rank)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
 
     from repo_amd.algorithms.repo import Dreamer, RePo
+    from repo_amd.common.buffers import SequenceReplayBuffer
     from repo_amd.common.utils import set_gpu_mode
 
+    algo, B, A, label = CONFIGS[args.config]
+    algo = args.algo or algo
     set_gpu_mode(True, local_rank)
     dev = torch.device("cuda", local_rank)
     dp = None
@@ -201,46 +328,78 @@ def main():
         dp = DataParallel(dist.group.WORLD)
 
     torch.manual_seed(0)
-    agent = (RePo if args.algo == "repo" else Dreamer)(config(args.algo), Env(), Env(), NullLogger())
+    cfg = config(algo, B)
+    agent = (RePo if algo == "repo" else Dreamer)(cfg, Env(A), Env(A), NullLogger())
     if dp is not None:
         dp.attach(agent)
     if args.strong:
         from repo_amd.parallel import shard_rows
 
         lo, hi = shard_rows(B, world, rank)
-        host = tuple(np.ascontiguousarray(x[:, lo:hi]) for x in synthetic_batch(1234))
+        host = tuple(np.ascontiguousarray(x[:, lo:hi]) for x in synthetic_batch(1234, B, A))
+        cfg.batch_size = hi - lo
     else:
-        host = synthetic_batch(1234 + rank)  # each rank holds its own B=50 shard of the global batch
-    batch = tuple(torch.from_numpy(x).to(dev) for x in host)
+        host = synthetic_batch(1234 + rank, B, A)  # each rank holds its own B-sequence shard of the global batch
+    resident = tuple(torch.from_numpy(x).to(dev) for x in host)
+    Bl = cfg.batch_size
 
-    # same call pattern as Dreamer.train_agent()'s loop: update(join=False) lets the world-model
-    # half of update k+1 overlap the actor-critic half of update k; the timed region is closed by
-    # joining both lanes + a device synchronize, so every one of the K updates is complete
-    for _ in range(args.warmup):
-        agent.update(batch, join=args.join)
-    agent.synchronize()
-    if dp is not None:
-        dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        agent.update(batch, join=args.join)
-    agent.synchronize()
-    torch.cuda.synchronize()
-    if dp is not None:
-        dp.barrier()
-    dt = time.perf_counter() - t0
-    if dp is not None:
-        dt = dp.max_float(dt)
+    def run_resident(k):
+        # same call pattern as Dreamer.train_agent()'s loop: update(join=False) lets the world-model half of
+        # update k+1 overlap the actor-critic half of update k
+        for _ in range(k):
+            agent.update(resident, join=args.join)
+        agent.synchronize()
+
+    np.random.seed(4321 + rank)  # the sampler's RNG (np.random.choice, like the reference)
+    agent.buffer = synthetic_ring(SequenceReplayBuffer, 1234 + rank, A, dev)
+
+    def run_from_ring(k):
+        # train_agent()'s loop body K times: fresh indices on the host, device gather, pipelined update
+        ring = agent.buffer
+        h = ring.prefetch(Bl, L, dev)
+        for i in range(k):
+            batch = ring.acquire(h, Bl, L, dev)
+            cur = h
+            agent.update(batch, join=args.join)
+            with torch.cuda.stream(agent._wm_stream):
+                ring.release(cur, Bl, L, dev)
+            if i + 1 < k:
+                h = ring.prefetch(Bl, L, dev)
+        agent.synchronize()
+
+    def timed(fn, k):
+        if dp is not None:
+            dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(k)
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.barrier()
+        dt = time.perf_counter() - t0
+        return dp.max_float(dt) if dp is not None else dt
+
+    main_loop = run_resident if args.strong else run_from_ring
+    main_loop(args.warmup)
+    from repo_amd import ops
+
+    timer = LaunchTimer(ops.DEC3)
+    with timer:
+        dt = timed(main_loop, args.steps)
+    run_resident(2)
+    dt_res = timed(run_resident, args.steps)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = (1 if args.strong else world) * args.steps / dt
+        nranks = dp.world_size if dp is not None else 1
+        value = (1 if args.strong else nranks) * args.steps / dt
+        flop = FLOP_PER_UPDATE_B50 * (Bl if args.strong else B) / 50.0
         line = {
-            "metric": "world-model+imagine updates/sec (B=50,L=50,64x64x3)",
+            "metric": "world-model+imagine updates/sec (B=50,L=50,64x64x3)" if args.config != "c4" else
+                      "world-model+imagine updates/sec (B=32,L=50,64x64x3,A=7)",
             "value": round(value, 3),
             "unit": "updates/s",
-            "n_gpus": world,
+            "n_gpus": nranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 3),
@@ -250,18 +409,20 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"algo={args.algo} dmc_distracted-walker-walk shapes: B=50/GPU L=50 H=15 A=6 64x64x3 uint8, "
-                            "one update = train_dynamics + train_actor_critic incl. 4 optimiser steps",
-                "global_batch": B if args.strong else B * world, "per_gpu_batch": (B / world) if args.strong else B,
-                "seq_len": L, "horizon": H,
-                "parallelism": f"dp{world}", "sequences_per_s": round(value * B, 2),
-                "algorithmic_tflops": round(FLOP_PER_UPDATE * value / 1e12, 2),
-                "frac_of_fp32_mfma_peak_all_gpus": round(FLOP_PER_UPDATE * value / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+                "workload": f"{args.config}: algo={algo} {label}: B={B}/GPU L={L} H={H} A={A} 64x64x3 uint8; one step = "
+                            "sample a fresh batch from the HBM-mirrored replay ring + train_dynamics + "
+                            "train_actor_critic incl. 4 optimiser steps" + (" (resident batch: --strong)" if args.strong else ""),
+                "global_batch": B if args.strong else B * nranks, "per_gpu_batch": Bl,
+                "seq_len": L, "horizon": H, "ring_frames": RING_FRAMES,
+                "parallelism": f"dp{nranks}", "sequences_per_s": round(value * B, 2),
+                "algorithmic_tflops": round(flop * args.steps / dt * (1 if args.strong else nranks) / 1e12, 2),
+                "frac_of_fp32_mfma_peak_all_gpus": round(flop * args.steps / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             },
+            "resident_batch_ms": round(dt_res / args.steps * 1e3, 3),
             "last_scalars": {k: round(float(v), 6) for k, v in agent.last_scalars.items()},
         }
-        line["roofline"] = dominant_kernel_roofline()
-        if world == 1 and not args.no_cpu_baseline:
+        line["roofline"] = roofline(timer, (L - 1) * Bl)
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dp is not None:

@@ -51,6 +51,12 @@ typedef struct ihipStream_t* hipStream_t;
 
 int repo_abi_version(void);
 const char* repo_strerror(int code);
+/* REPO_OK if HIP device `device` is gfx950 (MI355X), REPO_E_ARCH if it is another architecture, REPO_E_BADARG
+ * for an ordinal that does not exist, a positive hipError_t if the runtime cannot be queried.  Every entry
+ * point below makes the same check for the calling thread's current device (once per device, then cached)
+ * and returns REPO_E_ARCH before launching anything; the reference's counterpart is the device choice in
+ * common/utils.py:10-24 (set_gpu_mode / get_device), which has no notion of an unsupported GPU. */
+int repo_device_check(int device);
 /* Test aid: fills every CU's LDS with NaN patterns (see tests/test_ops_gpu.py::test_no_uninitialised_lds). */
 int repo_debug_poison_lds(hipStream_t stream);
 

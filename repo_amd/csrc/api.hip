@@ -1,7 +1,48 @@
 // ABI bookkeeping entry points.
 #include "common.h"
 
+#include <atomic>
+#include <string.h>
+
 extern "C" int repo_abi_version(void) { return REPO_ABI_VERSION; }
+
+namespace repo {
+// 0 = not queried yet, 1 = gfx950, 2 = some other architecture.  Written once per device ordinal; the only
+// mutable global state of the library ("once-initialised per-device constants").
+static std::atomic<int> g_arch[64];
+
+static int query_arch(int dev) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return (int)e;
+  // gcnArchName is e.g. "gfx950:sramecc+:xnack-"
+  const bool ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0 &&
+                  (prop.gcnArchName[6] == '\0' || prop.gcnArchName[6] == ':');
+  return ok ? REPO_OK : REPO_E_ARCH;
+}
+
+int arch_status() {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= 64) return query_arch(dev);
+  const int seen = g_arch[dev].load(std::memory_order_relaxed);
+  if (seen == 1) return REPO_OK;
+  if (seen == 2) return REPO_E_ARCH;
+  const int rc = query_arch(dev);
+  if (rc == REPO_OK) g_arch[dev].store(1, std::memory_order_relaxed);
+  else if (rc == REPO_E_ARCH) g_arch[dev].store(2, std::memory_order_relaxed);
+  return rc;
+}
+}  // namespace repo
+
+extern "C" int repo_device_check(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return (int)e;
+  if (device < 0 || device >= n) return REPO_E_BADARG;
+  return repo::query_arch(device);
+}
 
 extern "C" const char* repo_strerror(int code) {
   switch (code) {
@@ -30,6 +71,7 @@ __global__ __launch_bounds__(256) void poison_lds_kernel(int words, unsigned* si
 }  // namespace repo
 
 extern "C" int repo_debug_poison_lds(hipStream_t stream) {
+  REPO_ARCH_GUARD();
   const int bytes = 160 * 1024;
   hipError_t e = hipFuncSetAttribute((const void*)repo::poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      bytes);

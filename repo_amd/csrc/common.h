@@ -11,12 +11,24 @@
     if (_e != hipSuccess) return (int)_e;        \
   } while (0)
 
+// First statement of every entry point that launches work: REPO_E_ARCH unless the current device is gfx950
+// (queried once per device, api.hip).
+#define REPO_ARCH_GUARD()                 \
+  do {                                    \
+    int _a = repo::arch_status();         \
+    if (_a != REPO_OK) return _a;         \
+  } while (0)
+
 #define REPO_REQUIRE(cond, code) \
   do {                           \
     if (!(cond)) return (code);  \
   } while (0)
 
 namespace repo {
+
+// REPO_OK when the calling thread's current HIP device is gfx950, REPO_E_ARCH when it is anything else, a
+// positive hipError_t when the device cannot be queried.  Cached per device ordinal after the first query.
+int arch_status();
 
 constexpr float kLog2Pi = 1.8378770664093453f;  // ln(2*pi)
 constexpr int kMaxIdx = 0x7fffffff;

@@ -674,6 +674,7 @@ using namespace repo;
 
 extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
                               const float* bias, float* small, int epi, const float* aux, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(big && w && small, REPO_E_BADARG);
@@ -687,6 +688,7 @@ extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_
 
 extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
                             float* big, int epi, const float* aux, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(small && w && big, REPO_E_BADARG);
@@ -702,6 +704,7 @@ extern "C" size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg) {
 extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big, int big_is_u8,
                                float* dw, float* dbias_small, int accumulate, void* ws, size_t ws_bytes,
                                hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
   REPO_REQUIRE(small && big && dw, REPO_E_BADARG);
   if (big_is_u8) {
@@ -754,6 +757,7 @@ static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, cons
 extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* w, const float* bias,
                                     const void* target, int target_is_u8, float grad_scale, float* recon, float* dpre,
                                     float* loss_sum, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
   REPO_REQUIRE(h3 && w && target, REPO_E_BADARG);
   REPO_REQUIRE(nimg * (int64_t)GDec4::CS * GDec4::PS < kMaxBufElems, REPO_E_SHAPE);
@@ -782,6 +786,7 @@ extern "C" size_t repo_channel_sum_workspace_bytes(int64_t nimg, int64_t C, int6
 
 extern "C" int repo_channel_sum(int64_t nimg, int64_t C, int64_t P, const float* x, float* out, int accumulate,
                                 void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg > 0 && C > 0 && P > 0, REPO_E_SHAPE);
   REPO_REQUIRE(x && out, REPO_E_BADARG);
   REPO_REQUIRE(C <= 65535, REPO_E_SHAPE);
@@ -798,6 +803,7 @@ extern "C" int repo_channel_sum(int64_t nimg, int64_t C, int64_t P, const float*
 }
 
 extern "C" int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(n >= 0, REPO_E_SHAPE);
   if (n == 0) return REPO_OK;
   REPO_REQUIRE(dy && h && y, REPO_E_BADARG);

@@ -323,6 +323,7 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
                          int64_t lda, const float* B, int64_t ldb, const float* bias, int64_t bias_div,
                          float* C, int64_t ldc, int epi, const float* aux, int64_t ldaux, int accumulate,
                          hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(M >= 0 && N >= 0 && K >= 0, REPO_E_SHAPE);
   if (M == 0 || N == 0) return REPO_OK;
   REPO_REQUIRE(A && B && C, REPO_E_BADARG);
@@ -398,6 +399,7 @@ extern "C" size_t repo_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t 
 extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t lddy,
                                const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
                                int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(M >= 0 && N >= 0 && K >= 0, REPO_E_SHAPE);
   if (N == 0 || K == 0) return REPO_OK;
   REPO_REQUIRE(dY && X && dW, REPO_E_BADARG);

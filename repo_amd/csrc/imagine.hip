@@ -203,6 +203,7 @@ using namespace repo;
 extern "C" int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
                             const float* x, int64_t ldx, const float* const* params, float* const* hidden_out,
                             float* out, int64_t ldo, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(rows >= 0 && in_dim > 0 && hidden > 0 && out_dim > 0 && n_layers >= 1, REPO_E_SHAPE);
   if (rows == 0) return REPO_OK;
   REPO_REQUIRE(x && params && out && (n_layers == 1 || hidden_out), REPO_E_BADARG);
@@ -236,6 +237,7 @@ extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
                             const float* const* hidden_acts, const float* dout, int64_t lddout,
                             float* const* dparams, int accumulate_w, float* dx, int64_t lddx, int accumulate_dx,
                             void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && in_dim > 0 && hidden > 0 && out_dim > 0 && n_layers >= 1, REPO_E_SHAPE);
   REPO_REQUIRE(x && params && dout && (n_layers == 1 || hidden_acts), REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_mlp_bwd_workspace_bytes(rows, in_dim, hidden, out_dim, n_layers),
@@ -271,6 +273,7 @@ extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
 extern "C" int repo_actor_head_fwd(int64_t rows, int64_t A, int64_t S, const float* raw, const float* eps,
                                    const float* state, int64_t ldstate, float min_std, float init_std,
                                    float mean_scale, float* mean, float* std, float* xsa, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && A > 0 && rows * (S + A) < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(raw && mean && std && (!eps || (state && xsa)), REPO_E_BADARG);
   hipLaunchKernelGGL(actor_head_fwd_kernel, dim3(ew_blocks(rows * (S + A))), dim3(256), 0, stream, (int)rows, (int)A,
@@ -283,6 +286,7 @@ extern "C" int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, 
                                    const float* daction, int64_t ldda, const float* action, int64_t ldact,
                                    const float* eps, const float* mean, const float* std, float min_std,
                                    float mean_scale, float* draw, int accumulate, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && A > 0 && rows * 2 * A < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(mean && std && draw && (!daction || (action && eps)), REPO_E_BADARG);
   hipLaunchKernelGGL(actor_head_bwd_kernel, dim3(ew_blocks(rows * A)), dim3(256), 0, stream, (int)rows, (int)A, dmean,
@@ -312,6 +316,7 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                                      float* prior_std, float* a_hidden, int64_t a_layer_rows, float* a_raw,
                                      float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp,
                                      void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(img_dims_ok(Hm, N, A, D, Hd, S) && n_actor_layers >= 2 && n_actor_layers <= 8, REPO_E_SHAPE);
   REPO_REQUIRE(a_layer_rows >= Hm * N, REPO_E_SHAPE);
   REPO_REQUIRE(rssm_params && actor_params && belief0 && state0 && eps_act && eps_prior && featx && prior_mean &&
@@ -374,6 +379,7 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                                      const float* xsa, const float* e, const float* gates, const float* hp,
                                      const float* dfeat, const float* dprior_mean, const float* dprior_std,
                                      float* d_araw, float* dfeat0, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(img_dims_ok(Hm, N, A, D, Hd, S), REPO_E_SHAPE);
   REPO_REQUIRE(rssm_params && eps_act && eps_prior && featx && prior_std && a_mean && a_std && xsa && e && gates &&
                    hp && dfeat && d_araw,

@@ -290,6 +290,7 @@ extern "C" int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const f
                                const float* qs, int mode, float alpha, const float* log_beta, float free_nats,
                                float scale, float* dpm, float* dps, float* dqm, float* dqs, float* kl_sum, void* ws,
                                size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && S > 0 && S <= 64 && rows * S < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(pm && ps && qm && qs && kl_sum && (mode == 0 || mode == 1), REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
@@ -303,6 +304,7 @@ extern "C" int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const f
 extern "C" int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const float* kl_sum, int64_t rows,
                               float target_kl, float lr, float beta1, float beta2, float eps, int64_t step, int apply,
                               float* scalars_out, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(log_beta && exp_avg && exp_avg_sq && kl_sum && scalars_out && rows > 0 && step >= 1, REPO_E_BADARG);
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -315,6 +317,7 @@ extern "C" int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq
 
 extern "C" int repo_scalar_nll(int64_t n, const float* pred, const float* target, const float* mask, float scale,
                                float* dpred, float* sums2, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(n > 0 && n < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(pred && target && sums2, REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
@@ -328,6 +331,7 @@ extern "C" int repo_scalar_nll(int64_t n, const float* pred, const float* target
 extern "C" int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,
                                         const float* eps, float gscale, float* dmean, float* dstd, float* ent_sum,
                                         void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && A > 0 && samples > 0 && rows * A < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(mean && std && eps && ent_sum, REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
@@ -341,6 +345,7 @@ extern "C" int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples
 
 extern "C" int repo_normal_entropy(int64_t n, const float* std, float gscale, float* dstd, float* ent_sum, void* ws,
                                    size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(n > 0 && n < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(std && ent_sum, REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
@@ -353,6 +358,7 @@ extern "C" int repo_normal_entropy(int64_t n, const float* std, float gscale, fl
 extern "C" int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, const float* values, float gamma,
                                   float lambda_, float gret, float* returns, float* drewards, float* dvalues,
                                   float* ret_sum, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(Hm >= 2 && N > 0 && Hm * N < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(rewards && values && returns && ret_sum && ((drewards == nullptr) == (dvalues == nullptr)),
                REPO_E_BADARG);
@@ -366,6 +372,7 @@ extern "C" int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, c
 
 extern "C" int repo_tanh_normal_mode(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,
                                      const float* eps, float* action, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && A > 0 && samples > 0 && rows * A * samples < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(mean && std && eps && action, REPO_E_BADARG);
   const int blocks = (int)((rows + 3) / 4 > 4096 ? 4096 : (rows + 3) / 4);

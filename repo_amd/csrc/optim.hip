@@ -59,6 +59,7 @@ extern "C" size_t repo_grad_sqnorm_workspace_bytes(void) { return 1024 * sizeof(
 
 extern "C" int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* ws, size_t ws_bytes,
                                 hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(n > 0, REPO_E_SHAPE);
   REPO_REQUIRE(g && sqnorm, REPO_E_BADARG);
   REPO_REQUIRE(((uintptr_t)g & 15) == 0, REPO_E_ALIGN);
@@ -75,6 +76,7 @@ extern "C" int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* 
 extern "C" int repo_clip_adam(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                               const float* sqnorm, float max_norm, float lr, float beta1, float beta2, float eps,
                               int64_t step, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(n > 0 && step >= 1, REPO_E_SHAPE);
   REPO_REQUIRE(params && grads && exp_avg && exp_avg_sq, REPO_E_BADARG);
   const double bc1 = 1.0 - pow((double)beta1, (double)step);

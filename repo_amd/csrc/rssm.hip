@@ -692,6 +692,7 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
                                      float* prior_state, float* prior_mean, float* prior_std, float* post_mean,
                                      float* post_std, float* xsa, float* e, float* gates, float* hp, float* hq,
                                      float* eemb, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0, REPO_E_SHAPE);
   REPO_REQUIRE(params && prev_belief && prev_state && actions && nonterms && embeds && eps_prior && eps_post,
                REPO_E_BADARG);
@@ -774,6 +775,7 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
                                      const float* dqs, float* const* dparams, float* dembeds, float* dprev_belief,
                                      float* dprev_state, int accumulate, void* ws, size_t ws_bytes,
                                      hipStream_t stream) {
+  REPO_ARCH_GUARD();
   REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0 && T > 0, REPO_E_SHAPE);
   REPO_REQUIRE(params && nonterms && embeds && eps_prior && eps_post && featx && prior_std && post_std && xsa && e &&
                    gates && hp && hq && dparams,

@@ -97,3 +97,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.repo_abi_version() >= 1
     for code in range(-1, -8, -1):
         assert L.repo_strerror(code)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no external launcher starts two ranks itself (torch.distributed.run
+    children, rendezvous on 127.0.0.1) -- checked here on CPU with the workload switched off."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"rendezvous_ranks": 2, "world_size": 2}
+    # an external launcher's WORLD_SIZE that disagrees with --gpus is an error, not a silent single-rank run
+    env2 = dict(env, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                        capture_output=True, text=True, timeout=120, env=env2)
+    assert r2.returncode != 0 and "WORLD_SIZE=3" in r2.stderr

@@ -220,22 +220,27 @@ def test_repo_config0_b16_matches_oracle_scalars_two_updates():
 
 
 class ThreadDP:
-    """Stands in for repo_amd.parallel.DataParallel with world_size 2 on ONE GPU: the two 'ranks'
-    run in two host threads; all_reduce meets at a barrier and sums the two tensors."""
+    """Stands in for repo_amd.parallel.DataParallel on ONE GPU: the `world` 'ranks' run in host threads;
+    all_reduce meets at a barrier and every rank sums the same tensors in the same (rank) order, so the
+    replicas see bit-identical totals, as they do behind RCCL."""
 
-    def __init__(self, rank, shared):
-        self.rank, self.world_size, self.sh = rank, 2, shared
+    def __init__(self, rank, world, shared, ratio):
+        self.rank, self.world_size, self.sh, self.ratio = rank, world, shared, ratio
 
     def global_count(self, n):
-        return n * self.world_size
+        g = self.ratio * n
+        assert g.denominator == 1
+        return int(g)
 
     def all_reduce(self, t):
         sh = self.sh
         sh["slot"][self.rank] = t
-        torch.cuda.current_stream().synchronize()  # the peer reads t from ITS stream
+        torch.cuda.current_stream().synchronize()  # the peers read t from THEIR streams
         sh["barrier"].wait()
-        total = sh["slot"][0] + sh["slot"][1]
-        torch.cuda.current_stream().synchronize()  # before the peer overwrites its slot
+        total = sh["slot"][0].clone()
+        for r in range(1, self.world_size):
+            total += sh["slot"][r]
+        torch.cuda.current_stream().synchronize()  # before a peer overwrites its slot
         sh["barrier"].wait()
         t.copy_(total)
         return t
@@ -245,18 +250,16 @@ class ThreadDP:
         return buf
 
 
-def test_data_parallel_two_shards_equal_full_batch():
-    """Two row shards with sum-all-reduced gradients reproduce the full-batch update (8e)."""
+def _run_sharded(algo, L, B, H, A, world, batch, nz, seed=7):
+    """One update of `world` row shards (repo_amd.parallel.shard_rows) in threads on one GPU.
+    Returns (agents, their last_scalars)."""
     import threading
+    from fractions import Fraction
 
-    L, B, H, A = 8, 6, 5, 6
-    batch, _ = dev_batch(L, B, A, 21)
-    nz, _ = dev_noise(L, B, H, A, 22)
-    full, _ = make_agent("repo", L, B, H, A)
-    full.noise_source = nz
-    full.update(batch)
-    s_full = dict(full.last_scalars)
+    from repo_amd.parallel import shard_rows
+
     T, N = L - 1, (L - 1) * B
+    bounds = [shard_rows(B, world, r) for r in range(world)]
 
     def shard_noise(lo, hi):
         nb = hi - lo
@@ -269,31 +272,43 @@ def test_data_parallel_two_shards_equal_full_batch():
             "entropy": nz["entropy"].view(100, H - 1, N, A)[:, :, rows].reshape(100, (H - 1) * T * nb, A).contiguous(),
         }
 
-    halves = [(0, 3), (3, 6)]
-    shared = {"slot": [None, None], "barrier": threading.Barrier(2)}
-    agents, scal, errs = [None, None], [None, None], []
-    for r in range(2):
-        agents[r], _ = make_agent("repo", L, 3, H, A)
-        agents[r].dp = ThreadDP(r, shared)
-        agents[r].noise_source = shard_noise(*halves[r])
+    shared = {"slot": [None] * world, "barrier": threading.Barrier(world)}
+    agents, scal, errs = [None] * world, [None] * world, []
+    for r, (lo, hi) in enumerate(bounds):
+        agents[r], _ = make_agent(algo, L, hi - lo, H, A, seed=seed)
+        agents[r].dp = ThreadDP(r, world, shared, Fraction(B, hi - lo))
+        agents[r].noise_source = shard_noise(lo, hi)
 
     def run(r):
         try:
             torch.cuda.set_device(0)
-            lo, hi = halves[r]
+            lo, hi = bounds[r]
             agents[r].update(tuple(x[:, lo:hi].contiguous() for x in batch))
             scal[r] = dict(agents[r].last_scalars)
-        except Exception as e:  # noqa: BLE001
+        except BaseException as e:  # noqa: BLE001
             errs.append(e)
             shared["barrier"].abort()
 
-    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
-        t.join(120)
+        t.join(600)
     assert not errs, errs
     torch.cuda.synchronize()
+    return agents, scal
+
+
+def test_data_parallel_two_shards_equal_full_batch():
+    """Two row shards with sum-all-reduced gradients reproduce the full-batch update (8e)."""
+    L, B, H, A = 8, 6, 5, 6
+    batch, _ = dev_batch(L, B, A, 21)
+    nz, _ = dev_noise(L, B, H, A, 22)
+    full, _ = make_agent("repo", L, B, H, A)
+    full.noise_source = nz
+    full.update(batch)
+    s_full = dict(full.last_scalars)
+    agents, scal = _run_sharded("repo", L, B, H, A, 2, batch, nz)
     for k, w in s_full.items():
         assert abs(scal[0][k] - w) <= 2e-4 * abs(w) + 1e-7, (k, scal[0][k], w)
     assert scal[0] == scal[1]
@@ -303,6 +318,46 @@ def test_data_parallel_two_shards_equal_full_batch():
         log(f"[dp 2 shards] rank {r}: max |param diff| vs full batch after one update: model {e:.2e} actor {ea:.2e}")
         assert e < 2e-5 and ea < 2e-5
     assert torch.equal(agents[0].model_optimizer.flat, agents[1].model_optimizer.flat)  # replicas stay identical
+    assert abs(float(agents[0].log_beta) - float(full.log_beta)) < 1e-6
+
+
+def test_config3_eight_uneven_shards_equal_full_batch_b50():
+    """BASELINE config 3's partition on one GPU: the global batch of 50 sequences (L=50, H=15) dealt
+    7,7,6,6,6,6,6,6 over eight 'ranks' (repo_amd.parallel.shard_rows) with sum-all-reduced flat gradients
+    reproduces the full-batch update: logged scalars, pre-clip gradient norms, parameters, log_beta; the
+    eight replicas stay bit-identical."""
+    from repo_amd.parallel import shard_rows
+
+    L, B, H, A, world = 50, 50, 15, 6, 8
+    assert [b - a for a, b in (shard_rows(B, world, r) for r in range(world))] == [7, 7, 6, 6, 6, 6, 6, 6]
+    batch, _ = dev_batch(L, B, A, 31)
+    nz, _ = dev_noise(L, B, H, A, 32)
+    full, _ = make_agent("repo", L, B, H, A)
+    full.noise_source = nz
+    full.update(batch)
+    s_full = dict(full.last_scalars)
+    n_full = dict(full.last_grad_norms)
+    agents, scal = _run_sharded("repo", L, B, H, A, world, batch, nz)
+    for k, w in s_full.items():
+        r = abs(scal[0][k] - w) / (abs(w) + 1e-12)
+        log(f"[dp C3 8 shards B=50] {k}: sharded {scal[0][k]:.7g} full {w:.7g} rel {r:.2e}")
+        assert r < 1e-4, (k, scal[0][k], w)
+    for k, w in n_full.items():
+        g = agents[0].last_grad_norms[k]
+        log(f"[dp C3 8 shards B=50] grad-norm {k}: sharded {g:.6g} full {w:.6g}")
+        assert abs(g - w) < 1e-4 * w
+    for r in range(1, world):
+        assert scal[r] == scal[0]
+        for name in ("model_optimizer", "actor_optimizer", "value_optimizer"):
+            assert torch.equal(getattr(agents[r], name).flat, getattr(agents[0], name).flat), (r, name)
+        assert float(agents[r].log_beta) == float(agents[0].log_beta)
+    for name in ("model_optimizer", "actor_optimizer", "value_optimizer"):
+        d = (getattr(agents[0], name).flat - getattr(full, name).flat).abs()
+        lr = getattr(full, name).lr
+        frac = (d > 2e-6).float().mean().item()
+        log(f"[dp C3 8 shards B=50] {name}: max |param diff| {d.max().item():.2e}, fraction > 2e-6: {frac:.2e}")
+        # Adam's first step is lr*sign(g)-like: entries whose gradient is within rounding of zero may flip
+        assert d.max().item() <= 2.1 * lr and frac < 5e-3
     assert abs(float(agents[0].log_beta) - float(full.log_beta)) < 1e-6
 
 
@@ -325,3 +380,274 @@ def test_pipelined_updates_bitwise_equal_sequential():
         assert torch.equal(pa, pb), (name, (pa - pb).abs().max().item())
     assert a.last_scalars == b.last_scalars
     assert float(a.log_beta) == float(b.log_beta)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs at full size
+def _full_size_vs_oracle(tag, algo, L, B, H, A, n_updates=1):
+    agent, cfg = make_agent(algo, L, B, H, A)
+    oracle = ro.OracleAgent(cfg, A, seed=7)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    for u in range(n_updates):
+        batch, host = dev_batch(L, B, A, 2468 + u, u8=(u == 0))
+        agent.noise_source, nz = dev_noise(L, B, H, A, 99 + u)
+        agent.update(batch)
+        got = dict(agent.last_scalars)
+        want = oracle.update(*host, nz)[2]
+        for k, w in want.items():
+            r = abs(got[k] - w) / (abs(w) + 1e-12)
+            log(f"[{tag} update {u}] {k}: got {got[k]:.7g} oracle {w:.7g} rel {r:.2e}")
+            assert r < 1e-3, (tag, u, k, got[k], w)
+        assert abs(float(agent.log_beta) - float(oracle.log_beta)) < 1e-5
+        gn, on = agent.last_grad_norms, oracle.last
+        for name in ("model", "actor", "value"):
+            w = on[f"{name}_total_norm"]
+            log(f"[{tag} update {u}] grad-norm {name}: got {gn[name]:.6g} oracle {w:.6g}")
+            assert abs(gn[name] - w) < 2e-3 * w
+    return agent, oracle
+
+
+def test_repo_config2_b50_matches_oracle_scalars():
+    """BASELINE config 2 -- THE headline workload (dmc_distracted-walker-walk shapes: full RePo, B=50, L=50,
+    H=15, A=6): one update against the CPU oracle, every logged loss / KL / beta within 1e-3 relative
+    (north_star), log_beta within 1e-5, pre-clip gradient norms of all three optimisers within 2e-3."""
+    _full_size_vs_oracle("repo C2 B=50", "repo", 50, 50, 15, 6)
+
+
+def test_repo_config4_maniskill_b32_a7_matches_oracle_scalars():
+    """BASELINE config 4's pin (SURVEY.md header table / section 8d): ManiSkill shapes at the reference's
+    own 64x64 frames -- B=32, L=50, H=15, **A=7** (`pd_ee_delta_pose`, environments/__init__.py:93): the odd
+    action size changes three weight shapes and the [state|action] GEMM's K (37).  Two updates vs the oracle."""
+    _full_size_vs_oracle("repo C4 B=32 A=7", "repo", 50, 32, 15, 7, n_updates=2)
+
+
+# ----------------------------------------------------------------------------- checkpoint layout (f3)
+def _describe(v):
+    if isinstance(v, torch.Tensor):
+        return {"type": "tensor", "shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""),
+                "requires_grad": bool(v.requires_grad)}
+    if isinstance(v, bool):
+        return {"type": "bool", "value": v}
+    if isinstance(v, (int, float)):
+        return {"type": type(v).__name__, "value": v}
+    if v is None:
+        return {"type": "none"}
+    if isinstance(v, (tuple, list)):
+        return {"type": type(v).__name__, "value": [_describe(x) for x in v]}
+    raise TypeError(type(v))
+
+
+@pytest.mark.parametrize("algo", ["dreamer", "repo"])
+def test_checkpoint_structure_equals_reference_manifest(golden_dir, algo):
+    """get_param_dict() after one update has the structure the REFERENCE's has (tests/golden/
+    checkpoint_manifest.json, written by gen_golden_host.py from the reference's get_param_dict():
+    dreamer.py:501-520, repo.py:114-118): top-level key order, module key order / shapes / dtypes, and for
+    every optimiser the `state` indices, per-state keys and tensor forms and the `param_groups` entry."""
+    import json
+
+    man = json.load(open(os.path.join(golden_dir, "checkpoint_manifest.json")))[algo]
+    L, B, H, A = 6, 3, 4, 6
+    agent, cfg = make_agent(algo, L, B, H, A)
+    batch, _ = dev_batch(L, B, A, 3)
+    agent.noise_source, _ = dev_noise(L, B, H, A, 5)
+    agent.update(batch)
+    agent.step = 17
+    pd = agent.get_param_dict()
+    assert list(pd.keys()) == man["top_keys"]
+    assert _describe(pd["step"]) == man["step"]
+    same_torch = json.load(open(os.path.join(golden_dir, "checkpoint_manifest.json")))["torch_version"] == torch.__version__
+    for k, v in pd.items():
+        if k == "step":
+            continue
+        m = man[k]
+        if k.endswith("_optimizer"):
+            assert list(v.keys()) == m["top_keys"]
+            assert [int(i) for i in v["state"].keys()] == m["state_index_order"]
+            for i, st in v["state"].items():
+                ms = m["state"][str(i)]
+                assert list(st.keys()) == ms["keys"]
+                for kk, vv in st.items():
+                    assert _describe(vv) == ms["values"][kk], (k, i, kk)
+                    assert vv.device.type == "cuda" or kk == "step"
+            assert len(v["param_groups"]) == len(m["param_groups"]) == 1
+            g, mg = v["param_groups"][0], m["param_groups"][0]
+            assert list(g["params"]) == mg["params"]
+            if same_torch:  # the group's key set is torch-version dependent; it is derived from this install's Adam
+                assert list(g.keys()) == mg["keys"]
+            for kk, d in mg["values"].items():
+                if kk in g:
+                    assert _describe(g[kk]) == d, (k, kk, g[kk], d)
+        elif isinstance(v, torch.Tensor):
+            assert _describe(v) == m, (k, _describe(v), m)
+        else:
+            assert list(v.keys()) == m["keys"], k
+            for kk, vv in v.items():
+                assert _describe(vv) == m["values"][kk], (k, kk)
+
+
+def test_load_reference_format_checkpoint():
+    """A param dict in the REFERENCE's format (built from the manifest: plain state_dicts, torch.optim.Adam
+    state with 0-dim float32 `step`, a requires-grad `log_beta` leaf) loads, and is returned value for value."""
+    A = 6
+    agent, cfg = make_agent("repo", 6, 3, 4, A)
+    rs = np.random.RandomState(5)
+    shapes = fx.param_shapes(A)
+
+    def rnd(shape, pos=False):
+        a = np.asarray(rs.standard_normal(shape), dtype=np.float32) * np.float32(0.1)
+        return torch.from_numpy(np.asarray(np.abs(a) if pos else a, dtype=np.float32).reshape(shape))
+
+    ck = {"step": 4321}
+    for mod in fx.MODULES:
+        ck[mod] = {k: rnd(s) for k, s in shapes[mod].items()}
+
+    def adam_state(tensors, lr):
+        ps = [torch.nn.Parameter(t.clone()) for t in tensors]
+        sd = torch.optim.Adam(ps, lr=lr).state_dict()
+        sd["state"] = {i: {"step": torch.tensor(9.0), "exp_avg": rnd(tuple(t.shape)), "exp_avg_sq": rnd(tuple(t.shape), True)}
+                       for i, t in enumerate(tensors)}
+        return sd
+
+    ck["model_optimizer"] = adam_state([t for m in fx.MODEL_MODULES for t in ck[m].values()], 3e-4)
+    ck["actor_optimizer"] = adam_state(list(ck["actor_model"].values()), 8e-5)
+    ck["value_optimizer"] = adam_state(list(ck["value_model"].values()), 8e-5)
+    ck["log_beta"] = torch.tensor(-7.25, requires_grad=True)
+    ck["beta_optimizer"] = adam_state([ck["log_beta"].detach()], 1e-4)
+    agent.load_param_dict(ck)
+    back = agent.get_param_dict()
+    assert back["step"] == 4321 and float(back["log_beta"]) == -7.25
+    for mod in fx.MODULES:
+        for k, v in ck[mod].items():
+            assert torch.equal(back[mod][k].cpu(), v), (mod, k)
+    for name in ("model_optimizer", "actor_optimizer", "value_optimizer", "beta_optimizer"):
+        for i, st in ck[name]["state"].items():
+            for kk in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(back[name]["state"][i][kk].cpu(), st[kk]), (name, i, kk)
+            assert float(back[name]["state"][i]["step"]) == 9.0
+    # ... and the restored state drives the next update: the step counters continue from 9
+    batch, _ = dev_batch(6, 3, A, 3)
+    agent.update(batch)
+    torch.cuda.synchronize()
+    assert agent.model_optimizer.step_count == 10 and agent.beta_optimizer.step_count == 10
+
+
+# ----------------------------------------------------------------------------- host loops on a fake environment
+class FakeDMC:
+    """Deterministic stand-in for a pixel control suite: frames are a function of (episode, t), the reward
+    of the action; episodes last `horizon` steps; `info` carries a success flag on the last step."""
+
+    def __init__(self, A, horizon, seed):
+        self.observation_space = Env(A).observation_space
+        self.action_space = Env(A).action_space
+        self.action_space.sample = lambda: self.rs.uniform(-1, 1, A).astype(np.float32)
+        self.A, self.horizon, self.rs = A, horizon, np.random.RandomState(seed)
+        self.episode, self.t, self.actions = -1, 0, []
+
+    def _frame(self):
+        return ((np.arange(3 * 64 * 64).reshape(3, 64, 64) * 7 + self.episode * 31 + self.t * 13) % 256).astype(np.uint8)
+
+    def reset(self):
+        self.episode += 1
+        self.t = 0
+        return self._frame()
+
+    def step(self, action):
+        action = np.asarray(action)
+        assert action.shape == (self.A,) and np.all(np.abs(action) <= 1.0)
+        self.actions.append(action.copy())
+        self.t += 1
+        done = self.t == self.horizon
+        return self._frame(), float(action.sum()), done, ({"success": 1} if done else {})
+
+
+class DumpLogger(Logger):
+    def __init__(self):
+        super().__init__()
+        self.dumps, self.history = [], []
+
+    def record(self, k, v, exclude=None):
+        super().record(k, v, exclude)
+        self.history.append((k, exclude))
+
+    def dump(self, step=None):
+        self.dumps.append((step, dict(self.kv)))
+
+
+def test_train_and_eval_loops_on_fake_env(tmp_path):
+    """Dreamer.train() / eval_agent() (reference dreamer.py:403-490) end to end on a fake environment:
+    seed collection stops at an episode boundary, every environment step is stored, the periodic jobs
+    fire on their own periods in the reference's order, the last update's scalars reach the logger before
+    its dump, eval logs return / success / a (2, T, C, H, W) video, and a checkpoint is written."""
+    A, hor = 6, 9
+    agent, cfg = make_agent("repo", 6, 3, 4, A)
+    cfg.replay_size, cfg.prefill, cfg.num_steps = 400, 20, 25
+    cfg.train_every, cfg.train_steps, cfg.eval_every, cfg.checkpoint_every, cfg.log_every = 10, 2, 20, 25, 5
+    cfg.action_noise, cfg.save_buffer = 0.3, True
+    agent.buffer = type(agent.buffer)(cfg.replay_size, (3, 64, 64), (A,), obs_type=np.uint8)
+    agent.buffer.enable_device_mirror(agent.device)
+    env, eval_env = FakeDMC(A, hor, 1), FakeDMC(A, hor, 2)
+    agent.env, agent.eval_env = env, eval_env
+    agent.logger = DumpLogger()
+    agent.logger.dir = str(tmp_path)
+    calls = []
+    for name in ("train_agent", "eval_agent", "save_checkpoint"):
+        orig = getattr(agent, name)
+        setattr(agent, name, (lambda o, n: (lambda: (calls.append((n, agent.step)), o())[1]))(orig, name))
+    agent.train()
+    # seed data: whole episodes only, at least `prefill` transitions
+    n_seed = 27  # 3 episodes of 9 >= 20
+    assert len(agent.buffer) == n_seed + cfg.num_steps and agent.step == cfg.num_steps
+    d = agent.buffer.dones[:len(agent.buffer), 0]
+    assert list(np.nonzero(d)[0]) == [8, 17, 26, 35, 44]           # episode ends, seed + policy phases
+    # the policy's actions were stored next to the frames they were chosen from
+    stored = agent.buffer.actions[n_seed:n_seed + cfg.num_steps]
+    assert np.array_equal(stored, np.stack(env.actions[n_seed:]))
+    assert np.array_equal(agent.buffer.observations[n_seed], FakeDMC._frame(type("E", (), {"episode": 4, "t": 0})()))
+    # periodic jobs: order within a step and their periods
+    assert calls == [("train_agent", 0), ("eval_agent", 0), ("save_checkpoint", 0), ("train_agent", 10),
+                     ("train_agent", 20), ("eval_agent", 20)]
+    assert [s for s, _ in agent.logger.dumps] == [0, 5, 10, 15, 20]
+    assert agent.model_optimizer.step_count == 3 * cfg.train_steps
+    first = agent.logger.dumps[0][1]
+    assert "train/model_loss" in first and math.isfinite(first["train/model_loss"])   # flushed before the dump
+    assert first["train/step"] == 0
+    assert "train/return" in agent.logger.dumps[2][1] and agent.logger.dumps[2][1]["train/success"] == 1.0
+    # evaluation: deterministic policy, one episode, video of (observed, reconstructed) frames
+    kv = agent.logger.kv
+    assert "test/return" in kv and kv["test/success"] == 1.0
+    vid = kv["test/video"]
+    assert vid.fps == 30 and vid.frames.shape == (2, hor, 3, 64, 64) and vid.frames.dtype == np.uint8
+    assert ("test/video", "stdout") in agent.logger.history
+    assert len(eval_env.actions) == 2 * hor
+    assert np.array_equal(vid.frames[0, 0], FakeDMC._frame(type("E", (), {"episode": 1, "t": 0})()))
+    # checkpoint + buffer on disk, loadable
+    assert os.path.exists(os.path.join(str(tmp_path), "models.pt")) and os.path.exists(os.path.join(str(tmp_path), "buffer.npz"))
+    agent2, cfg2 = make_agent("repo", 6, 3, 4, A, seed=9)
+    agent2.logger.dir = str(tmp_path)
+    agent2.buffer = type(agent.buffer)(cfg.replay_size, (3, 64, 64), (A,), obs_type=np.uint8)
+    agent2.load_checkpoint()
+    assert agent2.step == 0 and len(agent2.buffer) == n_seed + 1     # written at step 0, after that step's push
+
+
+def test_load_offline_data_through_agent(tmp_path):
+    """load_checkpoint() falls back to load_offline_data() when no buffer.npz exists and load_offline is set
+    (dreamer.py:522-535); the adopted ring feeds train_agent()."""
+    A = 6
+    agent, cfg = make_agent("repo", 6, 3, 4, A)
+    src = type(agent.buffer)(40, (3, 64, 64), (A,), obs_type=np.uint8)
+    rs = np.random.RandomState(3)
+    for i in range(55):
+        src.push(rs.randint(0, 256, (3, 64, 64)).astype(np.uint8), rs.uniform(-1, 1, A), rs.uniform(), i % 11 == 10)
+    off = tmp_path / "offline"
+    off.mkdir()
+    src.save(str(off / "buffer_0.npz"))
+    cfg.load_offline, cfg.offline_dir, cfg.offline_truncate_size = True, str(off), 30
+    agent.logger.dir = str(tmp_path)
+    agent.load_checkpoint()
+    b = agent.buffer
+    assert (b.capacity, b.pos, b.full, len(b)) == (30, 0, True, 30) and b.dones[-1, 0] == 1
+    chrono = np.concatenate((src.observations[src.pos:], src.observations[:src.pos]))[:30]
+    assert np.array_equal(b.observations, chrono)
+    cfg.train_steps = 2
+    agent.train_agent()
+    torch.cuda.synchronize()
+    assert agent.model_optimizer.step_count == 2 and all(math.isfinite(v) for v in agent.last_scalars.values())

@@ -259,3 +259,15 @@ def test_no_uninitialised_lds(ops):
         poison()
         r2 = ops.gemm_wgrad(dy, A)
         assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+
+
+def test_device_check_and_arch_guard():
+    """repo_device_check: the MI355X passes, an ordinal that does not exist is a bad argument; every entry
+    point runs the same (cached) check before launching (REPO_E_ARCH on anything that is not gfx950)."""
+    from repo_amd._lib import lib
+
+    L = lib()
+    assert L.repo_device_check(0) == 0
+    assert L.repo_device_check(torch.cuda.device_count()) == -1  # REPO_E_BADARG
+    assert L.repo_strerror(-5).decode() == "device is not gfx950"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
