@@ -21,6 +21,7 @@
 
 #include "igemm.h"
 #include "dconv.h"
+#include "uconv.h"
 
 namespace repo {
 
@@ -50,19 +51,6 @@ __device__ __forceinline__ float epi_apply(float v, int epi, const float* bias, 
 // Compile-time k -> address-offset tables (one per geometry), read with scalar loads: inside the K
 // loop k is wave-uniform for the n-major operands, so the (channel, ky, kx) decode -- ~10 scalar ALU
 // instructions per element when done with div/mod by constants -- becomes one s_load per element.
-template <class G>
-struct DownKTab {
-  int v[G::CB * G::KK];
-  constexpr DownKTab() : v() {
-    for (int k = 0; k < G::CB * G::KK; ++k) {
-      const int cb = k / G::KK, r = k % G::KK;
-      v[k] = cb * G::PB + (r / G::KS) * G::WB + r % G::KS;
-    }
-  }
-};
-template <class G>
-__device__ const DownKTab<G> g_down_ktab{};
-
 template <class G, int JY, int JX>
 struct UpKTab {
   int off[G::CS * JY * JX];
@@ -80,120 +68,6 @@ template <class G, int JY, int JX>
 __device__ const UpKTab<G, JY, JX> g_up_ktab{};
 
 // ------------------------------------------------------------------------------- down
-template <class G, class BigT>
-struct ConvDownOp {
-  static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
-  const BigT* big;
-  const float* w;
-  const float* bias;
-  const float* aux;
-  float* out;
-  int nimg, epi;
-  typedef int AM;
-  typedef int AK;
-  typedef int BN;
-  typedef int BK;
-  __device__ void init(int) {}
-  __device__ int M() const { return G::CS; }
-  __device__ int N() const { return nimg * G::PS; }
-  __device__ int kbeg() const { return 0; }
-  __device__ int kend() const { return G::CB * G::KK; }
-  __device__ AM a_m(int m) const { return m * (G::CB * G::KK); }
-  __device__ AK a_k(int k) const { return k; }
-  __device__ float a(const AM& m, const AK& k) const { return w[(unsigned)(m + k)]; }
-  // big[img][cb][2sy+ky][2sx+kx] = big[ nOff(img,sy,sx) + kOff(cb,ky,kx) ]
-  __device__ BN b_n(int n) const {
-    const int img = n / G::PS, p = n % G::PS;
-    return (img * G::CB * G::HB + 2 * (p / G::WS)) * G::WB + 2 * (p % G::WS);
-  }
-  __device__ BK b_k(int k) const { return g_down_ktab<G>.v[k]; }
-  __device__ float b(const BK& k, const BN& n) const { return load_as_float(big, (unsigned)(n + k)); }
-  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
-    const int img = n / G::PS, p = n % G::PS;
-    const int o0 = (img * G::CS + mb) * G::PS + p;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dm = (r & 3) + 8 * (r >> 2);
-      if (mb + dm < M) {
-        const int o = o0 + dm * G::PS;
-        out[o] = epi_apply(acc[r], epi, bias, mb + dm, aux, o);
-      }
-    }
-  }
-  __device__ void finish() {}
-};
-
-// ------------------------------------------------------------------------------- up (one parity class)
-template <class G, int PY, int PX>
-struct ConvUpOp {
-  static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
-  static constexpr int NY = (G::HB - PY + 1) / 2, NX = (G::WB - PX + 1) / 2;
-  static constexpr int JY = (G::KS - PY + 1) / 2, JX = (G::KS - PX + 1) / 2;
-  static constexpr int JJ = JY * JX;
-  const float* small;
-  const float* w;
-  const float* bias;
-  const float* aux;
-  float* out;
-  int nimg, epi;
-  typedef int AM;
-  typedef int AK;
-  struct BN {
-    int off;
-    unsigned mask;  // bits 0..3: tap jy in range for this y; bits 4..7: tap jx in range for this x
-  };
-  struct BK {
-    int off;
-    int sh;  // jy | (4 + jx) << 8
-  };
-  __device__ void init(int) {}
-  __device__ int M() const { return G::CB; }
-  __device__ int N() const { return nimg * NY * NX; }
-  __device__ int kbeg() const { return 0; }
-  __device__ int kend() const { return G::CS * JJ; }
-  // w[cs][cb][PY+2jy][PX+2jx] = w[ m*KK + kOff(cs,jy,jx) ]
-  __device__ AM a_m(int m) const { return m * G::KK; }
-  __device__ AK a_k(int k) const {
-    const int cs = k / JJ, r = k % JJ;
-    return cs * (G::CB * G::KK) + (PY + 2 * (r / JX)) * G::KS + PX + 2 * (r % JX);
-  }
-  __device__ float a(const AM& m, const AK& k) const { return w[(unsigned)(m + k)]; }
-  // small[img][cs][y-jy][x-jx] = small[ nOff(img,y,x) + kOff(cs,jy,jx) ] where the tap exists
-  __device__ BN b_n(int n) const {
-    const int img = n / (NY * NX), q = n % (NY * NX);
-    const int y = q / NX, x = q % NX;
-    unsigned mask = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      mask |= ((y - j >= 0 && y - j < G::HS) ? 1u : 0u) << j;
-      mask |= ((x - j >= 0 && x - j < G::WS) ? 1u : 0u) << (4 + j);
-    }
-    return BN{(img * G::CS * G::HS + y) * G::WS + x, mask};
-  }
-  __device__ BK b_k(int k) const { return BK{g_up_ktab<G, JY, JX>.off[k], g_up_ktab<G, JY, JX>.sh[k]}; }
-  __device__ float b(const BK& k, const BN& n) const {
-    const bool ok = ((n.mask >> (k.sh & 0xff)) & (n.mask >> (k.sh >> 8)) & 1u) != 0;
-    const float v = small[(unsigned)(ok ? n.off + k.off : 0)];
-    return ok ? v : 0.f;
-  }
-  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
-    const int img = n / (NY * NX), q = n % (NY * NX);
-    const int y = q / NX, x = q % NX;
-    const int o0 = ((img * G::CB + mb) * G::HB + 2 * y + PY) * G::WB + 2 * x + PX;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dm = (r & 3) + 8 * (r >> 2);
-      if (mb + dm < M) {
-        const int o = o0 + dm * G::PB;
-        out[o] = epi_apply(acc[r], epi, bias, mb + dm, aux, o);
-      }
-    }
-  }
-  __device__ void finish() {}
-};
-
-// ------------------------------------------------------------------------------- up, classes merged on M
-// MODE 0: plain epilogue (bias / relu / mask).  MODE 1: pixel-likelihood epilogue.
 template <class G, class TgtT, int MODE>
 struct ConvUpMergedOp {
   static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
@@ -325,60 +199,6 @@ struct ConvUpMergedOp {
 };
 
 // ------------------------------------------------------------------------------- wgrad
-template <class G, class BigT>
-struct ConvWgradOp {
-  static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
-  static constexpr int NW = G::CB * G::KK;
-  const float* small;
-  const BigT* big;
-  float* slab;  // [splits][CS][NW+1]
-  int nimg, imgs_per_split;
-  int z, kb, ke;
-  __device__ void init(int zz) {
-    z = zz;
-    kb = zz * imgs_per_split * G::PS;
-    ke = min(nimg * G::PS, kb + imgs_per_split * G::PS);
-  }
-  typedef int AM;
-  typedef int AK;
-  struct BN {
-    int off;
-    bool one;
-  };
-  typedef int BK;
-  __device__ int M() const { return G::CS; }
-  __device__ int N() const { return NW + 1; }
-  __device__ int kbeg() const { return kb; }
-  __device__ int kend() const { return ke; }
-  // small[img][m][p] = small[ m*PS + kOff(img,p) ]
-  __device__ AM a_m(int m) const { return m * G::PS; }
-  __device__ AK a_k(int k) const { return (k / G::PS) * (G::CS * G::PS) + k % G::PS; }
-  __device__ float a(const AM& m, const AK& k) const { return small[(unsigned)(m + k)]; }
-  // big[img][cb][2sy+ky][2sx+kx] = big[ kOff(img,sy,sx) + nOff(cb,ky,kx) ]
-  __device__ BN b_n(int n) const {
-    const int nc = min(n, NW - 1);
-    const int cb = nc / G::KK, r = nc % G::KK;
-    return BN{cb * G::PB + (r / G::KS) * G::WB + r % G::KS, n == NW};
-  }
-  __device__ BK b_k(int k) const {
-    const int img = k / G::PS, p = k % G::PS;
-    return (img * G::CB * G::HB + 2 * (p / G::WS)) * G::WB + 2 * (p % G::WS);
-  }
-  __device__ float b(const BK& k, const BN& n) const {
-    const float v = load_as_float(big, (unsigned)(k + n.off));
-    return n.one ? 1.f : v;
-  }
-  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
-    float* c = slab + ((size_t)z * G::CS + mb) * (NW + 1) + n;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dm = (r & 3) + 8 * (r >> 2);
-      if (mb + dm < M) c[dm * (NW + 1)] = acc[r];
-    }
-  }
-  __device__ void finish() {}
-};
-
 __global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, int splits, int Mrows, int Ncols,
                                         float* __restrict__ dw, float* __restrict__ db, int accumulate) {
   const int total = Mrows * (Ncols + 1);
@@ -486,17 +306,6 @@ __global__ void relu_mask_kernel(int64_t n, const float* __restrict__ dy, const 
 }
 
 // ------------------------------------------------------------------------------- host-side dispatch
-template <class G>
-struct TileFor {
-  // M = channels on the tile's M; pick BM to match, BN to keep ~>=512 workgroups
-  using Down = typename std::conditional<(G::CS <= 32), T32x256,
-                                         typename std::conditional<(G::CS <= 64), T64x128, T128x128>::type>::type;
-  using Up = typename std::conditional<(G::CB <= 32), T32x256,
-                                       typename std::conditional<(G::CB <= 64), T64x128, T128x128>::type>::type;
-  // measured: 64x64 tiles beat 64x128 / 128x128 for the split-K weight gradients (occupancy)
-  using Wgrad = typename std::conditional<(G::CS <= 32), T32x128, T64x64>::type;
-};
-
 // direct-conv tiles per layer: <BM, BN, CK, WM, WN>
 template <class G>
 struct DTileFor;
@@ -521,73 +330,43 @@ template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
                        const float* aux, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
-  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
-  if (!old_engine) {
-    DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
-               (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
-    if (nimg * (int64_t)G::PS <= 512) return launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s);
-    return launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
-  }
-  ConvDownOp<G, BigT> op{big, w, bias, aux, small, (int)nimg, epi};
-  return launch_igemm<typename TileFor<G>::Down>(op, G::CS, nimg * G::PS, 1, s);
+  DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
+             (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
+  if (nimg * (int64_t)G::PS <= 512) return launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s);
+  return launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
 }
 
-template <class G, int PY, int PX>
-static int conv_up_class(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
-                         const float* aux, hipStream_t s) {
-  using Op = ConvUpOp<G, PY, PX>;
-  Op op{small, w, bias, aux, big, (int)nimg, epi};
-  return launch_igemm<typename TileFor<G>::Up>(op, G::CB, nimg * (int64_t)Op::NY * Op::NX, 1, s);
+// Scatter-form configuration per geometry: images per workgroup, resident N tiles, weight prefetch.
+template <class G> struct UConf { using type = void; };
+template <> struct UConf<GDec3> { using type = SConf<GDec3, 1, 6>; };
+template <> struct UConf<GEnc2> { using type = SConf<GEnc2, 1, 8>; };
+template <> struct UConf<GDec2> { using type = SConf<GDec2, 5, 2>; };
+template <> struct UConf<GEnc3> { using type = SConf<GEnc3, 4, 2>; };
+template <> struct UConf<GEnc4> { using type = SConf<GEnc4, 8, 1>; };
+
+template <class G>
+static size_t conv_up_ws_bytes() {
+  using C = typename UConf<G>::type;
+  if constexpr (std::is_void<C>::value) return 0;
+  else return C::PACK_FLOATS * sizeof(float);
 }
 
 template <class G>
 static int conv_up_t(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
-                     const float* aux, hipStream_t s) {
+                     const float* aux, void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
-  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
-  if constexpr (G::CB % 32 == 0) {
-    if (!old_engine) {
-      UpArgs a{small, w, bias, aux, big, (int)nimg, epi, (unsigned)(nimg * G::CS * G::PS * sizeof(float)),
-               (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
-      static const int ut = getenv("REPO_UP_TILE") ? atoi(getenv("REPO_UP_TILE")) : 0;  // experiments only
-      if (ut == 1) return launch_dconv_up<G, UTile<256, 2>>(a, s);
-      if (ut == 2) return launch_dconv_up<G, UTile<128, 4>>(a, s);
-      if (ut == 3) return launch_dconv_up<G, UTile<256, 4>>(a, s);
-      return launch_dconv_up<G, UTile<128, 2>>(a, s);
-    }
-  }
-  // All four output parity classes read the same (J x J) input taps, so for even kernels
-  // (no zero taps) they are merged on M: one pass over `small`, 4x fewer operand loads per
-  // MFMA and the four interleaved output pixels are written by the same workgroup.
-  if (G::CB < 8 || G::KS % 2 == 0) {
+  using UC = typename UConf<G>::type;
+  if constexpr (!std::is_void<UC>::value) {
+    return launch_uconv_scatter<G, UC>(small, w, bias, aux, big, nimg, epi, ws, ws_bytes, s);
+  } else {
+    // 3-channel outputs (encoder conv1 data-gradient, plain decoder conv4): the four output parity classes read
+    // the same (J x J) input taps, so they are merged on M (4 * 3 rows) in the gather engine of igemm.h
+    static_assert(G::CB < 8 && G::KS % 2 == 0, "only the 3-channel layers use the gather engine");
     ConvUpMergedOp<G, float, 0> op{small, w, bias, aux, big, (int)nimg, epi, nullptr, nullptr, nullptr, 0.f, 0.f};
-    using TM_ = typename std::conditional<(4 * G::CB <= 32), T32x256, T128x128>::type;
-    return launch_igemm<TM_>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
+    return launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
   }
-  int rc;
-  if ((rc = conv_up_class<G, 0, 0>(nimg, small, w, bias, big, epi, aux, s))) return rc;
-  if ((rc = conv_up_class<G, 0, 1>(nimg, small, w, bias, big, epi, aux, s))) return rc;
-  if ((rc = conv_up_class<G, 1, 0>(nimg, small, w, bias, big, epi, aux, s))) return rc;
-  return conv_up_class<G, 1, 1>(nimg, small, w, bias, big, epi, aux, s);
 }
 
-template <class G>
-static int conv_wgrad_splits(int64_t nimg) {
-  using T = typename TileFor<G>::Wgrad;
-  const long tiles = ((G::CS + T::BM - 1) / T::BM) * ((G::CB * G::KK + 1 + T::BN - 1) / T::BN);
-  long want = (768 + tiles - 1) / tiles;
-  // keep >= ~256 reduction elements per split
-  long min_imgs = (256 + G::PS - 1) / G::PS;
-  long maxs = (nimg + min_imgs - 1) / min_imgs;
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
-  if (want > 2048) want = 2048;
-  // round so that splits * imgs_per_split covers nimg with no empty tail beyond one
-  long ips = (nimg + want - 1) / want;
-  return (int)((nimg + ips - 1) / ips);
-}
-
-// direct wgrad: images per split (a multiple of the chunk's image group) for ~1500 workgroups
 template <class G>
 static int dwgrad_ips(int64_t nimg) {
   using T = typename DTileFor<G>::Wgrad;
@@ -606,8 +385,7 @@ static int dwgrad_splits(int64_t nimg) {
 }
 template <class G>
 static size_t wgrad_ws_bytes(int64_t nimg) {
-  const long sp = conv_wgrad_splits<G>(nimg) > dwgrad_splits<G>(nimg) ? conv_wgrad_splits<G>(nimg) : dwgrad_splits<G>(nimg);
-  return (size_t)sp * G::CS * (G::CB * G::KK + 1) * sizeof(float);
+  return (size_t)dwgrad_splits<G>(nimg) * G::CS * (G::CB * G::KK + 1) * sizeof(float);
 }
 
 static void launch_conv_slab_reduce(const float* ws, int splits, int cs, int nw, float* dw, float* db, int accumulate,
@@ -627,31 +405,12 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
                         void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   if (!ws || ws_bytes < wgrad_ws_bytes<G>(nimg)) return REPO_E_WS_TOO_SMALL;
-  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
-  if (!old_engine) {
-    const int dips = dwgrad_ips<G>(nimg), dsplits = dwgrad_splits<G>(nimg);
-    WgradArgs a{small, big, (float*)ws, (int)nimg, dips, db != nullptr,
-                (unsigned)(nimg * G::CS * G::PS * sizeof(float)), (unsigned)(nimg * G::CB * G::PB * sizeof(BigT))};
-    int rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
-    if (rc) return rc;
-    launch_conv_slab_reduce((const float*)ws, dsplits, G::CS, G::CB * G::KK, dw, db, accumulate, s);
-    REPO_CHECK_LAUNCH();
-    return REPO_OK;
-  }
-  const int splits = conv_wgrad_splits<G>(nimg);
-  const int ips = (int)((nimg + splits - 1) / splits);
-  ConvWgradOp<G, BigT> op{small, big, (float*)ws, (int)nimg, ips, 0, 0, 0};
-  int rc = launch_igemm<typename TileFor<G>::Wgrad>(op, G::CS, G::CB * G::KK + 1, splits, s);
+  const int dips = dwgrad_ips<G>(nimg), dsplits = dwgrad_splits<G>(nimg);
+  WgradArgs a{small, big, (float*)ws, (int)nimg, dips, db != nullptr,
+              (unsigned)(nimg * G::CS * G::PS * sizeof(float)), (unsigned)(nimg * G::CB * G::PB * sizeof(BigT))};
+  int rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
   if (rc) return rc;
-  const int total = G::CS * (G::CB * G::KK + 1);
-  if (splits >= 64 && total <= 65536) {
-    hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(total, 4)), dim3(256), 0, s, (const float*)ws, splits,
-                       G::CS, G::CB * G::KK, dw, db, accumulate);
-  } else {
-    const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
-    hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, splits, G::CS,
-                       G::CB * G::KK, dw, db, accumulate);
-  }
+  launch_conv_slab_reduce((const float*)ws, dsplits, G::CS, G::CB * G::KK, dw, db, accumulate, s);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }
@@ -686,14 +445,18 @@ extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_
   REPO_LAYER_SWITCH(layer, return (conv_down_t<G, float>(nimg, (const float*)big, w, bias, small, epi, aux, stream)))
 }
 
+extern "C" size_t repo_conv_up_workspace_bytes(int layer) {
+  REPO_LAYER_SWITCH(layer, return (conv_up_ws_bytes<G>()))
+}
+
 extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
-                            float* big, int epi, const float* aux, hipStream_t stream) {
+                            float* big, int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(small && w && big, REPO_E_BADARG);
   REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU || (epi == REPO_EPI_MUL_DRELU && aux), REPO_E_BADARG);
-  REPO_LAYER_SWITCH(layer, return (conv_up_t<G>(nimg, small, w, bias, big, epi, aux, stream)))
+  REPO_LAYER_SWITCH(layer, return (conv_up_t<G>(nimg, small, w, bias, big, epi, aux, ws, ws_bytes, stream)))
 }
 
 extern "C" size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg) {
@@ -716,15 +479,8 @@ extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, cons
                                                           accumulate, ws, ws_bytes, stream)))
 }
 
-static inline long nll_blocks(int64_t nimg) {
-  using Op = ConvUpMergedOp<GDec4, float, 1>;
-  const long N = nimg * (long)Op::NY * Op::NX;
-  const long old_blocks = (N + T32x256::BN - 1) / T32x256::BN;
-  return old_blocks > 1024 ? old_blocks : 1024;
-}
-
 extern "C" size_t repo_decoder_out_nll_workspace_bytes(int64_t nimg) {
-  return nimg <= 0 ? 0 : (size_t)nll_blocks(nimg) * sizeof(float);
+  return nimg <= 0 ? 0 : (size_t)dec4_nll_grid(nimg) * sizeof(float);
 }
 
 template <class TgtT>
@@ -732,20 +488,11 @@ static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, cons
                              float grad_scale, float* recon, float* dpre, float* loss_sum, void* ws,
                              hipStream_t stream) {
   using G = GDec4;
-  static const bool old_engine = getenv("REPO_CONV_OLD") != nullptr;  // experiments only
-  int nparts;
-  if (!old_engine) {
-    nparts = dec4_nll_grid(nimg);
-    NllArgs a{h3, w, bias, target, recon, dpre, (float*)ws, grad_scale, (int)nimg,
-              (unsigned)(nimg * G::CS * G::PS * sizeof(float))};
-    hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
-    REPO_CHECK_LAUNCH();
-  } else {
-    ConvUpMergedOp<G, TgtT, 1> op{h3, w, bias, nullptr, recon, (int)nimg, 0, target, dpre, (float*)ws, grad_scale, 0.f};
-    int rc = launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, stream);
-    if (rc) return rc;
-    nparts = (int)((nimg * (long)op.NY * op.NX + T32x256::BN - 1) / T32x256::BN);
-  }
+  const int nparts = dec4_nll_grid(nimg);
+  NllArgs a{h3, w, bias, target, recon, dpre, (float*)ws, grad_scale, (int)nimg,
+            (unsigned)(nimg * G::CS * G::PS * sizeof(float))};
+  hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
+  REPO_CHECK_LAUNCH();
   if (loss_sum) {
     hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)ws, nparts,
                        loss_sum, 0);

@@ -287,241 +287,6 @@ inline int launch_dconv_down(const DownArgs& a, hipStream_t s) {
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
-// ------------------------------------------------------------------------------------------- up
-//   big[img][cb][2cy+py][2cx+px] = sum_{cs,ty,tx} small[img][cs][cy-ty][cx-tx] w[cs][cb][py+2ty][px+2tx]
-// All four output parity classes (py,px) read the SAME input pixels (cy-ty, cx-tx), so one wave owns
-// the four classes of a 32-channel block for its pixels: a B (pixel) fragment read from the patch
-// feeds four MFMAs, one per class, whose A fragments are the class's taps of the weight chunk.
-//   * patch: whole small planes of the images the tile touches, re-pitched into LDS with a zero halo of
-//     J-1 rows/columns before and (class grid - plane) after, so taps that fall off the input read 0.0
-//     and the K loop has no masks.  The halo is zeroed once; the per-chunk copies never touch it.
-//   * weights: for a chunk of CK input channels the block's 32*KK floats per channel are contiguous in
-//     w[cs][cb][ky][kx]; they are copied whole (all taps, 16-byte loads) into Wl[(c,ky,kx)][cb].
-//   * K order is (tap, channel pair): the two k of an MFMA step are channels 2cp and 2cp+1 of the same
-//     tap, so both operand addresses are lane_base(+lh*const) + compile-time offset.
-//   * odd KS: classes have 3 or 2 taps per dimension; a missing tap is skipped at compile time.
-struct UpArgs {
-  const float* small;
-  const float* w;
-  const float* bias;
-  const float* aux;
-  float* out;
-  int nimg, epi;
-  unsigned small_bytes, w_bytes;
-};
-
-template <int BN_, int CK_>
-struct UTile {
-  static constexpr int BN = BN_, CK = CK_, TN = BN_ / 128, NT = 256;
-  static_assert(BN_ % 128 == 0 && CK_ % 2 == 0, "four waves along N; channel pairs per MFMA step");
-};
-
-template <class G, class T>
-__global__ __launch_bounds__(256) void dconv_up_kernel(UpArgs p) {
-  constexpr int BN = T::BN, CK = T::CK, TN = T::TN, NT = 256;
-  constexpr int J = (G::KS + 1) / 2;
-  constexpr int NYM = (G::HB + 1) / 2, NXM = (G::WB + 1) / 2, PC = NYM * NXM;  // class grid (uniform)
-  constexpr int P = NXM + J - 1, R = NYM + J - 1;  // LDS plane: R rows of pitch P, origin (iy,ix) = (-(J-1), -(J-1))
-  constexpr int RP = (R * P + 3) & ~3;
-  constexpr int NIMG_MAX = (BN - 1) / PC + 2;
-  constexpr int PLMAX = NIMG_MAX * RP;
-  constexpr int PSV = (G::PS + 3) / 4;  // vectors per small plane
-  constexpr int NSL = G::CS / CK;
-  static_assert(G::CS % CK == 0 && G::CB % 32 == 0, "channel chunking");
-  constexpr int LDW = 34;
-  constexpr int WROWS = CK * G::KK;
-  constexpr int W_NV = CK * 8 * G::KK, W_PER = (W_NV + NT - 1) / NT;            // 32*KK/4 vectors per channel
-  constexpr int P_NV = CK * NIMG_MAX * PSV, P_PER = (P_NV + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) float lds[2 * WROWS * LDW + 2 * CK * PLMAX];
-  float* Wl = lds;
-  float* Pl = lds + 2 * WROWS * LDW;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lh = lane >> 5;
-
-  const int Ntot = p.nimg * PC;
-  const int n0 = xcd_tile(blockIdx.x, gridDim.x) * BN, cb0 = blockIdx.y * 32;
-  const int nlast = min(n0 + BN, Ntot) - 1;
-  const int ia = n0 / PC, ib = nlast / PC;
-
-  const __amdgpu_buffer_rsrc_t rsm = make_rsrc(p.small, p.small_bytes), rw = make_rsrc(p.w, p.w_bytes);
-
-  // zero both patch buffers once (halo + everything else; the copies overwrite the interior)
-  for (int i = tid; i < 2 * CK * PLMAX / 4; i += NT) reinterpret_cast<f32x4*>(Pl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- staging roles (LDS element addresses hoisted: 4 per vector, -1 = do not write)
-  unsigned woff[W_PER];
-  short wlds[W_PER][4];
-#pragma unroll
-  for (int j = 0; j < W_PER; ++j) {
-    const int v = tid + j * NT, c = v / (8 * G::KK), e4 = v % (8 * G::KK);
-    const bool act = (W_NV % NT == 0) || v < W_NV;
-    woff[j] = act ? 4u * (unsigned)((c * G::CB + cb0) * G::KK + e4 * 4) : kOobOffset;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int q = e4 * 4 + e;
-      wlds[j][e] = act ? (short)((c * G::KK + q % G::KK) * LDW + q / G::KK) : (short)-1;
-    }
-  }
-  unsigned poff[P_PER];
-  int plds[P_PER][4];
-#pragma unroll
-  for (int j = 0; j < P_PER; ++j) {
-    const int v = tid + j * NT, c = v / (NIMG_MAX * PSV), rem = v % (NIMG_MAX * PSV);
-    const int irel = rem / PSV, e4 = rem % PSV;
-    const bool act = c < CK && ia + irel <= ib;
-    poff[j] = act ? 4u * (unsigned)(((ia + irel) * G::CS + c) * G::PS + e4 * 4) : kOobOffset;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int q = e4 * 4 + e;
-      plds[j][e] = (act && q < G::PS) ? c * PLMAX + irel * RP + (q / G::WS + J - 1) * P + (J - 1) + q % G::WS : -1;
-    }
-  }
-  constexpr unsigned W_STEP = 4u * CK * G::CB * G::KK, P_STEP = 4u * CK * G::PS;
-
-  // ---- per-lane fragment bases
-  int bbase[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = min(n0 + (wn * TN + j) * 32 + li, Ntot - 1);
-    const int q = n % PC;
-    bbase[j] = lh * PLMAX + (n / PC - ia) * RP + (q / NXM) * P + q % NXM;
-  }
-  const int abase = lh * G::KK * LDW + li;
-
-  f32x16 acc[4][TN];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  f32x4 rwv[W_PER], rpv[P_PER];
-  auto gload = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < W_PER; ++j)
-      rwv[j] = VecLoad<4>::load(rw, woff[j] == kOobOffset ? kOobOffset : woff[j] + (unsigned)t * W_STEP);
-#pragma unroll
-    for (int j = 0; j < P_PER; ++j)
-      rpv[j] = VecLoad<4>::load(rsm, poff[j] == kOobOffset ? kOobOffset : poff[j] + (unsigned)t * P_STEP);
-  };
-  auto lstore = [&](int buf) __attribute__((always_inline)) {
-    float* wl = Wl + buf * WROWS * LDW;
-    float* pl = Pl + buf * CK * PLMAX;
-#pragma unroll
-    for (int j = 0; j < W_PER; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if ((W_NV % NT == 0) || wlds[j][e] >= 0) wl[wlds[j][e]] = rwv[j][e];
-#pragma unroll
-    for (int j = 0; j < P_PER; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (plds[j][e] >= 0) pl[plds[j][e]] = rpv[j][e];
-  };
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const float* wl = Wl + buf * WROWS * LDW + abase;
-    const float* pl = Pl + buf * CK * PLMAX;
-#pragma unroll
-    for (int cp = 0; cp < CK / 2; ++cp)
-#pragma unroll
-      for (int ty_ = 0; ty_ < J; ++ty_)
-#pragma unroll
-        for (int tx_ = 0; tx_ < J; ++tx_) {
-          // LDS row offset ty_ / column offset tx_ from the lane base <-> taps ty = J-1-ty_, tx = J-1-tx_
-          float bv[TN];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bv[j] = pl[bbase[j] + 2 * cp * PLMAX + ty_ * P + tx_];
-#pragma unroll
-          for (int cls = 0; cls < 4; ++cls) {
-            const int ky = (cls >> 1) + 2 * (J - 1 - ty_), kx = (cls & 1) + 2 * (J - 1 - tx_);
-            if (ky < G::KS && kx < G::KS) {
-              const float av = wl[(2 * cp * G::KK + ky * G::KS + kx) * LDW];
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[cls][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[cls][j], 0, 0, 0);
-            }
-          }
-        }
-  };
-
-  REPO_STAMP_DECL
-  gload(0);
-  __syncthreads();  // zero fill complete before the first interior writes
-  lstore(0);
-  __syncthreads();
-  REPO_STAMP(5);
-  int buf = 0;
-  for (int t = 0; t < NSL; ++t) {
-    gload(min(t + 1, NSL - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    REPO_STAMP(0);
-    compute(buf);
-    __builtin_amdgcn_sched_barrier(0);
-    REPO_STAMP(1);
-    lstore(buf ^ 1);
-    REPO_STAMP(2);
-    __syncthreads();
-    REPO_STAMP(3);
-    buf ^= 1;
-  }
-
-  // ---- epilogue: the px = 0 / px = 1 classes of a pixel are horizontally adjacent outputs -> 8-byte stores
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + li;
-    if (n < Ntot) {
-      const int img = n / PC, q = n % PC;
-      const int cy = q / NXM, cx = q % NXM;
-      const int x = 2 * cx;
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        const int y = 2 * cy + py;
-        if (y < G::HB && x < G::WB) {
-          const bool two = x + 1 < G::WB;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int cb = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int o = ((img * G::CB + cb) * G::HB + y) * G::WB + x;
-            float v0 = acc[2 * py][j][r], v1 = acc[2 * py + 1][j][r];
-            if (p.bias) {
-              const float bv = p.bias[cb];
-              v0 += bv;
-              v1 += bv;
-            }
-            if (p.epi == REPO_EPI_RELU) {
-              v0 = fmaxf(v0, 0.f);
-              v1 = fmaxf(v1, 0.f);
-            } else if (p.epi == REPO_EPI_MUL_DRELU) {
-              v0 = p.aux[o] > 0.f ? v0 : 0.f;
-              if (two) v1 = p.aux[o + 1] > 0.f ? v1 : 0.f;
-            }
-            if (G::WB % 2 == 0) {
-              *reinterpret_cast<float2*>(p.out + o) = make_float2(v0, v1);
-            } else {
-              p.out[o] = v0;
-              if (two) p.out[o + 1] = v1;
-            }
-          }
-        }
-      }
-    }
-  }
-  REPO_STAMP_FLUSH(NSL);
-}
-
-template <class G, class T>
-inline int launch_dconv_up(const UpArgs& a, hipStream_t s) {
-  constexpr int PC = ((G::HB + 1) / 2) * ((G::WB + 1) / 2);
-  const long gx = ((long)a.nimg * PC + T::BN - 1) / T::BN;
-  hipLaunchKernelGGL((dconv_up_kernel<G, T>), dim3((unsigned)gx, G::CB / 32), dim3(256), 0, s, a);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? REPO_OK : (int)e;
-}
-
 // ---------------------------------------------------------------------------------------- wgrad
 //   dw[cs][cb][ky][kx] = sum_{img,sy,sx} small[img][cs][sy][sx] * big[img][cb][2sy+ky][2sx+kx]
 //   M = cs (A = small), N = (cb,ky,kx) (B = big), K = (img, sy, sx), split over image groups into slabs

@@ -155,15 +155,6 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(int M, int N, int K, co
 
 template <class Op>
 static int vgemm_dispatch(const Op& op, long M, long N, hipStream_t s) {
-  static const int force = getenv("REPO_GEMM_TILE") ? atoi(getenv("REPO_GEMM_TILE")) : 0;  // experiments only
-  switch (force) {
-    case 1: return launch_vgemm<T64x64>(op, M, N, 1, s);
-    case 5: return launch_vgemm<T64x128>(op, M, N, 1, s);
-    case 6: return launch_vgemm<T128x128>(op, M, N, 1, s);
-    case 7: return launch_vgemm<T128x128s1>(op, M, N, 1, s);
-    case 8: return launch_vgemm<T128x64>(op, M, N, 1, s);
-    default: break;
-  }
   // large products: 128x128 tiles with ONE register staging set (148 VGPRs -> 3 waves per SIMD; the
   // two-set variant needs > 256 and drops to one wave per SIMD: 102 vs 124-131 TFLOP/s at 4096^3)
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128);
@@ -175,70 +166,14 @@ static int vgemm_dispatch(const Op& op, long M, long N, hipStream_t s) {
 template <bool TA, bool TB>
 static int gemm_dispatch(const GemmOp<TA, TB>& op, long M, long N, hipStream_t s) {
   // pick the tile by how many workgroups the problem yields (256 CUs to fill)
-  static const int force = getenv("REPO_GEMM_TILE") ? atoi(getenv("REPO_GEMM_TILE")) : 0;  // experiments only
-  switch (force) {
-    case 1: return launch_igemm<T64x64>(op, M, N, 1, s);
-    case 2: return launch_igemm<T64x64k32>(op, M, N, 1, s);
-    case 3: return launch_igemm<T32x64k32>(op, M, N, 1, s);
-    case 4: return launch_igemm<T32x128k32>(op, M, N, 1, s);
-    case 5: return launch_igemm<T64x128k32>(op, M, N, 1, s);
-    case 6: return launch_igemm<T128x128>(op, M, N, 1, s);
-    default: break;
-  }
   const long t128 = ((M + 127) / 128) * ((N + 127) / 128);
   if (M >= 512 && N >= 512 && t128 >= 192) return launch_igemm<T128x128>(op, M, N, 1, s);
   if (M <= 32) return launch_igemm<T32x128>(op, M, N, 1, s);
   return launch_igemm<T64x64>(op, M, N, 1, s);
 }
 
-// dW[n][k] = sum_m dY[m][n] X[m][k]; column K of the product is the bias gradient.
-struct WgradOp {
-  static constexpr bool A_KMAJOR = false;  // A(m'=n, k'=m) = dY[m][n]: m' contiguous
-  static constexpr bool B_KMAJOR = false;  // B(k'=m, n'=k) = X[m][k]:  n' contiguous
-  const float* dY;
-  const float* X;
-  float* slab;  // [splits][N][K+1]
-  int lddy, ldx;
-  int rows, N_, K_, rows_per_split;
-  int z, kb, ke;
-
-  __device__ void init(int zz) {
-    z = zz;
-    kb = zz * rows_per_split;
-    ke = min(rows, kb + rows_per_split);
-  }
-  typedef int AM;
-  typedef int AK;
-  struct BN {
-    int off;
-    bool one;
-  };
-  typedef int BK;
-  __device__ int M() const { return N_; }
-  __device__ int N() const { return K_ + 1; }
-  __device__ int kbeg() const { return kb; }
-  __device__ int kend() const { return ke; }
-  __device__ AM a_m(int m) const { return m; }
-  __device__ AK a_k(int k) const { return k * lddy; }
-  __device__ float a(const AM& m, const AK& k) const { return dY[(unsigned)(m + k)]; }
-  __device__ BN b_n(int n) const { return BN{min(n, K_ - 1), n == K_}; }
-  __device__ BK b_k(int k) const { return k * ldx; }
-  __device__ float b(const BK& k, const BN& n) const {
-    const float v = X[(unsigned)(k + n.off)];
-    return n.one ? 1.f : v;
-  }
-  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
-    float* c = slab + ((size_t)z * N_ + mb) * (K_ + 1) + n;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dm = (r & 3) + 8 * (r >> 2);
-      if (mb + dm < M) c[dm * (K_ + 1)] = acc[r];
-    }
-  }
-  __device__ void finish() {}
-};
-
-// Same split-K product on the vector-load engine: both operands are contiguous along m'/n'.
+// dW[n][k] = sum_m dY[m][n] X[m][k]; column K of the product is the bias gradient.  Split-K over row groups on the
+// vector-load engine: both operands are contiguous along m'/n'.
 struct VWgradOp {
   static constexpr bool A_VK = false;  // A(m'=n, k'=row) = dY[row][n]
   static constexpr bool B_VK = false;  // B(k'=row, n'=k) = X[row][k]
@@ -314,11 +249,6 @@ static int wgrad_splits(long rows, long N, long K) {
 
 using namespace repo;
 
-static bool old_engine_gemv() {
-  static const bool v = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
-  return v;
-}
-
 extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K, const float* A,
                          int64_t lda, const float* B, int64_t ldb, const float* bias, int64_t bias_div,
                          float* C, int64_t ldc, int epi, const float* aux, int64_t ldaux, int accumulate,
@@ -341,7 +271,7 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
   // operand is its own transpose, which turns its k-vectors (K % 2 != 0: gather engine) into m/n-vectors
   if (K == 1 && !transa && lda == 1) { transa = 1; lda = M; }
   if (K == 1 && transb && ldb == 1) { transb = 0; ldb = N; }
-  if (M <= 8 && !transa && !old_engine_gemv()) {
+  if (M <= 8 && !transa) {
     if (transb) {
       hipLaunchKernelGGL((gemv_small_kernel<true>), dim3(cdiv(N, 4)), dim3(256), 0, stream, (int)M, (int)N, (int)K, A,
                          (int)lda, B, (int)ldb, bias, (int)bias_div, C, (int)ldc, epi, aux, (int)ldaux, accumulate);
@@ -353,10 +283,9 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
     return REPO_OK;
   }
   // vector-load engine whenever the k-contiguous operands (A if !transa, B if transb) have K % VW == 0
-  static const bool old_engine = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
   const bool kvec = !transa || transb;
   const int vw = (!kvec || K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 0);
-  if (vw && !old_engine) {
+  if (vw) {
     const unsigned abytes = 4u * (unsigned)(transa ? (K - 1) * lda + M : (M - 1) * lda + K);
     const unsigned bbytes = 4u * (unsigned)(transb ? (N - 1) * ldb + K : (K - 1) * ldb + N);
 #define REPO_VGEMM_CASE(TA, TB, VW)                                                                            \
@@ -415,17 +344,10 @@ extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY,
   const int splits = wgrad_splits(M, N, K);
   REPO_REQUIRE(ws && ws_bytes >= repo_gemm_wgrad_workspace_bytes(M, N, K), REPO_E_WS_TOO_SMALL);
   const int rps = (int)((M + splits - 1) / splits);
-  static const bool old_engine = getenv("REPO_GEMM_OLD") != nullptr;  // experiments only
-  int rc;
-  if (old_engine) {
-    WgradOp op{dY, X, (float*)ws, (int)lddy, (int)ldx, (int)M, (int)N, (int)K, rps, 0, 0, 0};
-    rc = launch_igemm<T64x64>(op, N, K + 1, splits, stream);
-  } else {
-    VWgradOp op{Dense2D{dY, 4u * (unsigned)((M - 1) * lddy + N), (int)lddy},
-                Dense2D{X, 4u * (unsigned)((M - 1) * ldx + K), (int)ldx},
-                (float*)ws, (int)M, (int)N, (int)K, rps, 0, 0, 0};
-    rc = launch_vgemm<T64x64>(op, N, K + 1, splits, stream);
-  }
+  VWgradOp op{Dense2D{dY, 4u * (unsigned)((M - 1) * lddy + N), (int)lddy},
+              Dense2D{X, 4u * (unsigned)((M - 1) * ldx + K), (int)ldx},
+              (float*)ws, (int)M, (int)N, (int)K, rps, 0, 0, 0};
+  const int rc = launch_vgemm<T64x64>(op, N, K + 1, splits, stream);
   if (rc) return rc;
   const int total = (int)(N * (K + 1));
   const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;

@@ -494,8 +494,6 @@ static int tr(const float* src, int rows, int cols, float* dst, hipStream_t s) {
 }
 
 bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers) {
-  static const bool off = getenv("REPO_IMAGINE_UNFUSED") && atoi(getenv("REPO_IMAGINE_UNFUSED")) != 0;
-  if (off) return false;
   return n_actor_layers == 5 && D <= 256 && Hd <= 256 && D % 2 == 0 && Hd % 2 == 0 && (S + A) % 2 == 0 &&
          (D + S) % 2 == 0 && (2 * S) % 2 == 0 && 2 * A <= 64 && 2 * S <= 64 && S + A <= 64 &&
          (Hm + 1) * N * 4 * D < kMaxIdx;

@@ -134,9 +134,11 @@ def conv_up(layer, small, w, bias=None, epi=EPI_NONE, aux=None, out=None):
     assert tuple(small.shape[1:]) == (cs, hs, hs) and small.is_contiguous(), small.shape
     if out is None:
         out = torch.empty(nimg, cb, hb, hb, dtype=torch.float32, device=small.device)
+    nb = lib().repo_conv_up_workspace_bytes(layer)
+    ws = workspace(nb, small.device) if nb else None
     check(
         lib().repo_conv_up(layer, nimg, _ptr(_f32c(small)), _ptr(_f32c(w)), _ptr(bias), _ptr(out), epi, _ptr(aux),
-                           _stream()),
+                           _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
         "repo_conv_up",
     )
     return out
