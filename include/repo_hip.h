@@ -60,6 +60,17 @@ int repo_device_check(int device);
 /* Test aid: fills every CU's LDS with NaN patterns (see tests/test_ops_gpu.py::test_no_uninitialised_lds). */
 int repo_debug_poison_lds(hipStream_t stream);
 
+/* ------------------------------------------------------------------ reparameterisation noise
+ * The reference draws its noise from torch's global generator (torch.randn_like in models/rssm.py:49,61-63;
+ * Normal.rsample in models/actor_critic.py:97-102 and models/utils.py:161).  Here every op that consumes noise
+ * takes the tensor(s) as explicit inputs -- OR null pointers plus (noise_seed, noise_offset): the kernel then
+ * DRAWS standard normals itself from a counter-based generator (Philox4x32-10 keyed by the seed, Box-Muller),
+ * normal number noise_offset + i standing in for element i of the tensor (per-op layouts below).  Nothing is
+ * written to or read from memory for it, the backward op re-draws the same values from the same (seed, offset),
+ * and repo_philox_normal materialises out[i] = normal number offset + i for tests.  The caller owns the
+ * counter: advance the offset by the number of normals an op consumed before the next draw. */
+int repo_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t stream);
+
 /* ------------------------------------------------------------------ dense layers
  * C[m][n] (+)= epi( sum_k opA(m,k) * opB(k,n) + bias[n / bias_div] )
  *   opA(m,k) = transa ? A[k*lda + m] : A[m*lda + k]
@@ -143,7 +154,8 @@ int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStre
  *  10 fc_embed_belief_posterior.weight (Hd,D+E)  11 .bias  12 fc_state_posterior.weight (2S,Hd)  13 .bias
  * Inputs : prev_belief (B,D), prev_state (B,S), actions (T,B,A), nonterms (T,B),
  *          embeds (T,B,E), eps_prior / eps_post (T,B,S) standard-normal noise in the
- *          reference's draw order (rssm.py:49,61-63).
+ *          reference's draw order (rssm.py:49,61-63); both NULL => drawn in-kernel: eps_prior = normals
+ *          [noise_offset, +T*B*S), eps_post = the next T*B*S (2*T*B*S consumed).
  * Outputs: featx (T+1,B,D+S): slot 0 = [prev_belief|prev_state], slot t+1 = [belief_t|post_t]
  *          (so beliefs = featx[1:,:,:D], posterior_states = featx[1:,:,D:]);
  *          prior_state/mean/std, post_mean/std (T,B,S).
@@ -155,6 +167,7 @@ int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd
                           const float* const* params, const float* prev_belief,
                           const float* prev_state, const float* actions, const float* nonterms,
                           const float* embeds, const float* eps_prior, const float* eps_post,
+                          uint64_t noise_seed, uint64_t noise_offset,
                           float min_std, float* featx, float* prior_state, float* prior_mean,
                           float* prior_std, float* post_mean, float* post_std, float* xsa, float* e,
                           float* gates, float* hp, float* hq, float* eemb, void* ws, size_t ws_bytes,
@@ -171,7 +184,8 @@ size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, int64_t A, in
                                              int64_t S, int64_t E);
 int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
                           const float* const* params, const float* nonterms, const float* embeds,
-                          const float* eps_prior, const float* eps_post, float min_std,
+                          const float* eps_prior, const float* eps_post, uint64_t noise_seed,
+                          uint64_t noise_offset, float min_std,
                           const float* featx, const float* prior_std, const float* post_std,
                           const float* xsa, const float* e, const float* gates, const float* hp,
                           const float* hq, const float* dfeat, const float* dprior_state,
@@ -217,7 +231,8 @@ int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, const float
  * with policy.get_action = rsample of the tanh-Normal on DETACHED inputs (rssm.py:170,
  * actor_critic.py:97-102).  Hm = horizon-1 steps over N independent rows.
  * rssm_params: 14 pointers as in repo_rssm_observe_fwd; actor_params: 2*n_actor_layers.
- * eps_act (Hm,N,A) then eps_prior (Hm,N,S) per step, in the reference's draw order.
+ * eps_act (Hm,N,A) then eps_prior (Hm,N,S) per step, in the reference's draw order; both NULL => drawn
+ * in-kernel: eps_act = normals [noise_offset, +Hm*N*A), eps_prior = the next Hm*N*S.
  * Outputs: featx (Hm+1,N,D+S), slot 0 = start, slot t+1 = [belief|prior sample];
  *          prior_mean/std (Hm,N,S).
  * Saved  : a_hidden (n_actor_layers-1, a_layer_rows, Hd) with a_layer_rows >= Hm*N (row stride of a
@@ -228,7 +243,8 @@ size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, i
 int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                           int n_actor_layers, const float* const* rssm_params,
                           const float* const* actor_params, const float* belief0, const float* state0,
-                          const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
+                          const float* eps_act, const float* eps_prior, uint64_t noise_seed,
+                          uint64_t noise_offset, float min_std, float a_min_std,
                           float a_init_std, float a_mean_scale, float* featx, float* prior_mean,
                           float* prior_std, float* a_hidden, int64_t a_layer_rows, float* a_raw,
                           float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp,
@@ -241,7 +257,8 @@ size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, i
                                              int64_t S);
 int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                           const float* const* rssm_params, const float* eps_act,
-                          const float* eps_prior, float min_std, float a_min_std, float a_mean_scale,
+                          const float* eps_prior, uint64_t noise_seed, uint64_t noise_offset,
+                          float min_std, float a_min_std, float a_mean_scale,
                           const float* featx, const float* prior_std, const float* a_mean,
                           const float* a_std, const float* xsa, const float* e, const float* gates,
                           const float* hp, const float* dfeat, const float* dprior_mean,
@@ -274,10 +291,12 @@ int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const flo
 int repo_scalar_nll(int64_t n, const float* pred, const float* target, const float* mask, float scale,
                     float* dpred, float* sums2, void* ws, size_t ws_bytes, hipStream_t stream);
 /* SampleDist.entropy of the tanh-Normal policy (models/utils.py:126-134,160-163):
- * eps (samples, rows, A).  *ent_sum = sum_rows entropy_row; dmean/dstd (rows,A) =
- * gscale * d ent_sum / d(mean,std) (nullable). */
+ * eps (samples, rows, A), or NULL => drawn in-kernel, sample s of element e = row*A + a being normal number
+ * noise_offset + e*samples + s (sample-fastest; rows*A*samples consumed).  *ent_sum = sum_rows entropy_row;
+ * dmean/dstd (rows,A) = gscale * d ent_sum / d(mean,std) (nullable). */
 int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean,
-                             const float* std, const float* eps, float gscale, float* dmean,
+                             const float* std, const float* eps, uint64_t noise_seed,
+                             uint64_t noise_offset, float gscale, float* dmean,
                              float* dstd, float* ent_sum, void* ws, size_t ws_bytes, hipStream_t stream);
 /* SampleDist.mode (models/utils.py:149-158): per row, the tanh-Normal sample with the highest
  * log-probability among `samples` draws (first maximum, like torch.argmax); eps (samples,rows,A). */

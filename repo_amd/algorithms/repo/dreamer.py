@@ -67,6 +67,12 @@ class Dreamer:
         self.step = 0
         self.dp = None  # set by repo_amd.parallel.attach() for multi-GPU runs
         self.noise_source = None  # tests inject pre-drawn noise here
+        # the update's reparameterisation noise is drawn INSIDE the kernels (counter-based Philox: include/repo_hip.h,
+        # "reparameterisation noise"); the stream is keyed by torch's seed at construction and the agent owns the
+        # counter.  REPO_NOISE=torch restores torch.randn tensors (the round-1 behaviour).
+        self._noise_seed = int(torch.initial_seed()) & ((1 << 64) - 1)
+        self._noise_counter = 0
+        self._noise_in_kernel = os.environ.get("REPO_NOISE", "philox") == "philox"
         self.build_models(config, env)
         self.buffer = SequenceReplayBuffer(
             config.replay_size,
@@ -158,11 +164,20 @@ class Dreamer:
 
     # ------------------------------------------------------------------ helpers
     def _noise(self, key, shape):
+        """An explicit noise tensor (injected by a test, or torch.randn), or None = "draw it in the kernel"."""
         if self.noise_source is not None:
             t = self.noise_source[key]
             assert tuple(t.shape) == tuple(shape), (key, t.shape, shape)
             return t
+        if self._noise_in_kernel:
+            return None
         return torch.randn(*shape, device=self.device)
+
+    def _draw(self, n):
+        """Reserve n normals of the agent's Philox stream: (seed, offset) for one op."""
+        off = self._noise_counter
+        self._noise_counter += int(n)
+        return self._noise_seed, off
 
     def _global_rows(self, local_rows):
         """Row count of the global batch (sum over data-parallel ranks)."""
@@ -197,6 +212,7 @@ class Dreamer:
         sv = ops.rssm_observe_fwd(
             pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
             self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev,
+            noise=self._draw(2 * T * B * S),
         )
         st["sv"] = sv
         feat = sv.featx[1:].reshape(rows, D + S)
@@ -307,6 +323,7 @@ class Dreamer:
         sv = ops.rssm_imagine_fwd(
             pr, pa, beliefs.contiguous(), posterior_states.contiguous(), self._noise("img_act", (Hm, N, A)),
             self._noise("img_prior", (Hm, N, S)), self.transition_model.min_std_dev, *a_consts, spare_slot=True,
+            noise=self._draw(Hm * N * (A + S)), horizon=Hm,
         )
         feats = sv.featx[1:].reshape(Hm * N, F_)
         r_pred, r_hid = ops.mlp_fwd(pw, feats)
@@ -322,7 +339,8 @@ class Dreamer:
         ent_rows = slice(N, (Hm + 1) * N)  # imagined steps 1..Hm
         mean2, std2 = sv.a_mean[ent_rows], sv.a_std[ent_rows]
         eps_ent = self._noise("entropy", (am._samples, Hm * N, A))
-        ent_sum, dmean2, dstd2 = ops.tanh_normal_entropy(mean2, std2, eps_ent, gscale=-c.action_ent_coef / (Hm * gN))
+        ent_sum, dmean2, dstd2 = ops.tanh_normal_entropy(mean2, std2, eps_ent, gscale=-c.action_ent_coef / (Hm * gN),
+                                                         noise=self._draw(am._samples * Hm * N * A), samples=am._samples)
         lat_sum, dpstd = ops.normal_entropy(sv.prior_std, gscale=-c.latent_ent_coef / (Hm * gN),
                                             want_grad=c.latent_ent_coef != 0)
         # -- lambda returns and the actor objective

@@ -58,6 +58,16 @@ extern "C" const char* repo_strerror(int code) {
   return "unknown error";
 }
 
+namespace repo {
+int philox_fill(float* out, long n, uint64_t seed, uint64_t offset, hipStream_t s);  // imagine.hip
+}
+extern "C" int repo_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(n >= 0, REPO_E_SHAPE);
+  REPO_REQUIRE(out || n == 0, REPO_E_BADARG);
+  return repo::philox_fill(out, (long)n, seed, offset, stream);
+}
+
 // Debug aid for the parity tests: fill the LDS of every CU with NaN bit patterns, so that a kernel which
 // reads LDS it never wrote (and, say, multiplies it by zero) shows up deterministically instead of once
 // in a dozen runs.  LDS contents persist until a later workgroup on that CU overwrites them.

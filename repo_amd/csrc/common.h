@@ -83,4 +83,49 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats 
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---------------------------------------------------------------------------------------------------- noise
+// Standard normals from a counter-based generator (Philox4x32-10, Salmon et al. SC'11; key = seed, counter =
+// element index / 4) + Box-Muller, so that a kernel can DRAW the reparameterisation noise it needs instead of
+// reading a tensor the host filled first ("noise tensors are explicit inputs, nullable =>
+// in-kernel Philox with (seed, offset)").  Normal number i of stream `seed` is a pure function of (seed, i): the
+// forward and the backward kernel of an op, and repo_philox_normal (which materialises the tensor for the
+// parity tests and the per-step fallback engine), all see the same values.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
+    const unsigned h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+    const unsigned n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+// the four normals of counter block `blk` (elements 4 blk .. 4 blk + 3)
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t blk, float (&z)[4]) {
+  unsigned c[4] = {(unsigned)blk, (unsigned)(blk >> 32), 0u, 0u};
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.f / 16777216.f);      // (0, 1)
+    const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float rad = sqrtf(-2.f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+}
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t i) {
+  float z[4];
+  philox_normal4(seed, i >> 2, z);
+  const int l = (int)(i & 3);
+  return l == 0 ? z[0] : l == 1 ? z[1] : l == 2 ? z[2] : z[3];
+}
+// A noise operand: an explicit tensor, or (p == nullptr) normals base, base+1, ... of stream `seed`.
+struct NoiseSrc {
+  const float* p;
+  uint64_t seed, base;
+  __device__ __forceinline__ float at(size_t i) const { return p ? p[i] : philox_normal(seed, base + i); }
+};
+
 }  // namespace repo

@@ -179,17 +179,29 @@ static inline int lin_bwd_data(int64_t rows, int64_t n, int64_t k, const float* 
                    aux, ldaux, accumulate, s);
 }
 
+// Materialise normals [offset, offset+n) of stream `seed` (the per-step engine takes tensors).
+__global__ __launch_bounds__(256) void philox_fill_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t offset) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = philox_normal(seed, offset + i);
+}
+int philox_fill(float* out, long n, uint64_t seed, uint64_t offset, hipStream_t s) {
+  if (n <= 0) return REPO_OK;
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, out, n, seed, offset);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
 // persistent row-tiled rollout (imagine_fused.hip)
 bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers);
 size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
 int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
-                      const float* const* ap, const float* belief0, const float* state0, const float* eps_act,
-                      const float* eps_prior, float min_std, float a_min_std, float a_init_std, float a_mean_scale,
+                      const float* const* ap, const float* belief0, const float* state0, NoiseSrc eps_act,
+                      NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std, float a_mean_scale,
                       float* featx, float* prior_mean, float* prior_std, float* a_hidden, int64_t a_layer_rows,
                       float* a_raw, float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp, void* ws,
                       hipStream_t stream);
 int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
-                      const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
+                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std,
                       float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
                       const float* a_std, const float* xsa, const float* e, const float* gates, const float* hp,
                       const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
@@ -302,8 +314,8 @@ static bool img_dims_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
 
 extern "C" size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S) {
-  (void)Hm;
-  const size_t unfused = (size_t)N * (6 * D + 2 * S) * sizeof(float);
+  // per-step engine: gate / head scratch + room to materialise the two noise tensors when they are drawn in-library
+  const size_t unfused = ((size_t)N * (6 * D + 2 * S) + (size_t)Hm * N * (A + S)) * sizeof(float);
   const size_t fused = imagine_fused_fwd_ws_floats(A, D, Hd, S) * sizeof(float);
   return unfused > fused ? unfused : fused;
 }
@@ -311,7 +323,8 @@ extern "C" size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, i
 extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                                      int n_actor_layers, const float* const* rssm_params,
                                      const float* const* actor_params, const float* belief0, const float* state0,
-                                     const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
+                                     const float* eps_act, const float* eps_prior, uint64_t noise_seed,
+                                     uint64_t noise_offset, float min_std, float a_min_std,
                                      float a_init_std, float a_mean_scale, float* featx, float* prior_mean,
                                      float* prior_std, float* a_hidden, int64_t a_layer_rows, float* a_raw,
                                      float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp,
@@ -319,19 +332,28 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
   REPO_ARCH_GUARD();
   REPO_REQUIRE(img_dims_ok(Hm, N, A, D, Hd, S) && n_actor_layers >= 2 && n_actor_layers <= 8, REPO_E_SHAPE);
   REPO_REQUIRE(a_layer_rows >= Hm * N, REPO_E_SHAPE);
-  REPO_REQUIRE(rssm_params && actor_params && belief0 && state0 && eps_act && eps_prior && featx && prior_mean &&
+  REPO_REQUIRE(rssm_params && actor_params && belief0 && state0 && !eps_act == !eps_prior && featx && prior_mean &&
                    prior_std && a_hidden && a_raw && a_mean && a_std && xsa && e && gates && hp,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_fwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
   if (imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers))
-    return imagine_fused_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0, eps_act, eps_prior,
-                             min_std, a_min_std, a_init_std, a_mean_scale, featx, prior_mean, prior_std, a_hidden,
+    return imagine_fused_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0,
+                             NoiseSrc{eps_act, noise_seed, noise_offset},
+                             NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_init_std, a_mean_scale, featx, prior_mean, prior_std, a_hidden,
                              a_layer_rows, a_raw, a_mean, a_std, xsa, e, gates, hp, ws, stream);
   const int64_t F = D + S, X = S + A, rowsAll = Hm * N;
   const float* const* P = rssm_params;
   float* gi = (float*)ws;
   float* gh = gi + (size_t)N * 3 * D;
   float* pout = gh + (size_t)N * 3 * D;
+  if (!eps_act) {  // draw the tensors the fused engine would have drawn element by element
+    float* na = pout + (size_t)N * 2 * S;
+    float* np_ = na + (size_t)Hm * N * A;
+    REPO_RC(philox_fill(na, Hm * N * A, noise_seed, noise_offset, stream));
+    REPO_RC(philox_fill(np_, Hm * N * S, noise_seed, noise_offset + (uint64_t)(Hm * N * A), stream));
+    eps_act = na;
+    eps_prior = np_;
+  }
   // slot 0 = start states
   hipLaunchKernelGGL(add_cols_kernel, dim3(ew_blocks(N * D)), dim3(256), 0, stream, (int)N, (int)D, belief0, (int)D,
                      (const float*)nullptr, 0, featx, (int)F);
@@ -367,26 +389,27 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
 
 extern "C" size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S) {
-  (void)Hm;
-  // g(F) carry(F) dpout(2S) dhp(Hd) dbel(D) dgi(3D) dgh(3D) de(D) dxsa(S+A)
-  return (size_t)N * (2 * (D + S) + 2 * S + Hd + D + 6 * D + D + (S + A)) * sizeof(float);
+  // g(F) carry(F) dpout(2S) dhp(Hd) dbel(D) dgi(3D) dgh(3D) de(D) dxsa(S+A) + the two noise tensors
+  return ((size_t)N * (2 * (D + S) + 2 * S + Hd + D + 6 * D + D + (S + A)) + (size_t)Hm * N * (A + S)) * sizeof(float);
 }
 
 extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                                      const float* const* rssm_params, const float* eps_act, const float* eps_prior,
-                                     float min_std, float a_min_std, float a_mean_scale, const float* featx,
+                                     uint64_t noise_seed, uint64_t noise_offset, float min_std, float a_min_std,
+                                     float a_mean_scale, const float* featx,
                                      const float* prior_std, const float* a_mean, const float* a_std,
                                      const float* xsa, const float* e, const float* gates, const float* hp,
                                      const float* dfeat, const float* dprior_mean, const float* dprior_std,
                                      float* d_araw, float* dfeat0, void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(img_dims_ok(Hm, N, A, D, Hd, S), REPO_E_SHAPE);
-  REPO_REQUIRE(rssm_params && eps_act && eps_prior && featx && prior_std && a_mean && a_std && xsa && e && gates &&
+  REPO_REQUIRE(rssm_params && !eps_act == !eps_prior && featx && prior_std && a_mean && a_std && xsa && e && gates &&
                    hp && dfeat && d_araw,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_bwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
   if (imagine_fused_ok(Hm, N, A, D, Hd, S, 5))
-    return imagine_fused_bwd(Hm, N, A, D, Hd, S, rssm_params, eps_act, eps_prior, min_std, a_min_std, a_mean_scale,
+    return imagine_fused_bwd(Hm, N, A, D, Hd, S, rssm_params, NoiseSrc{eps_act, noise_seed, noise_offset},
+                             NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_mean_scale,
                              featx, prior_std, a_mean, a_std, xsa, e, gates, hp, dfeat, dprior_mean, dprior_std,
                              d_araw, dfeat0, stream);
   const int64_t F = D + S, X = S + A;
@@ -400,7 +423,15 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
   float* dgi = w;    w += (size_t)N * 3 * D;
   float* dgh = w;    w += (size_t)N * 3 * D;
   float* de = w;     w += (size_t)N * D;
-  float* dxsa = w;
+  float* dxsa = w;   w += (size_t)N * X;
+  if (!eps_act) {
+    float* na = w;
+    float* np_ = na + (size_t)Hm * N * A;
+    REPO_RC(philox_fill(na, Hm * N * A, noise_seed, noise_offset, stream));
+    REPO_RC(philox_fill(np_, Hm * N * S, noise_seed, noise_offset + (uint64_t)(Hm * N * A), stream));
+    eps_act = na;
+    eps_prior = np_;
+  }
   bool have_carry = false;
   for (int64_t t = Hm - 1; t >= 0; --t) {
     const size_t r0 = (size_t)t * N;

@@ -109,7 +109,8 @@ struct ImgFwdArgs {
   const float* aWt[5];  // actor weights transposed [k][n]
   const float* ab[5];
   const float *WsaT, *bsa, *WihT, *WhhT, *bih, *bhh, *WbpT, *bbp, *WspT, *bsp;
-  const float *belief0, *state0, *eps_act, *eps_prior;
+  const float *belief0, *state0;
+  NoiseSrc eps_act, eps_prior;
   float min_std, a_min_std, a_init_std, a_mean_scale;
   float *featx, *prior_mean, *prior_std, *a_hidden, *a_raw, *a_mean, *a_std, *xsa, *e, *gates, *hp;
   size_t a_layer_rows;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
         const int a = k - S;
         const float mu = p.a_mean_scale * tanh_fast(SM[a * kLD + row] / p.a_mean_scale);
         const float sd = softplus(SM[(A + a) * kLD + row] + p.a_init_std) + p.a_min_std;
-        const float ep = row < nr ? p.eps_act[(rb + row) * A + a] : 0.f;
+        const float ep = row < nr ? p.eps_act.at((rb + row) * A + a) : 0.f;
         v = tanh_fast(fmaf(sd, ep, mu));
         if (row < nr) {
           p.a_mean[(rb + row) * A + a] = mu;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
       float smp = mu;
       if (row < nr) {
         const size_t o = (rb + row) * S + s;
-        smp = fmaf(sd, p.eps_prior[o], mu);
+        smp = fmaf(sd, p.eps_prior.at(o), mu);
         p.prior_mean[o] = mu;
         p.prior_std[o] = sd;
         p.featx[((size_t)(t + 1) * N + r0 + row) * F + D + s] = smp;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
 struct ImgBwdArgs {
   ImgDims d;
   const float *Wsa, *Wih, *Whh, *Wbp, *Wsp;  // native [out][in] layouts = [k][n] for the transposed products
-  const float *eps_act, *eps_prior;
+  NoiseSrc eps_act, eps_prior;
   float min_std, a_min_std, a_mean_scale;
   const float *featx, *prior_std, *a_mean, *a_std, *xsa, *e, *gates, *hp;
   const float *dfeat, *dprior_mean, *dprior_std;
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
         const size_t o = (rb + row) * S + s;
         const float ds = Gs[s * kLD + row];
         gm = ds + (p.dprior_mean ? p.dprior_mean[o] : 0.f);
-        const float gs = fmaf(ds, p.eps_prior[o], p.dprior_std ? p.dprior_std[o] : 0.f);
+        const float gs = fmaf(ds, p.eps_prior.at(o), p.dprior_std ? p.dprior_std[o] : 0.f);
         gr = gs * (-expm1f(-(p.prior_std[o] - p.min_std)));
       }
       SM[s * kLD + row] = gm;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
         const float du = SM[(S + a) * kLD + row] * (1.f - act * act);
         const float tm = p.a_mean[o] / p.a_mean_scale;
         p.d_araw[(rb + row) * 2 * A + a] = du * (1.f - tm * tm);
-        p.d_araw[(rb + row) * 2 * A + A + a] = du * p.eps_act[o] * (-expm1f(-(p.a_std[o] - p.a_min_std)));
+        p.d_araw[(rb + row) * 2 * A + A + a] = du * p.eps_act.at(o) * (-expm1f(-(p.a_std[o] - p.a_min_std)));
       }
     }
     __syncthreads();
@@ -514,7 +515,7 @@ static size_t bwd_lds_bytes(int A, int D, int Hd, int S) {
 
 int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                       const float* const* rp, const float* const* ap, const float* belief0, const float* state0,
-                      const float* eps_act, const float* eps_prior, float min_std, float a_min_std, float a_init_std,
+                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std,
                       float a_mean_scale, float* featx, float* prior_mean, float* prior_std, float* a_hidden,
                       int64_t a_layer_rows, float* a_raw, float* a_mean, float* a_std, float* xsa, float* e,
                       float* gates, float* hp, void* ws, hipStream_t stream) {
@@ -557,7 +558,7 @@ int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
 }
 
 int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
-                      const float* eps_act, const float* eps_prior, float min_std, float a_min_std,
+                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std,
                       float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
                       const float* a_std, const float* xsa, const float* e, const float* gates, const float* hp,
                       const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,

@@ -132,12 +132,14 @@ __global__ __launch_bounds__(256) void scalar_nll_kernel(int n, const float* __r
 // SampleDist.entropy (models/utils.py:160-163) over TanhBijector (models/utils.py:126-134):
 //   u = mean + std*eps ; y = tanh(u) ; x = atanh(clamp(y, +-0.99999994)) (inverse recomputed)
 //   logp = -0.5((x-mean)/std)^2 - log std - 0.5 log 2pi - 2(log2 - x - softplus(-2x))
-// element e = row*A + a; eps is (NS, n) with n = rows*A.  Writes
+// element e = row*A + a; eps is (NS, n) with n = rows*A, or null: then sample s of element e is normal number
+// offset + e*NS + s of the Philox stream (SAMPLE-fastest, so a thread's NS draws are NS/4 counter blocks).  Writes
 //   parts[blk]   = sum_e ( -(1/NS) sum_s logp_{s,e} )         (sum over rows of the row entropy)
 //   dmean/dstd[e] = gscale * d(entropy_sum)/d(mean,std)[e]
 __global__ __launch_bounds__(256) void tanh_normal_entropy_kernel(int n, int NS, const float* __restrict__ mean,
                                                                   const float* __restrict__ stdv,
-                                                                  const float* __restrict__ eps, float gscale,
+                                                                  const float* __restrict__ eps, uint64_t nseed,
+                                                                  uint64_t noffset, float gscale,
                                                                   float* __restrict__ dmean, float* __restrict__ dstd,
                                                                   float* __restrict__ parts) {
   __shared__ float red[16];
@@ -148,8 +150,18 @@ __global__ __launch_bounds__(256) void tanh_normal_entropy_kernel(int n, int NS,
     const float mu = mean[e], sd = stdv[e];
     const float isd = 1.f / sd, isd2 = isd * isd, lsd = logf(sd);
     float slog = 0.f, gmu = 0.f, gsd = 0.f;
+    float z[4];
+    const uint64_t first = noffset + (uint64_t)e * NS;  // this element's first normal
     for (int s = 0; s < NS; ++s) {
-      const float ep = eps[(size_t)s * n + e];
+      float ep;
+      if (eps) {
+        ep = eps[(size_t)s * n + e];
+      } else {
+        const uint64_t i = first + s;
+        if (s == 0 || (i & 3) == 0) philox_normal4(nseed, i >> 2, z);
+        const int l = (int)(i & 3);
+        ep = l == 0 ? z[0] : l == 1 ? z[1] : l == 2 ? z[2] : z[3];
+      }
       const float u = fmaf(sd, ep, mu);
       const float y = tanhf(u);
       const bool pass = fabsf(y) <= kClamp;  // clamp passes gradient inside (inclusive) the bounds
@@ -329,16 +341,17 @@ extern "C" int repo_scalar_nll(int64_t n, const float* pred, const float* target
 }
 
 extern "C" int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,
-                                        const float* eps, float gscale, float* dmean, float* dstd, float* ent_sum,
-                                        void* ws, size_t ws_bytes, hipStream_t stream) {
+                                        const float* eps, uint64_t noise_seed, uint64_t noise_offset, float gscale,
+                                        float* dmean, float* dstd, float* ent_sum, void* ws, size_t ws_bytes,
+                                        hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && A > 0 && samples > 0 && rows * A < kMaxIdx, REPO_E_SHAPE);
-  REPO_REQUIRE(mean && std && eps && ent_sum, REPO_E_BADARG);
+  REPO_REQUIRE(mean && std && ent_sum, REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
   const long n = rows * A;
   const int blocks = red_blocks(n, 256);
   hipLaunchKernelGGL(tanh_normal_entropy_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, (int)samples, mean, std,
-                     eps, gscale, dmean, dstd, (float*)ws);
+                     eps, noise_seed, noise_offset, gscale, dmean, dstd, (float*)ws);
   REPO_CHECK_LAUNCH();
   return final_sum((const float*)ws, blocks, 1, ent_sum, stream);
 }

@@ -87,7 +87,7 @@ struct ObsFwdArgs {
   const float *prev_belief, *prev_state;  // (B,D), (B,S)
   const float *actions, *nonterms;        // (T,B,A), (T,B)
   const float* eemb;                      // (T,B,Hd) hoisted embed contribution (no bias)
-  const float *eps_prior, *eps_post;      // (T,B,S)
+  NoiseSrc eps_prior, eps_post;           // (T,B,S)
   float* featx;                           // (T+1,B,D+S): slot 0 = [prev_belief|prev_state], slot t+1 = [belief_t|post_t]
   float *prior_state, *prior_mean, *prior_std, *post_mean, *post_std;  // (T,B,S)
   float *xsa, *e, *gates, *hp, *hq;       // saved for backward: (T,B,S+A) (T,B,D) (T,B,4D) (T,B,Hd) (T,B,Hd)
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       const float sd = softplus(outs[r][base + S + s]) + p.min_std;
       if (r < nr) {
         const size_t o = (row0 + r) * S + s;
-        const float eps = post ? p.eps_post[o] : p.eps_prior[o];
+        const float eps = post ? p.eps_post.at(o) : p.eps_prior.at(o);
         const float smp = fmaf(sd, eps, mean);
         if (post) {
           p.post_mean[o] = mean;
@@ -376,7 +376,8 @@ struct ObsBwdArgs {
   // W(n = input index, k = output index) = native[k*ld + n]
   const float *Wsa, *Wih, *Whh, *Wbp, *Wsp, *Wbq, *Wsq;
   // saved by forward
-  const float *featx, *nonterms, *e, *gates, *hp, *hq, *prior_std, *post_std, *eps_prior, *eps_post;
+  const float *featx, *nonterms, *e, *gates, *hp, *hq, *prior_std, *post_std;
+  NoiseSrc eps_prior, eps_post;
   // upstream gradients, each nullable: d featx[1:] (T,B,D+S); prior_state, and the four (mean,std) (T,B,S)
   const float *dfeat, *dprior_state, *dpm, *dps, *dqm, *dqs;
   // per-step deltas (outputs)
@@ -453,13 +454,13 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
           dm = p.dqm ? p.dqm[o] : 0.f;
           dsd = p.dqs ? p.dqs[o] : 0.f;
           sd = p.post_std[o];
-          eps = p.eps_post[o];
+          eps = p.eps_post.at(o);
         } else {
           dsmp = p.dprior_state ? p.dprior_state[o] : 0.f;
           dm = p.dpm ? p.dpm[o] : 0.f;
           dsd = p.dps ? p.dps[o] : 0.f;
           sd = p.prior_std[o];
-          eps = p.eps_prior[o];
+          eps = p.eps_prior.at(o);
         }
         dm += dsmp;
         dsd = fmaf(dsmp, eps, dsd);
@@ -688,13 +689,14 @@ extern "C" size_t repo_rssm_observe_fwd_workspace_bytes(int64_t T, int64_t B, in
 extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
                                      const float* const* params, const float* prev_belief, const float* prev_state,
                                      const float* actions, const float* nonterms, const float* embeds,
-                                     const float* eps_prior, const float* eps_post, float min_std, float* featx,
+                                     const float* eps_prior, const float* eps_post, uint64_t noise_seed,
+                                     uint64_t noise_offset, float min_std, float* featx,
                                      float* prior_state, float* prior_mean, float* prior_std, float* post_mean,
                                      float* post_std, float* xsa, float* e, float* gates, float* hp, float* hq,
                                      float* eemb, void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0, REPO_E_SHAPE);
-  REPO_REQUIRE(params && prev_belief && prev_state && actions && nonterms && embeds && eps_prior && eps_post,
+  REPO_REQUIRE(params && prev_belief && prev_state && actions && nonterms && embeds && !eps_prior == !eps_post,
                REPO_E_BADARG);
   REPO_REQUIRE(featx && prior_state && prior_mean && prior_std && post_mean && post_std && xsa && e && gates && hp &&
                    hq && eemb,
@@ -729,7 +731,9 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   a.WsaT = WsaT; a.bsa = P[1]; a.WihT = WihT; a.WhhT = WhhT; a.bih = P[4]; a.bhh = P[5];
   a.WbpT = WbpT; a.bbp = P[7]; a.WspT = WspT; a.bsp = P[9]; a.WbqT = WbqT; a.bbq = P[11]; a.WsqT = WsqT; a.bsq = P[13];
   a.prev_belief = prev_belief; a.prev_state = prev_state; a.actions = actions; a.nonterms = nonterms;
-  a.eemb = eemb; a.eps_prior = eps_prior; a.eps_post = eps_post;
+  a.eemb = eemb;
+  a.eps_prior = NoiseSrc{eps_prior, noise_seed, noise_offset};
+  a.eps_post = NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)};
   a.featx = featx; a.prior_state = prior_state; a.prior_mean = prior_mean; a.prior_std = prior_std;
   a.post_mean = post_mean; a.post_std = post_std; a.xsa = xsa; a.e = e; a.gates = gates; a.hp = hp; a.hq = hq;
   a.min_std = min_std;
@@ -768,7 +772,8 @@ extern "C" size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, in
 
 extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
                                      const float* const* params, const float* nonterms, const float* embeds,
-                                     const float* eps_prior, const float* eps_post, float min_std, const float* featx,
+                                     const float* eps_prior, const float* eps_post, uint64_t noise_seed,
+                                     uint64_t noise_offset, float min_std, const float* featx,
                                      const float* prior_std, const float* post_std, const float* xsa, const float* e,
                                      const float* gates, const float* hp, const float* hq, const float* dfeat,
                                      const float* dprior_state, const float* dpm, const float* dps, const float* dqm,
@@ -777,7 +782,7 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
                                      hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0 && T > 0, REPO_E_SHAPE);
-  REPO_REQUIRE(params && nonterms && embeds && eps_prior && eps_post && featx && prior_std && post_std && xsa && e &&
+  REPO_REQUIRE(params && nonterms && embeds && !eps_prior == !eps_post && featx && prior_std && post_std && xsa && e &&
                    gates && hp && hq && dparams,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_observe_bwd_workspace_bytes(T, B, A, D, Hd, S, E), REPO_E_WS_TOO_SMALL);
@@ -817,7 +822,9 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
     if ((rc0 = put(P[0], (int)S, d, X_, &a.Wsa))) return rc0;
   }
   a.featx = featx; a.nonterms = nonterms; a.e = e; a.gates = gates; a.hp = hp; a.hq = hq;
-  a.prior_std = prior_std; a.post_std = post_std; a.eps_prior = eps_prior; a.eps_post = eps_post;
+  a.prior_std = prior_std; a.post_std = post_std;
+  a.eps_prior = NoiseSrc{eps_prior, noise_seed, noise_offset};
+  a.eps_post = NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)};
   a.dfeat = dfeat; a.dprior_state = dprior_state; a.dpm = dpm; a.dps = dps; a.dqm = dqm; a.dqs = dqs;
   a.doutp = doutp; a.doutq = doutq; a.dhp = dhp; a.dhq = dhq; a.dgi = dgi; a.dgh = dgh; a.de = de;
   a.dprev_belief = dprev_belief; a.dprev_state = dprev_state; a.min_std = min_std;

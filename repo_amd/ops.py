@@ -226,11 +226,13 @@ def reduce_ws(device):
 # ----------------------------------------------------------------------------- RSSM observe
 class ObserveSaved:
     __slots__ = ("T", "B", "A", "D", "Hd", "S", "E", "featx", "prior_state", "prior_mean", "prior_std", "post_mean",
-                 "post_std", "xsa", "e", "gates", "hp", "hq", "nonterms", "embeds", "eps_prior", "eps_post")
+                 "post_std", "xsa", "e", "gates", "hp", "hq", "nonterms", "embeds", "eps_prior", "eps_post", "noise")
 
 
-def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds, eps_prior, eps_post, min_std=0.1):
-    """params: list of the 14 TransitionModel tensors in state_dict order.  Time-major inputs."""
+def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds, eps_prior, eps_post, min_std=0.1,
+                     noise=(0, 0)):
+    """params: list of the 14 TransitionModel tensors in state_dict order.  Time-major inputs.
+    eps_prior = eps_post = None: the kernel draws its noise from Philox stream noise = (seed, offset)."""
     T, B, A = actions.shape
     D, S = prev_belief.shape[1], prev_state.shape[1]
     Hd = params[6].shape[0]
@@ -245,15 +247,18 @@ def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds,
     sv.xsa, sv.e, sv.gates, sv.hp, sv.hq = f(T, B, S + A), f(T, B, D), f(T, B, 4 * D), f(T, B, Hd), f(T, B, Hd)
     eemb = f(T, B, Hd)
     sv.nonterms = _f32c(nonterms.reshape(T, B))
-    sv.embeds, sv.eps_prior, sv.eps_post = _f32c(embeds), _f32c(eps_prior), _f32c(eps_post)
+    sv.embeds = _f32c(embeds)
+    sv.eps_prior = _f32c(eps_prior) if eps_prior is not None else None
+    sv.eps_post = _f32c(eps_post) if eps_post is not None else None
+    sv.noise = (int(noise[0]), int(noise[1]))
     nb = lib().repo_rssm_observe_fwd_workspace_bytes(T, B, A, D, Hd, S, E)
     ws = workspace(nb, dev)
     pa = ptr_array(params)
     check(
         lib().repo_rssm_observe_fwd(
             T, B, A, D, Hd, S, E, pa, _ptr(_f32c(prev_belief)), _ptr(_f32c(prev_state)), _ptr(_f32c(actions)),
-            _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior), _ptr(sv.eps_post), float(min_std),
-            _ptr(sv.featx), _ptr(sv.prior_state), _ptr(sv.prior_mean), _ptr(sv.prior_std), _ptr(sv.post_mean),
+            _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior), _ptr(sv.eps_post), sv.noise[0], sv.noise[1],
+            float(min_std), _ptr(sv.featx), _ptr(sv.prior_state), _ptr(sv.prior_mean), _ptr(sv.prior_std), _ptr(sv.post_mean),
             _ptr(sv.post_std), _ptr(sv.xsa), _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(eemb),
             _ptr(ws), ws.numel(), _stream(),
         ),
@@ -271,7 +276,7 @@ def rssm_observe_bwd(params, sv, dparams, dfeat=None, dprior_state=None, dpm=Non
     check(
         lib().repo_rssm_observe_bwd(
             sv.T, sv.B, sv.A, sv.D, sv.Hd, sv.S, sv.E, pa, _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior),
-            _ptr(sv.eps_post), float(min_std), _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.post_std), _ptr(sv.xsa),
+            _ptr(sv.eps_post), sv.noise[0], sv.noise[1], float(min_std), _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.post_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(dfeat), _ptr(dprior_state), _ptr(dpm),
             _ptr(dps), _ptr(dqm), _ptr(dqs), ga, _ptr(dembeds), _ptr(dprev_belief), _ptr(dprev_state),
             int(accumulate), _ptr(ws), ws.numel(), _stream(),
@@ -358,14 +363,18 @@ def actor_head_bwd(mean, std, dmean=None, dstd=None, daction=None, action=None, 
 # ----------------------------------------------------------------------------- imagination
 class ImagineSaved:
     __slots__ = ("Hm", "N", "A", "D", "Hd", "S", "featx", "prior_mean", "prior_std", "a_hidden", "a_raw", "a_mean",
-                 "a_std", "xsa", "e", "gates", "hp", "eps_act", "eps_prior")
+                 "a_std", "xsa", "e", "gates", "hp", "eps_act", "eps_prior", "noise")
 
 
 def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_prior, min_std=0.1, a_min_std=0.1,
-                     a_init_std=0.0, a_mean_scale=5.0, spare_slot=False):
+                     a_init_std=0.0, a_mean_scale=5.0, spare_slot=False, noise=(0, 0), horizon=None):
     """spare_slot: allocate the saved actor tensors with one extra step slot ((Hm+1)*N rows) so the
-    caller can evaluate the actor on the final imagined state into the same buffers."""
-    Hm, N, A = eps_act.shape
+    caller can evaluate the actor on the final imagined state into the same buffers.
+    eps_act = eps_prior = None (+ horizon = Hm): the kernel draws its noise from Philox stream noise = (seed, offset)."""
+    if eps_act is None:
+        Hm, N, A = int(horizon), belief0.shape[0], actor_params[-1].shape[0] // 2
+    else:
+        Hm, N, A = eps_act.shape
     D, S = belief0.shape[1], state0.shape[1]
     Hd = rssm_params[6].shape[0]
     La = len(actor_params) // 2
@@ -379,14 +388,16 @@ def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_pr
     sv.a_hidden = f(La - 1, ar, Hd)
     sv.a_raw, sv.a_mean, sv.a_std = f(ar, 2 * A), f(ar, A), f(ar, A)
     sv.xsa, sv.e, sv.gates, sv.hp = f(Hm * N, S + A), f(Hm * N, D), f(Hm * N, 4 * D), f(Hm * N, Hd)
-    sv.eps_act, sv.eps_prior = _f32c(eps_act), _f32c(eps_prior)
+    sv.eps_act = _f32c(eps_act) if eps_act is not None else None
+    sv.eps_prior = _f32c(eps_prior) if eps_prior is not None else None
+    sv.noise = (int(noise[0]), int(noise[1]))
     nb = lib().repo_rssm_imagine_fwd_workspace_bytes(Hm, N, A, D, Hd, S)
     ws = workspace(nb, dev)
     ra, aa = ptr_array(rssm_params), ptr_array(actor_params)
     check(
         lib().repo_rssm_imagine_fwd(
             Hm, N, A, D, Hd, S, La, ra, aa, _ptr(_f32c(belief0)), _ptr(_f32c(state0)), _ptr(sv.eps_act),
-            _ptr(sv.eps_prior), min_std, a_min_std, a_init_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_mean),
+            _ptr(sv.eps_prior), sv.noise[0], sv.noise[1], min_std, a_min_std, a_init_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_mean),
             _ptr(sv.prior_std), _ptr(sv.a_hidden), ar, _ptr(sv.a_raw), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(ws), ws.numel(), _stream(),
         ),
@@ -406,8 +417,8 @@ def rssm_imagine_bwd(rssm_params, sv, dfeat, dprior_mean=None, dprior_std=None, 
     ra = ptr_array(rssm_params)
     check(
         lib().repo_rssm_imagine_bwd(
-            sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S, ra, _ptr(sv.eps_act), _ptr(sv.eps_prior), min_std, a_min_std,
-            a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
+            sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S, ra, _ptr(sv.eps_act), _ptr(sv.eps_prior), sv.noise[0], sv.noise[1],
+            min_std, a_min_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(_f32c(dfeat)), _ptr(dprior_mean), _ptr(dprior_std),
             _ptr(d_araw), _ptr(dfeat0), _ptr(ws), ws.numel(), _stream(),
         ),
@@ -460,17 +471,19 @@ def scalar_nll(pred, target, mask, scale, want_grad=True, out=None):
     return out, dpred
 
 
-def tanh_normal_entropy(mean, std, eps, gscale=0.0, want_grads=True):
+def tanh_normal_entropy(mean, std, eps, gscale=0.0, want_grads=True, noise=(0, 0), samples=None):
+    """eps (samples, rows, A), or None (+ samples): drawn in-kernel from Philox stream noise = (seed, offset)."""
     rows, A = mean.shape
-    NS = eps.shape[0]
-    assert eps.numel() == NS * rows * A
+    NS = eps.shape[0] if eps is not None else int(samples)
+    assert eps is None or eps.numel() == NS * rows * A
     dev = mean.device
     dmean = torch.empty_like(mean) if want_grads else None
     dstd = torch.empty_like(std) if want_grads else None
     out = torch.empty(1, dtype=torch.float32, device=dev)
     ws = reduce_ws(dev)
     check(
-        lib().repo_tanh_normal_entropy(rows, A, NS, _ptr(_f32c(mean)), _ptr(_f32c(std)), _ptr(_f32c(eps)),
+        lib().repo_tanh_normal_entropy(rows, A, NS, _ptr(_f32c(mean)), _ptr(_f32c(std)),
+                                       _ptr(_f32c(eps)) if eps is not None else None, int(noise[0]), int(noise[1]),
                                        float(gscale), _ptr(dmean), _ptr(dstd), _ptr(out), _ptr(ws), ws.numel(),
                                        _stream()),
         "repo_tanh_normal_entropy",
@@ -536,3 +549,11 @@ def clip_adam(p, g, m, v, sqnorm, max_norm, lr, step, betas=(0.9, 0.999), eps=1e
                              float(max_norm), float(lr), betas[0], betas[1], eps, step, _stream()),
         "repo_clip_adam",
     )
+
+
+def philox_normal(n, seed, offset, device):
+    """The n standard normals [offset, offset+n) of Philox stream `seed` -- what a kernel given (seed, offset)
+    instead of a noise tensor draws for elements 0..n-1."""
+    out = torch.empty(int(n), dtype=torch.float32, device=device)
+    check(lib().repo_philox_normal(_ptr(out), int(n), int(seed), int(offset), _stream()), "repo_philox_normal")
+    return out

@@ -100,5 +100,8 @@ class DataParallel:
             self.broadcast(agent.log_beta)
             self.broadcast(agent.beta_optimizer.exp_avg)
             self.broadcast(agent.beta_optimizer.exp_avg_sq)
+        # every rank draws its OWN reparameterisation noise for its rows: decorrelate the in-kernel Philox streams
+        if hasattr(agent, "_noise_seed"):
+            agent._noise_seed = (agent._noise_seed + self.rank * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
         agent.dp = self
         return agent

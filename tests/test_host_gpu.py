@@ -397,7 +397,7 @@ def _full_size_vs_oracle(tag, algo, L, B, H, A, n_updates=1):
             r = abs(got[k] - w) / (abs(w) + 1e-12)
             log(f"[{tag} update {u}] {k}: got {got[k]:.7g} oracle {w:.7g} rel {r:.2e}")
             assert r < 1e-3, (tag, u, k, got[k], w)
-        assert abs(float(agent.log_beta) - float(oracle.log_beta)) < 1e-5
+        assert abs(float(agent.log_beta) - float(oracle.log_beta.detach())) < 1e-5
         gn, on = agent.last_grad_norms, oracle.last
         for name in ("model", "actor", "value"):
             w = on[f"{name}_total_norm"]

@@ -253,3 +253,63 @@ def test_clip_adam(ops):
         e = (p.cpu() - ref.detach()).abs().max().item()
         log(f"clip_adam step {step}: max abs diff {e:.2e}")
         assert e < 2e-7
+
+
+# ----------------------------------------------------------------------------- in-kernel Philox noise (8b)
+def test_philox_normal_stream_statistics_and_addressing():
+    """repo_philox_normal: out[i] is a pure function of (seed, offset + i); moments of N(0,1); distinct seeds and
+    disjoint offset ranges are uncorrelated."""
+    from repo_amd import ops
+
+    dev = torch.device("cuda")
+    n = 1 << 22
+    a = ops.philox_normal(n, 1234, 0, dev)
+    b = ops.philox_normal(n // 2, 1234, 1001, dev)
+    assert torch.equal(a[1001:1001 + n // 2], b)                      # offset addressing, unaligned to the block of 4
+    assert torch.equal(ops.philox_normal(n, 1234, 0, dev), a)        # deterministic
+    x = a.double()
+    assert abs(x.mean().item()) < 3e-3 and abs(x.var().item() - 1.0) < 5e-3
+    assert abs((x ** 3).mean().item()) < 1e-2 and abs((x ** 4).mean().item() - 3.0) < 3e-2
+    assert x.abs().max().item() < 6.5 and torch.isfinite(a).all()
+    c = ops.philox_normal(n, 1235, 0, dev).double()
+    assert abs((x * c).mean().item()) < 3e-3                          # other seed
+    assert abs((x[:-1] * x[1:]).mean().item()) < 3e-3                 # lag-1
+    assert abs((x[:-4] * x[4:]).mean().item()) < 3e-3                 # across counter blocks
+    frac = (x.abs() < 1.0).double().mean().item()
+    assert abs(frac - 0.682689) < 2e-3
+
+
+@pytest.mark.parametrize("A,fused", [(6, True), (7, False)])
+def test_update_with_in_kernel_noise_equals_explicit_tensors(A, fused):
+    """An update whose kernels DRAW their noise (null eps + (seed, offset)) equals, bit for bit, the update fed the
+    tensors repo_philox_normal materialises for the same (seed, offset) ranges -- observe fwd/bwd, the rollout
+    (fused engine at A=6, per-step engine at A=7) fwd/bwd and the 100-sample entropy."""
+    from repo_amd import ops
+    from tests.test_update_gpu import dev_batch, make_agent
+
+    L, B, H = 7, 5, 5
+    T, S, Hm = L - 1, 30, H - 1
+    N = T * B
+    batch, _ = dev_batch(L, B, A, 77)
+    drawn, _ = make_agent("repo", L, B, H, A)
+    fed, _ = make_agent("repo", L, B, H, A)
+    seed = 987654321
+    drawn._noise_seed = seed
+    dev = torch.device("cuda")
+    for u in range(2):
+        off = drawn._noise_counter
+        o_obs, o_img, o_ent = off, off + 2 * T * B * S, off + 2 * T * B * S + Hm * N * (A + S)
+        fed.noise_source = {
+            "obs_prior": ops.philox_normal(T * B * S, seed, o_obs, dev).view(T, B, S),
+            "obs_post": ops.philox_normal(T * B * S, seed, o_obs + T * B * S, dev).view(T, B, S),
+            "img_act": ops.philox_normal(Hm * N * A, seed, o_img, dev).view(Hm, N, A),
+            "img_prior": ops.philox_normal(Hm * N * S, seed, o_img + Hm * N * A, dev).view(Hm, N, S),
+            # sample-fastest: element e's 100 draws are consecutive
+            "entropy": ops.philox_normal(100 * Hm * N * A, seed, o_ent, dev).view(Hm * N, A, 100).permute(2, 0, 1).contiguous(),
+        }
+        drawn.update(batch)
+        fed.update(batch)
+        assert drawn._noise_counter == o_ent + 100 * Hm * N * A
+        assert drawn.last_scalars == fed.last_scalars, (u, drawn.last_scalars, fed.last_scalars)
+        for name in ("model_optimizer", "actor_optimizer", "value_optimizer"):
+            assert torch.equal(getattr(drawn, name).flat, getattr(fed, name).flat), (u, name)
