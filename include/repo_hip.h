@@ -160,7 +160,10 @@ int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStre
  *          (so beliefs = featx[1:,:,:D], posterior_states = featx[1:,:,D:]);
  *          prior_state/mean/std, post_mean/std (T,B,S).
  * Saved for backward: xsa (T,B,S+A), e (T,B,D), gates (T,B,4D) = r|z|n|W_hn h+b_hn,
- *          hp, hq (T,B,Hd); eemb (T,B,Hd) is scratch for the hoisted embedding GEMM. */
+ *          hp, hq (T,B,Hd); eemb (T,B,Hd) is scratch for the hoisted embedding GEMM.
+ * prior_only != 0: the reference's `observations=None` branch (rssm.py:118): step t+1 is fed the PRIOR sample of
+ *          step t, featx[t+1][D:] = prior sample; the posterior outputs are then computed from whatever
+ *          `embeds` holds and mean nothing (forward only: repo_rssm_observe_bwd assumes prior_only == 0). */
 size_t repo_rssm_observe_fwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
                                              int64_t S, int64_t E);
 int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
@@ -170,8 +173,8 @@ int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd
                           uint64_t noise_seed, uint64_t noise_offset,
                           float min_std, float* featx, float* prior_state, float* prior_mean,
                           float* prior_std, float* post_mean, float* post_std, float* xsa, float* e,
-                          float* gates, float* hp, float* hq, float* eemb, void* ws, size_t ws_bytes,
-                          hipStream_t stream);
+                          float* gates, float* hp, float* hq, float* eemb, int prior_only, void* ws,
+                          size_t ws_bytes, hipStream_t stream);
 
 /* Reverse scan (BPTT) + deferred weight gradients.  Upstream gradients (each nullable):
  * dfeat (T,B,D+S) w.r.t. featx[1:], dprior_state, dpm, dps, dqm, dqs (T,B,S) w.r.t. the

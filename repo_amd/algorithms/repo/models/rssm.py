@@ -41,10 +41,24 @@ class TransitionModel(nn.Module):
         from ..autograd import observe_apply
 
         if observations is None:
-            raise NotImplementedError(
-                "observe() without observations (prior-only rollout) is not on the hot path; use imagine()"
-            )
+            # open-loop rollout under GIVEN actions (reference rssm.py:118: the next step is fed the prior sample):
+            # -> [beliefs, prior_states, prior_means, prior_std_devs].  Forward values only.
+            return self._observe_prior_only(prev_belief, prev_state, actions, nonterminals, noise)
         return observe_apply(self, prev_belief, prev_state, actions, observations, nonterminals, noise)
+
+    @torch.no_grad()
+    def _observe_prior_only(self, prev_belief, prev_state, actions, nonterminals, noise):
+        from .... import ops
+
+        T, B = actions.shape[:2]
+        dev = actions.device
+        S, D = self.state_size, self.belief_size
+        nt = torch.ones(T, B, device=dev) if nonterminals is None else nonterminals.reshape(T, B).float()
+        eps = noise[0] if noise is not None else torch.randn(T, B, S, device=dev)
+        sv = ops.rssm_observe_fwd([t.detach() for t in self.plist()], prev_belief.contiguous(), prev_state.contiguous(),
+                                  actions.contiguous(), nt.contiguous(), torch.zeros(T, B, self.embedding_size, device=dev),
+                                  eps.contiguous(), torch.zeros(T, B, S, device=dev), self.min_std_dev, prior_only=True)
+        return [sv.featx[1:, :, :D], sv.prior_state, sv.prior_mean, sv.prior_std]
 
     @torch.no_grad()
     def imagine(self, prev_belief, prev_state, policy, horizon, noise=None):

@@ -92,6 +92,7 @@ struct ObsFwdArgs {
   float *prior_state, *prior_mean, *prior_std, *post_mean, *post_std;  // (T,B,S)
   float *xsa, *e, *gates, *hp, *hq;       // saved for backward: (T,B,S+A) (T,B,D) (T,B,4D) (T,B,Hd) (T,B,Hd)
   float min_std;
+  int prior_only;  // the NEXT step is fed the prior sample (observe without observations, rssm.py:118)
 };
 
 // R rows per workgroup, KQ-way split of every reduction (k) range over thread groups of 256:
@@ -357,12 +358,18 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
         if (post) {
           p.post_mean[o] = mean;
           p.post_std[o] = sd;
-          p.featx[((size_t)(t + 1) * B + b0 + r) * F + D + s] = smp;
-          st[r][s] = smp;
+          if (!p.prior_only) {
+            p.featx[((size_t)(t + 1) * B + b0 + r) * F + D + s] = smp;
+            st[r][s] = smp;
+          }
         } else {
           p.prior_mean[o] = mean;
           p.prior_std[o] = sd;
           p.prior_state[o] = smp;
+          if (p.prior_only) {
+            p.featx[((size_t)(t + 1) * B + b0 + r) * F + D + s] = smp;
+            st[r][s] = smp;
+          }
         }
       }
     }
@@ -693,7 +700,7 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
                                      uint64_t noise_offset, float min_std, float* featx,
                                      float* prior_state, float* prior_mean, float* prior_std, float* post_mean,
                                      float* post_std, float* xsa, float* e, float* gates, float* hp, float* hq,
-                                     float* eemb, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                     float* eemb, int prior_only, void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0, REPO_E_SHAPE);
   REPO_REQUIRE(params && prev_belief && prev_state && actions && nonterms && embeds && !eps_prior == !eps_post,
@@ -732,6 +739,7 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   a.WbpT = WbpT; a.bbp = P[7]; a.WspT = WspT; a.bsp = P[9]; a.WbqT = WbqT; a.bbq = P[11]; a.WsqT = WsqT; a.bsq = P[13];
   a.prev_belief = prev_belief; a.prev_state = prev_state; a.actions = actions; a.nonterms = nonterms;
   a.eemb = eemb;
+  a.prior_only = prior_only;
   a.eps_prior = NoiseSrc{eps_prior, noise_seed, noise_offset};
   a.eps_post = NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)};
   a.featx = featx; a.prior_state = prior_state; a.prior_mean = prior_mean; a.prior_std = prior_std;

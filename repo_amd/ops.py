@@ -230,7 +230,7 @@ class ObserveSaved:
 
 
 def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds, eps_prior, eps_post, min_std=0.1,
-                     noise=(0, 0)):
+                     noise=(0, 0), prior_only=False):
     """params: list of the 14 TransitionModel tensors in state_dict order.  Time-major inputs.
     eps_prior = eps_post = None: the kernel draws its noise from Philox stream noise = (seed, offset)."""
     T, B, A = actions.shape
@@ -260,7 +260,7 @@ def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds,
             _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior), _ptr(sv.eps_post), sv.noise[0], sv.noise[1],
             float(min_std), _ptr(sv.featx), _ptr(sv.prior_state), _ptr(sv.prior_mean), _ptr(sv.prior_std), _ptr(sv.post_mean),
             _ptr(sv.post_std), _ptr(sv.xsa), _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(eemb),
-            _ptr(ws), ws.numel(), _stream(),
+            int(prior_only), _ptr(ws), ws.numel(), _stream(),
         ),
         "repo_rssm_observe_fwd",
     )

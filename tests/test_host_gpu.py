@@ -514,7 +514,7 @@ def test_load_reference_format_checkpoint():
     ck["beta_optimizer"] = adam_state([ck["log_beta"].detach()], 1e-4)
     agent.load_param_dict(ck)
     back = agent.get_param_dict()
-    assert back["step"] == 4321 and float(back["log_beta"]) == -7.25
+    assert back["step"] == 4321 and float(back["log_beta"].detach()) == -7.25
     for mod in fx.MODULES:
         for k, v in ck[mod].items():
             assert torch.equal(back[mod][k].cpu(), v), (mod, k)

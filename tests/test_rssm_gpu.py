@@ -313,3 +313,35 @@ def test_update_with_in_kernel_noise_equals_explicit_tensors(A, fused):
         assert drawn.last_scalars == fed.last_scalars, (u, drawn.last_scalars, fed.last_scalars)
         for name in ("model_optimizer", "actor_optimizer", "value_optimizer"):
             assert torch.equal(getattr(drawn, name).flat, getattr(fed, name).flat), (u, name)
+
+
+def test_observe_without_observations_prior_only_rollout():
+    """TransitionModel.observe(observations=None) (reference rssm.py:112-146): open-loop rollout under given actions,
+    the next step fed the nonterminal-masked PRIOR sample; four outputs."""
+    from tests.test_update_gpu import make_agent
+
+    A, T, B = 6, 9, 5
+    agent, cfg = make_agent("repo", 8, 4, 5, A)
+    p = ro.OracleAgent(cfg, A, seed=7).p["transition_model"]
+    rs = np.random.RandomState(3)
+    b0 = torch.from_numpy(rs.standard_normal((B, 200)).astype(np.float32) * 0.3)
+    s0 = torch.from_numpy(rs.standard_normal((B, 30)).astype(np.float32))
+    act = torch.from_numpy(rs.uniform(-1, 1, (T, B, A)).astype(np.float32))
+    non = torch.ones(T, B, 1)
+    non[3, 1] = 0
+    non[5, 4] = 0
+    eps = torch.from_numpy(rs.standard_normal((T, B, 30)).astype(np.float32))
+    with torch.no_grad():
+        bel, st, want = b0, s0, [[], [], [], []]
+        for t in range(T):
+            bel = ro.compute_belief(p, bel, st * non[t], act[t])
+            smp, mean, std = ro.gaussian_head(p, "fc_embed_belief_prior", "fc_state_prior", bel, eps[t])
+            st = smp
+            for lst, v in zip(want, (bel, smp, mean, std)):
+                lst.append(v)
+        want = [torch.stack(w) for w in want]
+    got = agent.transition_model.observe(b0.cuda(), s0.cuda(), act.cuda(), None, non.cuda(), noise=(eps.cuda(),))
+    assert len(got) == 4
+    for g, w, name in zip(got, want, ("beliefs", "prior_states", "prior_means", "prior_std_devs")):
+        assert tuple(g.shape) == tuple(w.shape)
+        np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
