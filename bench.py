@@ -20,7 +20,7 @@ RANK/WORLD_SIZE it runs as that rank.  Rank 0 prints ONE JSON line; `n_gpus` is 
 process group saw.
 
 `roofline` is for the dominant kernel (the largest single launch: the decoder's 64->32 transposed
-convolution, `dconv_up_kernel<GDec3>`): algorithmic FLOPs of that launch / its average duration measured
+convolution, `uconv_scatter_kernel<GDec3>`): algorithmic FLOPs of that launch / its average duration measured
 with HIP events recorded on its launch stream INSIDE the timed updates.  `traffic` comes from the
 rocprofv3 --pmc summary committed under profiles/ (named in `traffic_source`), never from this run.
 `cpu_baseline` is the CPU oracle (PyTorch fp32 restatement of the reference) timed on this box's host
@@ -181,7 +181,7 @@ def roofline(timer, nimg):
     out = {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "dconv_up_kernel<Geo<32,64,30,6>> (decoder conv3 forward)",
+        "kernel": "uconv_scatter_kernel<Geo<32,64,30,6>> (decoder conv3 forward)",
         "ms_per_launch": round(ms, 4), "launches_timed": len(timer.pairs), "flop_per_launch": flop,
         "timing": "HIP events on the launch stream inside the timed updates (other streams of the update run beside it)",
         "isolated_ms_per_launch": round(iso, 4),
