@@ -194,6 +194,7 @@ int philox_fill(float* out, long n, uint64_t seed, uint64_t offset, hipStream_t 
 // persistent row-tiled rollout (imagine_fused.hip)
 bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers);
 size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
+size_t imagine_fused_bwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
 int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
                       const float* const* ap, const float* belief0, const float* state0, NoiseSrc eps_act,
                       NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std, float a_mean_scale,
@@ -205,7 +206,7 @@ int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
                       float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
                       const float* a_std, const float* xsa, const float* e, const float* gates, const float* hp,
                       const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
-                      float* dfeat0, hipStream_t stream);
+                      float* dfeat0, void* ws, hipStream_t stream);
 
 }  // namespace repo
 
@@ -390,7 +391,9 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
 extern "C" size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S) {
   // g(F) carry(F) dpout(2S) dhp(Hd) dbel(D) dgi(3D) dgh(3D) de(D) dxsa(S+A) + the two noise tensors
-  return ((size_t)N * (2 * (D + S) + 2 * S + Hd + D + 6 * D + D + (S + A)) + (size_t)Hm * N * (A + S)) * sizeof(float);
+  const size_t unfused = ((size_t)N * (2 * (D + S) + 2 * S + Hd + D + 6 * D + D + (S + A)) + (size_t)Hm * N * (A + S)) * sizeof(float);
+  const size_t fused = imagine_fused_bwd_ws_floats(A, D, Hd, S) * sizeof(float);
+  return unfused > fused ? unfused : fused;
 }
 
 extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
@@ -411,7 +414,7 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
     return imagine_fused_bwd(Hm, N, A, D, Hd, S, rssm_params, NoiseSrc{eps_act, noise_seed, noise_offset},
                              NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_mean_scale,
                              featx, prior_std, a_mean, a_std, xsa, e, gates, hp, dfeat, dprior_mean, dprior_std,
-                             d_araw, dfeat0, stream);
+                             d_araw, dfeat0, ws, stream);
   const int64_t F = D + S, X = S + A;
   const float* const* P = rssm_params;
   float* w = (float*)ws;

@@ -1,0 +1,630 @@
+// Persistent, row-tiled imagination rollout (forward and reverse pass) on 16-row tiles.
+//
+// Imagined rows are independent across ALL H-1 steps (each row is the child of one posterior state), so one
+// workgroup owns a tile of rows for the whole rollout: no kernel boundary, no grid synchronisation, activations
+// of a step never leave the CU.  Per step a workgroup runs the actor trunk (5 dense layers), the tanh-Normal
+// sample, fc_embed_state_action, the GRU and the prior head back to back.
+//
+// Round 1 used 32-row tiles on v_mfma_f32_32x32x2_f32: 2450 start states -> 77 workgroups on 256 CUs, 107 us per
+// step.  The rollout is a chain of 11 dependent layers x 14 steps, so its duration is (steps x per-tile latency),
+// not work / chip: here a tile is 16 rows on v_mfma_f32_16x16x4_f32 -- 154 workgroups, half the MFMA work per
+// tile and step.  What makes 16 rows affordable is the operand traffic: per FLOP a 16-row tile streams twice the
+// weights of a 32-row one, so both MFMA operands move 16 bytes per lane per 4 k-steps:
+//   * activations live in LDS "k4-interleaved": element (k, row) at ((k/4)*16 + row)*4 + k%4, so the A fragments
+//     of four consecutive k-steps are ONE ds_read_b128 (k-step j of a 16-k block feeds lane quarter q the k
+//     16b + 4q + j -- any assignment of the block's 16 k to (quarter, step) is a valid MFMA schedule as long as
+//     both operands use it);
+//   * weights are packed the same way ([k/4][n][4], zero-padded to a multiple of 16 k; ONE pack launch per call
+//     for all ten matrices): the B fragments of four k-steps are one 16-byte global load, issued for the whole
+//     K range of a column-tile pair before its first MFMA;
+//   * a wave owns column tiles w and w+8 of a layer and runs them as two interleaved accumulator chains
+//     (the GRU pairs r with z and the two n products).
+// Padding columns of the activation tiles (K -> multiple of 16) are zeroed once and never written.
+// (S + A) may be odd (ManiSkill's A = 7): K is padded, not paired.
+//
+// Reference: TransitionModel.imagine + ActorModel.get_action (models/rssm.py:148-184,
+// models/actor_critic.py:76-102) and autograd's backward through them (dreamer.py:357).
+#include "common.h"
+
+namespace repo {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kR = 16;      // rows per workgroup
+constexpr int kW = 8;       // waves per workgroup (512 threads)
+constexpr int kMaxBlk = 15; // K <= 240
+
+__host__ __device__ constexpr int pad16(int k) { return (k + 15) & ~15; }
+// k4-interleaved activation tile: element (k, row)
+__device__ __forceinline__ int ai(int k, int row) { return (((k >> 2) * kR + row) << 2) + (k & 3); }
+
+// ---- weight pack: dst[(kg*N + n)*4 + u] = W(n, 4kg+u) = src[n*sn + (4kg+u)*sk] for 4kg+u < K, else 0; kg < pad16(K)/4
+struct PackJob {
+  const float* src;
+  float* dst;
+  int N, K, sn, sk;
+};
+constexpr int kMaxJobs = 12;
+struct PackArgs {
+  PackJob job[kMaxJobs];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void pack16_kernel(PackArgs a) {
+  const PackJob j = a.job[blockIdx.y];
+  const int total = pad16(j.K) * j.N;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int u = i & 3, q = i >> 2;
+    const int n = q % j.N, k = 4 * (q / j.N) + u;
+    j.dst[i] = k < j.K ? j.src[(size_t)n * j.sn + (size_t)k * j.sk] : 0.f;
+  }
+}
+static size_t pack_floats(int64_t N, int64_t K) { return (size_t)pad16((int)K) * N; }
+
+// acc0 (+ acc1) += A[16 x K] * packed W column tile.  A0/A1: LDS tiles (k4-interleaved), W0/W1: packs with N0/N1
+// columns, col0/col1: this lane's (clamped) column.  The B fragments run kPD blocks (kPD * 8 MFMAs = ~1300 cycles,
+// an L2 round trip) ahead of the MFMAs in a rotating register window.
+constexpr int kPD = 5;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+// W0/W1 are BYTE offsets of the packs inside the buffer `rw` (wave-uniform): a block's address is
+// lane part (VGPR, one per call) + scalar offset -- a 64-bit VGPR address per block and call site would be
+// hoisted out of the step loop by the compiler and spill everything else.
+template <int NBLK>
+__device__ __forceinline__ void mma_pair_t(f32x4v& acc0, f32x4v& acc1, const float* A0, const float* A1,
+                                           __amdgpu_buffer_rsrc_t rw, unsigned W0, int N0, int col0, unsigned W1,
+                                           int N1, int col1, bool two, int lane) {
+  const int row = lane & 15, kq = lane >> 4;
+  constexpr int PD = NBLK < kPD ? NBLK : kPD;
+  f32x4v b0[PD], b1[PD];
+  const unsigned v0 = 16u * (unsigned)(kq * N0 + col0), v1 = 16u * (unsigned)(kq * N1 + col1);
+  const unsigned s0 = 64u * (unsigned)N0, s1 = 64u * (unsigned)N1;  // bytes per 16-k block of a pack
+  auto ld = [&](unsigned v, unsigned so) {
+    return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, v, so, 0));
+  };
+#pragma unroll
+  for (int b = 0; b < PD; ++b) {
+    b0[b] = ld(v0, W0 + b * s0);
+    if (two) b1[b] = ld(v1, W1 + b * s1);
+  }
+  const float* a0p = A0 + (kq * kR + row) * 4;
+  const float* a1p = A1 + (kq * kR + row) * 4;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const f32x4v a0 = *reinterpret_cast<const f32x4v*>(a0p + b * 16 * kR);
+    const f32x4v a1 = (A1 == A0) ? a0 : *reinterpret_cast<const f32x4v*>(a1p + b * 16 * kR);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[b % PD][j], acc0, 0, 0, 0);
+      if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[b % PD][j], acc1, 0, 0, 0);
+    }
+    if (b + PD < NBLK) {
+      b0[b % PD] = ld(v0, W0 + (b + PD) * s0);
+      if (two) b1[b % PD] = ld(v1, W1 + (b + PD) * s1);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the window: no hoisting of later blocks' loads
+  }
+}
+// Dense layer on the row tile: wave w owns column tiles w and w + 8.  epi(valid, n, acc): n = this lane's column,
+// acc[r] belongs to row 4*(lane>>4) + r.
+template <int NBLK, class Epi>
+__device__ __forceinline__ void dense16(const float* A, __amdgpu_buffer_rsrc_t rw, unsigned W, int N, int wave, int lane,
+                                        Epi epi) {
+  const int ntiles = (N + 15) >> 4;
+  const int t0 = wave, t1 = wave + kW;
+  if (t0 >= ntiles) return;
+  const bool two = t1 < ntiles;
+  const int n = lane & 15;
+  const int c0 = t0 * 16 + n, c1 = t1 * 16 + n;
+  f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  mma_pair_t<NBLK>(acc0, acc1, A, A, rw, W, N, min(c0, N - 1), W, N, min(c1, N - 1), two, lane);
+  epi(c0 < N, c0, acc0);
+  if (two) epi(c1 < N, c1, acc1);
+}
+
+struct ImgDims {
+  int Hm, N, A, D, Hd, S;
+};
+
+struct ImgFwdArgs {
+  ImgDims d;
+  const float* wpack;  // all packs, contiguous
+  unsigned wbytes;
+  unsigned aW[5];      // byte offsets of the packed actor weights
+  const float* ab[5];
+  unsigned Wsa, Wih, Whh, Wbp, Wsp;
+  const float *bsa, *bih, *bhh, *bbp, *bsp;
+  const float *belief0, *state0;
+  NoiseSrc eps_act, eps_prior;
+  float min_std, a_min_std, a_init_std, a_mean_scale;
+  float *featx, *prior_mean, *prior_std, *a_hidden, *a_raw, *a_mean, *a_std, *xsa, *e, *gates, *hp;
+  size_t a_layer_rows;
+};
+
+// BF / BW / BX / BS: 16-k blocks of F = D + S, of D and Hd, of X = S + A, of 2 S
+template <int BF, int BW, int BX, int BS>
+__global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int Hm = p.d.Hm, N = p.d.N, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
+  const int F = D + S, X = S + A;
+  const int FP = pad16(F), WP = pad16(max(D, Hd)), XP = pad16(X), SP = pad16(max(2 * A, 2 * S));
+  float* Fa = lds;               // [FP x 16]  current [belief|state]
+  float* Fb = Fa + FP * kR;      // next
+  float* HA = Fb + FP * kR;      // [WP x 16]
+  float* HB = HA + WP * kR;
+  float* XS = HB + WP * kR;      // [XP x 16]  [state|action]
+  float* SM = XS + XP * kR;      // [SP x 16]
+  const int lds_floats = (2 * FP + 2 * WP + XP + SP) * kR;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane >> 4;
+  const int r0 = blockIdx.x * kR;
+  const int nr = min(kR, N - r0);
+  const size_t rowsAll = p.a_layer_rows;  // row stride between the saved actor layers
+  const __amdgpu_buffer_rsrc_t rw = wrsrc(p.wpack, p.wbytes);
+
+  for (int i = tid; i < lds_floats / 4; i += 512) reinterpret_cast<f32x4v*>(lds)[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  // ---- slot 0: start states (row-major global -> tile), also echoed to featx[0]
+  for (int i = tid; i < kR * F; i += 512) {
+    const int row = i / F, f = i % F;
+    if (row < nr) {
+      const float v = f < D ? p.belief0[(size_t)(r0 + row) * D + f] : p.state0[(size_t)(r0 + row) * S + (f - D)];
+      p.featx[(size_t)(r0 + row) * F + f] = v;
+      Fa[ai(f, row)] = v;
+    }
+  }
+  __syncthreads();
+
+  float* Fc = Fa;
+  float* Fn = Fb;
+  for (int t = 0; t < Hm; ++t) {
+    const size_t rb = (size_t)t * N + r0;  // first global row of this tile at step t
+    // ---------------- actor trunk: 4 ELU layers + linear head
+    auto hidden_epi = [&](float* dst, const float* bias, float* save) {
+      return [=](bool ok, int n, const f32x4v& acc) {
+        if (!ok) return;
+        const float bv = bias[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * lq + r;
+          const float v = elu(acc[r] + bv);
+          dst[ai(n, m)] = v;
+          if (m < nr) save[(rb + m) * Hd + n] = v;
+        }
+      };
+    };
+    dense16<BF>(Fc, rw, p.aW[0], Hd, wave, lane, hidden_epi(HA, p.ab[0], p.a_hidden));
+    __syncthreads();
+    dense16<BW>(HA, rw, p.aW[1], Hd, wave, lane, hidden_epi(HB, p.ab[1], p.a_hidden + rowsAll * Hd));
+    __syncthreads();
+    dense16<BW>(HB, rw, p.aW[2], Hd, wave, lane, hidden_epi(HA, p.ab[2], p.a_hidden + 2 * rowsAll * Hd));
+    __syncthreads();
+    dense16<BW>(HA, rw, p.aW[3], Hd, wave, lane, hidden_epi(HB, p.ab[3], p.a_hidden + 3 * rowsAll * Hd));
+    __syncthreads();
+    dense16<BW>(HB, rw, p.aW[4], 2 * A, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+      if (!ok) return;
+      const float bv = p.ab[4][n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * lq + r;
+        const float v = acc[r] + bv;
+        SM[ai(n, m)] = v;
+        if (m < nr) p.a_raw[(rb + m) * 2 * A + n] = v;
+      }
+    });
+    __syncthreads();
+    // ---------------- tanh-Normal action sample; x = [state, action]
+    for (int i = tid; i < kR * X; i += 512) {
+      const int row = i / X, k = i % X;
+      float v;
+      if (k < S) {
+        v = Fc[ai(D + k, row)];
+      } else {
+        const int a = k - S;
+        const float mu = p.a_mean_scale * tanh_fast(SM[ai(a, row)] / p.a_mean_scale);
+        const float sd = softplus(SM[ai(A + a, row)] + p.a_init_std) + p.a_min_std;
+        const float ep = row < nr ? p.eps_act.at((rb + row) * A + a) : 0.f;
+        v = tanh_fast(fmaf(sd, ep, mu));
+        if (row < nr) {
+          p.a_mean[(rb + row) * A + a] = mu;
+          p.a_std[(rb + row) * A + a] = sd;
+        }
+      }
+      XS[ai(k, row)] = v;
+      if (row < nr) p.xsa[(rb + row) * X + k] = v;
+    }
+    __syncthreads();
+    // ---------------- e = elu(W_sa x + b)
+    dense16<BX>(XS, rw, p.Wsa, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+      if (!ok) return;
+      const float bv = p.bsa[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * lq + r;
+        const float v = elu(acc[r] + bv);
+        HA[ai(n, m)] = v;
+        if (m < nr) p.e[(rb + m) * D + n] = v;
+      }
+    });
+    __syncthreads();
+    // ---------------- GRU: the gate pre-activations of a column tile stay in one wave
+    {
+      const int ntiles = (D + 15) >> 4;
+      for (int ct = wave; ct < ntiles; ct += kW) {
+        const int n = ct * 16 + (lane & 15);
+        const int col = min(n, D - 1);
+        // r and z only need gi + gh: both products accumulate into one tile
+        f32x4v ar = {0.f, 0.f, 0.f, 0.f}, az = ar, gin = ar, ghn_ = ar;
+        mma_pair_t<BW>(ar, az, HA, HA, rw, p.Wih, 3 * D, col, p.Wih, 3 * D, D + col, true, lane);
+        mma_pair_t<BW>(ar, az, Fc, Fc, rw, p.Whh, 3 * D, col, p.Whh, 3 * D, D + col, true, lane);
+        mma_pair_t<BW>(gin, ghn_, HA, Fc, rw, p.Wih, 3 * D, 2 * D + col, p.Whh, 3 * D, 2 * D + col, true, lane);
+        if (n < D) {
+          const float br = p.bih[n] + p.bhh[n], bz = p.bih[D + n] + p.bhh[D + n];
+          const float bin = p.bih[2 * D + n], bhn = p.bhh[2 * D + n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 4 * lq + r;
+            const float rg = sigmoidf(ar[r] + br);
+            const float zg = sigmoidf(az[r] + bz);
+            const float ghn = ghn_[r] + bhn;
+            const float ng = tanh_fast(gin[r] + bin + rg * ghn);
+            const float hprev = Fc[ai(n, m)];
+            const float hn = (1.f - zg) * ng + zg * hprev;
+            Fn[ai(n, m)] = hn;
+            if (m < nr) {
+              float* g = p.gates + (rb + m) * 4 * D;
+              g[n] = rg;
+              g[D + n] = zg;
+              g[2 * D + n] = ng;
+              g[3 * D + n] = ghn;
+              p.featx[((size_t)(t + 1) * N + r0 + m) * F + n] = hn;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- prior head
+    dense16<BW>(Fn, rw, p.Wbp, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+      if (!ok) return;
+      const float bv = p.bbp[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * lq + r;
+        const float v = elu(acc[r] + bv);
+        HB[ai(n, m)] = v;
+        if (m < nr) p.hp[(rb + m) * Hd + n] = v;
+      }
+    });
+    __syncthreads();
+    dense16<BW>(HB, rw, p.Wsp, 2 * S, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+      if (!ok) return;
+      const float bv = p.bsp[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) SM[ai(n, 4 * lq + r)] = acc[r] + bv;
+    });
+    __syncthreads();
+    for (int i = tid; i < kR * S; i += 512) {
+      const int row = i / S, s = i % S;
+      const float mu = SM[ai(s, row)];
+      const float sd = softplus(SM[ai(S + s, row)]) + p.min_std;
+      float smp = mu;
+      if (row < nr) {
+        const size_t o = (rb + row) * S + s;
+        smp = fmaf(sd, p.eps_prior.at(o), mu);
+        p.prior_mean[o] = mu;
+        p.prior_std[o] = sd;
+        p.featx[((size_t)(t + 1) * N + r0 + row) * F + D + s] = smp;
+      }
+      Fn[ai(D + s, row)] = smp;
+    }
+    __syncthreads();
+    float* tmp = Fc;
+    Fc = Fn;
+    Fn = tmp;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ reverse pass
+struct ImgBwdArgs {
+  ImgDims d;
+  // packs with the reduction over the layer's OUTPUT index: W'(n = input index, k = output index)
+  const float* wpack;
+  unsigned wbytes;
+  unsigned Wsp, Wbp, Whh[3], Wih[3], Wsa;
+  NoiseSrc eps_act, eps_prior;
+  float min_std, a_min_std, a_mean_scale;
+  const float *featx, *prior_std, *a_mean, *a_std, *xsa, *e, *gates, *hp;
+  const float *dfeat, *dprior_mean, *dprior_std;
+  float *d_araw, *dfeat0;
+};
+
+template <int BF, int BW, int BX, int BS>
+__global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int Hm = p.d.Hm, N = p.d.N, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
+  const int F = D + S, X = S + A;
+  const int DP = pad16(D), SP = pad16(max(2 * S, X)), WP = pad16(max(D, Hd));
+  float* Gb = lds;              // [DP x 16]  grad on belief_{t+1} (carry + dfeat)
+  float* Gs = Gb + DP * kR;     // [pad16(S) x 16]  grad on state_{t+1}
+  float* SM = Gs + pad16(S) * kR;  // [SP x 16]   d prior-head outputs, later d [state|action]
+  float* X1 = SM + SP * kR;
+  float* X2 = X1 + WP * kR;
+  float* X3 = X2 + WP * kR;
+  float* X4 = X3 + WP * kR;
+  const int lds_floats = (DP + pad16(S) + SP + 4 * WP) * kR;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane >> 4;
+  const int r0 = blockIdx.x * kR;
+  const int nr = min(kR, N - r0);
+  const __amdgpu_buffer_rsrc_t rw = wrsrc(p.wpack, p.wbytes);
+
+  for (int i = tid; i < lds_floats / 4; i += 512) reinterpret_cast<f32x4v*>(lds)[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int t = Hm - 1; t >= 0; --t) {
+    const size_t rb = (size_t)t * N + r0;
+    // ---- G += dfeat[t]
+    for (int i = tid; i < kR * F; i += 512) {
+      const int row = i / F, f = i % F;
+      if (row < nr) {
+        float* g = f < D ? &Gb[ai(f, row)] : &Gs[ai(f - D, row)];
+        *g += p.dfeat[(rb + row) * F + f];
+      }
+    }
+    __syncthreads();
+    // ---- prior head: sample / mean / std gradients -> d [mean | raw_std]
+    for (int i = tid; i < kR * S; i += 512) {
+      const int row = i / S, s = i % S;
+      float gm = 0.f, gr = 0.f;
+      if (row < nr) {
+        const size_t o = (rb + row) * S + s;
+        const float ds = Gs[ai(s, row)];
+        gm = ds + (p.dprior_mean ? p.dprior_mean[o] : 0.f);
+        const float gs = fmaf(ds, p.eps_prior.at(o), p.dprior_std ? p.dprior_std[o] : 0.f);
+        gr = gs * (-expm1f(-(p.prior_std[o] - p.min_std)));
+      }
+      SM[ai(s, row)] = gm;
+      SM[ai(S + s, row)] = gr;
+    }
+    __syncthreads();
+    // ---- X1 = (d out @ W_sp) * elu'(hp)
+    dense16<BS>(SM, rw, p.Wsp, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+      if (!ok) return;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * lq + r;
+        const float h = m < nr ? p.hp[(rb + m) * Hd + n] : 0.f;
+        X1[ai(n, m)] = acc[r] * elu_grad_from_out(h);
+      }
+    });
+    __syncthreads();
+    // ---- X2 = d belief_{t+1} = Gb + X1 @ W_bp
+    dense16<BW>(X1, rw, p.Wbp, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+      if (!ok) return;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * lq + r;
+        X2[ai(n, m)] = acc[r] + Gb[ai(n, m)];
+      }
+    });
+    __syncthreads();
+    // ---- GRU gates (element-wise): X2 <- g_r, X1 <- g_z, X3 <- g_n, X4 <- g_n * r, Gb <- d * z
+    for (int i = tid; i < kR * D; i += 512) {
+      const int row = i / D, n = i % D;
+      float g_r = 0.f, g_z = 0.f, g_n = 0.f, g_hn = 0.f, dhp = 0.f;
+      if (row < nr) {
+        const float* g = p.gates + (rb + row) * 4 * D;
+        const float rg = g[n], zg = g[D + n], ng = g[2 * D + n], ghn = g[3 * D + n];
+        const float hprev = p.featx[((size_t)t * N + r0 + row) * F + n];
+        const float d = X2[ai(n, row)];
+        g_n = d * (1.f - zg) * (1.f - ng * ng);
+        g_z = d * (hprev - ng) * zg * (1.f - zg);
+        g_r = g_n * ghn * rg * (1.f - rg);
+        g_hn = g_n * rg;
+        dhp = d * zg;
+      }
+      X2[ai(n, row)] = g_r;
+      X1[ai(n, row)] = g_z;
+      X3[ai(n, row)] = g_n;
+      X4[ai(n, row)] = g_hn;
+      Gb[ai(n, row)] = dhp;
+    }
+    __syncthreads();
+    // ---- through W_hh into belief_t (new carry) and through W_ih into e; both from the same tiles
+    {
+      const int ntiles = (D + 15) >> 4;  // <= 2 * kW: results of tiles w, w+8 are held across the barrier
+      f32x4v ah[2], ae[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        ae[i] = ah[i];
+        const int ct = wave + i * kW;
+        if (ct < ntiles) {
+          const int col = min(ct * 16 + (lane & 15), D - 1);
+          mma_pair_t<BW>(ah[i], ae[i], X2, X2, rw, p.Whh[0], D, col, p.Wih[0], D, col, true, lane);
+          mma_pair_t<BW>(ah[i], ae[i], X1, X1, rw, p.Whh[1], D, col, p.Wih[1], D, col, true, lane);
+          mma_pair_t<BW>(ah[i], ae[i], X4, X3, rw, p.Whh[2], D, col, p.Wih[2], D, col, true, lane);
+        }
+      }
+      __syncthreads();  // every wave has finished reading X1..X4
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = (wave + i * kW) * 16 + (lane & 15);
+        if (wave + i * kW < ntiles && n < D) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 4 * lq + r;
+            Gb[ai(n, m)] += ah[i][r];
+            const float ev = m < nr ? p.e[(rb + m) * D + n] : 0.f;
+            X4[ai(n, m)] = ae[i][r] * elu_grad_from_out(ev);  // d pre-activation of fc_embed_state_action
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- d [state_t | action_t] = X4 @ W_sa
+    dense16<BW>(X4, rw, p.Wsa, X, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+      if (!ok) return;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * lq + r;
+        if (n < S) Gs[ai(n, m)] = acc[r];
+        else SM[ai(n, m)] = acc[r];
+      }
+    });
+    __syncthreads();
+    // ---- tanh-Normal sample backward -> gradient at the actor trunk's output of step t
+    for (int i = tid; i < kR * A; i += 512) {
+      const int row = i / A, a = i % A;
+      if (row < nr) {
+        const size_t o = (rb + row) * A + a;
+        const float act = p.xsa[(rb + row) * X + S + a];
+        const float du = SM[ai(S + a, row)] * (1.f - act * act);
+        const float tm = p.a_mean[o] / p.a_mean_scale;
+        p.d_araw[(rb + row) * 2 * A + a] = du * (1.f - tm * tm);
+        p.d_araw[(rb + row) * 2 * A + A + a] = du * p.eps_act.at(o) * (-expm1f(-(p.a_std[o] - p.a_min_std)));
+      }
+    }
+    __syncthreads();
+  }
+  if (p.dfeat0) {
+    for (int i = tid; i < kR * F; i += 512) {
+      const int row = i / F, f = i % F;
+      if (row < nr) p.dfeat0[(size_t)(r0 + row) * F + f] = f < D ? Gb[ai(f, row)] : Gs[ai(f - D, row)];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+// The kernels are instantiated for the reference architecture's block counts: belief = hidden = 200 (13 blocks of
+// 16 k), belief + state = 230 (15), state + action 33..48 (3: A = 6 and ManiSkill's A = 7), 2 * state = 60 (4);
+// any other size runs the per-step engine (imagine.hip).
+constexpr int kBF = 15, kBW = 13, kBX = 3, kBS = 4;
+bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers) {
+  auto blk = [](int64_t k) { return pad16((int)k) >> 4; };
+  return n_actor_layers == 5 && blk(D) == kBW && blk(Hd) == kBW && blk(D + S) == kBF && blk(S + A) == kBX &&
+         blk(2 * S) == kBS && 2 * A <= 16 && (Hm + 1) * N * 4 * D < kMaxIdx;
+}
+
+size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  return pack_floats(Hd, D + S) + 3 * pack_floats(Hd, Hd) + pack_floats(2 * A, Hd) + pack_floats(D, S + A) +
+         2 * pack_floats(3 * D, D) + pack_floats(Hd, D) + pack_floats(2 * S, Hd);
+}
+size_t imagine_fused_bwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  return pack_floats(Hd, 2 * S) + pack_floats(D, Hd) + 6 * pack_floats(D, D) + pack_floats(S + A, D);
+}
+
+static int launch_pack(PackArgs& pa, hipStream_t s) {
+  int mx = 1;
+  for (int i = 0; i < pa.njobs; ++i) {
+    const int blocks = (pad16(pa.job[i].K) * pa.job[i].N + 255) / 256;
+    if (blocks > mx) mx = blocks;
+  }
+  if (mx > 256) mx = 256;
+  hipLaunchKernelGGL(pack16_kernel, dim3(mx, pa.njobs), dim3(256), 0, s, pa);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
+                      const float* const* rp, const float* const* ap, const float* belief0, const float* state0,
+                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std,
+                      float a_mean_scale, float* featx, float* prior_mean, float* prior_std, float* a_hidden,
+                      int64_t a_layer_rows, float* a_raw, float* a_mean, float* a_std, float* xsa, float* e,
+                      float* gates, float* hp, void* ws, hipStream_t stream) {
+  const int F = (int)(D + S), X = (int)(S + A);
+  float* w = (float*)ws;
+  ImgFwdArgs a;
+  a.d = ImgDims{(int)Hm, (int)N, (int)A, (int)D, (int)Hd, (int)S};
+  PackArgs pa;
+  pa.njobs = 0;
+  float* const w_begin = w;
+  auto add = [&](const float* src, int Nn, int K, int sn, int sk) {
+    pa.job[pa.njobs++] = PackJob{src, w, Nn, K, sn, sk};
+    const unsigned r = (unsigned)((w - w_begin) * sizeof(float));
+    w += pack_floats(Nn, K);
+    return r;
+  };
+  const int kin[5] = {F, (int)Hd, (int)Hd, (int)Hd, (int)Hd};
+  const int nout[5] = {(int)Hd, (int)Hd, (int)Hd, (int)Hd, (int)(2 * A)};
+  for (int l = 0; l < 5; ++l) {
+    a.aW[l] = add(ap[2 * l], nout[l], kin[l], kin[l], 1);
+    a.ab[l] = ap[2 * l + 1];
+  }
+  a.Wsa = add(rp[0], (int)D, X, X, 1);
+  a.Wih = add(rp[2], (int)(3 * D), (int)D, (int)D, 1);
+  a.Whh = add(rp[3], (int)(3 * D), (int)D, (int)D, 1);
+  a.Wbp = add(rp[6], (int)Hd, (int)D, (int)D, 1);
+  a.Wsp = add(rp[8], (int)(2 * S), (int)Hd, (int)Hd, 1);
+  a.wpack = w_begin;
+  a.wbytes = (unsigned)((w - w_begin) * sizeof(float));
+  int rc = launch_pack(pa, stream);
+  if (rc) return rc;
+  a.bsa = rp[1]; a.bih = rp[4]; a.bhh = rp[5]; a.bbp = rp[7]; a.bsp = rp[9];
+  a.belief0 = belief0; a.state0 = state0; a.eps_act = eps_act; a.eps_prior = eps_prior;
+  a.min_std = min_std; a.a_min_std = a_min_std; a.a_init_std = a_init_std; a.a_mean_scale = a_mean_scale;
+  a.featx = featx; a.prior_mean = prior_mean; a.prior_std = prior_std; a.a_hidden = a_hidden; a.a_raw = a_raw;
+  a.a_mean = a_mean; a.a_std = a_std; a.xsa = xsa; a.e = e; a.gates = gates; a.hp = hp;
+  a.a_layer_rows = (size_t)a_layer_rows;
+  const int W = (int)(D > Hd ? D : Hd), SMr = (int)(2 * A > 2 * S ? 2 * A : 2 * S);
+  const size_t lds_b = (size_t)(2 * pad16(F) + 2 * pad16(W) + pad16(X) + pad16(SMr)) * kR * sizeof(float);
+  hipError_t he = hipFuncSetAttribute((const void*)imagine_fwd_kernel<kBF, kBW, kBX, kBS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_b);
+  if (he != hipSuccess) return (int)he;
+  hipLaunchKernelGGL((imagine_fwd_kernel<kBF, kBW, kBX, kBS>), dim3((unsigned)((N + kR - 1) / kR)), dim3(512), lds_b, stream, a);
+  he = hipGetLastError();
+  return he == hipSuccess ? REPO_OK : (int)he;
+}
+
+int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
+                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std,
+                      float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
+                      const float* a_std, const float* xsa, const float* e, const float* gates, const float* hp,
+                      const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
+                      float* dfeat0, void* ws, hipStream_t stream) {
+  const int X = (int)(S + A);
+  float* w = (float*)ws;
+  ImgBwdArgs a;
+  a.d = ImgDims{(int)Hm, (int)N, (int)A, (int)D, (int)Hd, (int)S};
+  PackArgs pa;
+  pa.njobs = 0;
+  // W'(n = input index, k = output index) = native[k * ld + n]
+  float* const w_begin = w;
+  auto add = [&](const float* src, int Nin, int Kout, int ld) {
+    pa.job[pa.njobs++] = PackJob{src, w, Nin, Kout, 1, ld};
+    const unsigned r = (unsigned)((w - w_begin) * sizeof(float));
+    w += pack_floats(Nin, Kout);
+    return r;
+  };
+  a.Wsp = add(rp[8], (int)Hd, (int)(2 * S), (int)Hd);
+  a.Wbp = add(rp[6], (int)D, (int)Hd, (int)D);
+  for (int g = 0; g < 3; ++g) {
+    a.Whh[g] = add(rp[3] + (size_t)g * D * D, (int)D, (int)D, (int)D);
+    a.Wih[g] = add(rp[2] + (size_t)g * D * D, (int)D, (int)D, (int)D);
+  }
+  a.Wsa = add(rp[0], X, (int)D, X);
+  a.wpack = w_begin;
+  a.wbytes = (unsigned)((w - w_begin) * sizeof(float));
+  int rc = launch_pack(pa, stream);
+  if (rc) return rc;
+  a.eps_act = eps_act; a.eps_prior = eps_prior;
+  a.min_std = min_std; a.a_min_std = a_min_std; a.a_mean_scale = a_mean_scale;
+  a.featx = featx; a.prior_std = prior_std; a.a_mean = a_mean; a.a_std = a_std; a.xsa = xsa; a.e = e;
+  a.gates = gates; a.hp = hp; a.dfeat = dfeat; a.dprior_mean = dprior_mean; a.dprior_std = dprior_std;
+  a.d_araw = d_araw; a.dfeat0 = dfeat0;
+  const int W = (int)(D > Hd ? D : Hd), SMr = (int)(2 * S > X ? 2 * S : X);
+  const size_t lds_b = (size_t)(pad16((int)D) + pad16((int)S) + pad16(SMr) + 4 * pad16(W)) * kR * sizeof(float);
+  hipError_t he = hipFuncSetAttribute((const void*)imagine_bwd_kernel<kBF, kBW, kBX, kBS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_b);
+  if (he != hipSuccess) return (int)he;
+  hipLaunchKernelGGL((imagine_bwd_kernel<kBF, kBW, kBX, kBS>), dim3((unsigned)((N + kR - 1) / kR)), dim3(512), lds_b, stream, a);
+  he = hipGetLastError();
+  return he == hipSuccess ? REPO_OK : (int)he;
+}
+
+}  // namespace repo
