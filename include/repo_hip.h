@@ -112,11 +112,14 @@ int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t ld
  * the output's shape).  `big_is_u8` != 0: big is uint8 pixels (encoder conv1 only). */
 int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
                    const float* bias, float* small, int epi, const float* aux, hipStream_t stream);
-/* `up` needs scratch for a fragment-ready copy of the layer's weights (layers 1..5; 0 bytes for the
- * 3-channel layers 0 and 6): pass at least repo_conv_up_workspace_bytes(layer). */
+/* `up` works from a fragment-ready copy of the layer's weights in `ws` (layers 1..5; 0 bytes for the 3-channel
+ * layers 0 and 6): at least repo_conv_up_workspace_bytes(layer).  repo_conv_up_pack writes that copy; repo_conv_up
+ * writes it itself first unless ws_is_packed != 0 (the weights change once per optimiser step, not per call). */
 size_t repo_conv_up_workspace_bytes(int layer);
+int repo_conv_up_pack(int layer, const float* w, void* ws, size_t ws_bytes, hipStream_t stream);
 int repo_conv_up(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
-                 float* big, int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t stream);
+                 float* big, int epi, const float* aux, int ws_is_packed, void* ws, size_t ws_bytes,
+                 hipStream_t stream);
 /* dw (+)= ..., dbias_small[small_ch] (+)= sum over images and pixels of `small` (NULL to skip). */
 size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg);
 int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big, int big_is_u8,

@@ -352,12 +352,19 @@ static size_t conv_up_ws_bytes() {
 }
 
 template <class G>
+static int conv_up_pack_t(const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+  using UC = typename UConf<G>::type;
+  if constexpr (!std::is_void<UC>::value) return launch_uconv_pack<G, UC>(w, ws, ws_bytes, s);
+  else return REPO_OK;  // the 3-channel layers read the native weights
+}
+
+template <class G>
 static int conv_up_t(int64_t nimg, const float* small, const float* w, const float* bias, float* big, int epi,
-                     const float* aux, void* ws, size_t ws_bytes, hipStream_t s) {
+                     const float* aux, int packed, void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   using UC = typename UConf<G>::type;
   if constexpr (!std::is_void<UC>::value) {
-    return launch_uconv_scatter<G, UC>(small, w, bias, aux, big, nimg, epi, ws, ws_bytes, s);
+    return launch_uconv_scatter<G, UC>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   } else {
     // 3-channel outputs (encoder conv1 data-gradient, plain decoder conv4): the four output parity classes read
     // the same (J x J) input taps, so they are merged on M (4 * 3 rows) in the gather engine of igemm.h
@@ -449,14 +456,21 @@ extern "C" size_t repo_conv_up_workspace_bytes(int layer) {
   REPO_LAYER_SWITCH(layer, return (conv_up_ws_bytes<G>()))
 }
 
+extern "C" int repo_conv_up_pack(int layer, const float* w, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(w, REPO_E_BADARG);
+  REPO_LAYER_SWITCH(layer, return (conv_up_pack_t<G>(w, ws, ws_bytes, stream)))
+}
+
 extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
-                            float* big, int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t stream) {
+                            float* big, int epi, const float* aux, int ws_is_packed, void* ws, size_t ws_bytes,
+                            hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(small && w && big, REPO_E_BADARG);
   REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU || (epi == REPO_EPI_MUL_DRELU && aux), REPO_E_BADARG);
-  REPO_LAYER_SWITCH(layer, return (conv_up_t<G>(nimg, small, w, bias, big, epi, aux, ws, ws_bytes, stream)))
+  REPO_LAYER_SWITCH(layer, return (conv_up_t<G>(nimg, small, w, bias, big, epi, aux, ws_is_packed, ws, ws_bytes, stream)))
 }
 
 extern "C" size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg) {

@@ -63,30 +63,51 @@ static size_t pack_floats(int64_t N, int64_t K) { return (size_t)pad16((int)K) *
 // acc0 (+ acc1) += A[16 x K] * packed W column tile.  A0/A1: LDS tiles (k4-interleaved), W0/W1: packs with N0/N1
 // columns, col0/col1: this lane's (clamped) column.  The B fragments run kPD blocks (kPD * 8 MFMAs = ~1300 cycles,
 // an L2 round trip) ahead of the MFMAs in a rotating register window.
-constexpr int kPD = 5;
+constexpr int kPD = 4;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const float* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
 }
-// W0/W1 are BYTE offsets of the packs inside the buffer `rw` (wave-uniform): a block's address is
-// lane part (VGPR, one per call) + scalar offset -- a 64-bit VGPR address per block and call site would be
-// hoisted out of the step loop by the compiler and spill everything else.
+// A weight stream of one or two column tiles: its first kPD blocks are requested by wopen() -- which the caller
+// places BEFORE the barrier / the MFMA chain that precedes the stream's use, so no layer starts with an exposed
+// L2 round trip -- and wrun() keeps the window kPD blocks ahead.  W0/W1 are BYTE offsets of the packs inside the
+// buffer `rw` (wave-uniform): a block's address is lane part (VGPR, one per stream) + scalar offset -- a 64-bit
+// VGPR address per block and call site would be hoisted out of the step loop by the compiler and spill the rest.
+struct WWin {
+  f32x4v b0[kPD], b1[kPD];
+  unsigned v0, v1, W0, W1, s0, s1;
+  bool act, two;
+};
+__device__ __forceinline__ f32x4v wld(__amdgpu_buffer_rsrc_t rw, unsigned v, unsigned so) {
+  return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, v, so, 0));
+}
 template <int NBLK>
-__device__ __forceinline__ void mma_pair_t(f32x4v& acc0, f32x4v& acc1, const float* A0, const float* A1,
-                                           __amdgpu_buffer_rsrc_t rw, unsigned W0, int N0, int col0, unsigned W1,
-                                           int N1, int col1, bool two, int lane) {
-  const int row = lane & 15, kq = lane >> 4;
+__device__ __forceinline__ void wopen(WWin& w, __amdgpu_buffer_rsrc_t rw, bool act, unsigned W0, int N0, int col0,
+                                      unsigned W1, int N1, int col1, bool two, int lane) {
   constexpr int PD = NBLK < kPD ? NBLK : kPD;
-  f32x4v b0[PD], b1[PD];
-  const unsigned v0 = 16u * (unsigned)(kq * N0 + col0), v1 = 16u * (unsigned)(kq * N1 + col1);
-  const unsigned s0 = 64u * (unsigned)N0, s1 = 64u * (unsigned)N1;  // bytes per 16-k block of a pack
-  auto ld = [&](unsigned v, unsigned so) {
-    return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, v, so, 0));
-  };
+  const int kq = lane >> 4;
+  w.act = act;
+  w.two = two;
+  w.v0 = 16u * (unsigned)(kq * N0 + col0);
+  w.v1 = 16u * (unsigned)(kq * N1 + col1);
+  w.W0 = W0;
+  w.W1 = W1;
+  w.s0 = 64u * (unsigned)N0;  // bytes per 16-k block of a pack
+  w.s1 = 64u * (unsigned)N1;
+  // always both tiles, also for an idle wave (clamped columns: the loads are valid): conditional stores into the
+  // window make the compiler keep it in scratch memory with run-time offsets
 #pragma unroll
   for (int b = 0; b < PD; ++b) {
-    b0[b] = ld(v0, W0 + b * s0);
-    if (two) b1[b] = ld(v1, W1 + b * s1);
+    w.b0[b] = wld(rw, w.v0, W0 + b * w.s0);
+    w.b1[b] = wld(rw, w.v1, W1 + b * w.s1);
   }
+}
+// acc0 (+ acc1) += A[16 x K] * the stream's column tile(s).  A0/A1: LDS tiles (k4-interleaved).
+template <int NBLK>
+__device__ __forceinline__ void wrun(f32x4v& acc0, f32x4v& acc1, const float* A0, const float* A1, WWin& w,
+                                     __amdgpu_buffer_rsrc_t rw, int lane) {
+  constexpr int PD = NBLK < kPD ? NBLK : kPD;
+  if (!w.act) return;
+  const int row = lane & 15, kq = lane >> 4;
   const float* a0p = A0 + (kq * kR + row) * 4;
   const float* a1p = A1 + (kq * kR + row) * 4;
 #pragma unroll
@@ -95,31 +116,34 @@ __device__ __forceinline__ void mma_pair_t(f32x4v& acc0, f32x4v& acc1, const flo
     const f32x4v a1 = (A1 == A0) ? a0 : *reinterpret_cast<const f32x4v*>(a1p + b * 16 * kR);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[b % PD][j], acc0, 0, 0, 0);
-      if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[b % PD][j], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], w.b0[b % PD][j], acc0, 0, 0, 0);
+      if (w.two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], w.b1[b % PD][j], acc1, 0, 0, 0);
     }
     if (b + PD < NBLK) {
-      b0[b % PD] = ld(v0, W0 + (b + PD) * s0);
-      if (two) b1[b % PD] = ld(v1, W1 + (b + PD) * s1);
+      w.b0[b % PD] = wld(rw, w.v0, w.W0 + (b + PD) * w.s0);
+      w.b1[b % PD] = wld(rw, w.v1, w.W1 + (b + PD) * w.s1);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the window: no hoisting of later blocks' loads
   }
 }
-// Dense layer on the row tile: wave w owns column tiles w and w + 8.  epi(valid, n, acc): n = this lane's column,
-// acc[r] belongs to row 4*(lane>>4) + r.
-template <int NBLK, class Epi>
-__device__ __forceinline__ void dense16(const float* A, __amdgpu_buffer_rsrc_t rw, unsigned W, int N, int wave, int lane,
-                                        Epi epi) {
+// Dense layer on the row tile: wave w owns column tiles w and w + 8.
+template <int NBLK>
+__device__ __forceinline__ void dense_open(WWin& w, __amdgpu_buffer_rsrc_t rw, unsigned W, int N, int wave, int lane) {
   const int ntiles = (N + 15) >> 4;
-  const int t0 = wave, t1 = wave + kW;
-  if (t0 >= ntiles) return;
-  const bool two = t1 < ntiles;
   const int n = lane & 15;
-  const int c0 = t0 * 16 + n, c1 = t1 * 16 + n;
+  wopen<NBLK>(w, rw, wave < ntiles, W, N, min(wave * 16 + n, N - 1), W, N, min((wave + kW) * 16 + n, N - 1),
+              wave + kW < ntiles, lane);
+}
+// epi(valid, n, acc): n = this lane's column, acc[r] belongs to row 4*(lane>>4) + r.
+template <int NBLK, class Epi>
+__device__ __forceinline__ void dense_run(const float* A, WWin& w, __amdgpu_buffer_rsrc_t rw, int N, int wave, int lane,
+                                          Epi epi) {
+  if (!w.act) return;
+  const int c0 = wave * 16 + (lane & 15), c1 = c0 + kW * 16;
   f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  mma_pair_t<NBLK>(acc0, acc1, A, A, rw, W, N, min(c0, N - 1), W, N, min(c1, N - 1), two, lane);
+  wrun<NBLK>(acc0, acc1, A, A, w, rw, lane);
   epi(c0 < N, c0, acc0);
-  if (two) epi(c1 < N, c1, acc1);
+  if (w.two) epi(c1 < N, c1, acc1);
 }
 
 struct ImgDims {
@@ -179,6 +203,10 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
 
   float* Fc = Fa;
   float* Fn = Fb;
+  // Weight windows.  Every stream is opened one stage before it is used (before the barrier / during the MFMAs of
+  // the previous stream); w0 / w1 alternate.
+  WWin w0, w1, wc;
+  dense_open<BF>(w0, rw, p.aW[0], Hd, wave, lane);
   for (int t = 0; t < Hm; ++t) {
     const size_t rb = (size_t)t * N + r0;  // first global row of this tile at step t
     // ---------------- actor trunk: 4 ELU layers + linear head
@@ -195,15 +223,20 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
         }
       };
     };
-    dense16<BF>(Fc, rw, p.aW[0], Hd, wave, lane, hidden_epi(HA, p.ab[0], p.a_hidden));
+    dense_open<BW>(w1, rw, p.aW[1], Hd, wave, lane);
+    dense_run<BF>(Fc, w0, rw, Hd, wave, lane, hidden_epi(HA, p.ab[0], p.a_hidden));
     __syncthreads();
-    dense16<BW>(HA, rw, p.aW[1], Hd, wave, lane, hidden_epi(HB, p.ab[1], p.a_hidden + rowsAll * Hd));
+    dense_open<BW>(w0, rw, p.aW[2], Hd, wave, lane);
+    dense_run<BW>(HA, w1, rw, Hd, wave, lane, hidden_epi(HB, p.ab[1], p.a_hidden + rowsAll * Hd));
     __syncthreads();
-    dense16<BW>(HB, rw, p.aW[2], Hd, wave, lane, hidden_epi(HA, p.ab[2], p.a_hidden + 2 * rowsAll * Hd));
+    dense_open<BW>(w1, rw, p.aW[3], Hd, wave, lane);
+    dense_run<BW>(HB, w0, rw, Hd, wave, lane, hidden_epi(HA, p.ab[2], p.a_hidden + 2 * rowsAll * Hd));
     __syncthreads();
-    dense16<BW>(HA, rw, p.aW[3], Hd, wave, lane, hidden_epi(HB, p.ab[3], p.a_hidden + 3 * rowsAll * Hd));
+    dense_open<BW>(w0, rw, p.aW[4], 2 * A, wave, lane);
+    dense_run<BW>(HA, w1, rw, Hd, wave, lane, hidden_epi(HB, p.ab[3], p.a_hidden + 3 * rowsAll * Hd));
     __syncthreads();
-    dense16<BW>(HB, rw, p.aW[4], 2 * A, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_open<BX>(w1, rw, p.Wsa, D, wave, lane);
+    dense_run<BW>(HB, w0, rw, 2 * A, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
       if (!ok) return;
       const float bv = p.ab[4][n];
 #pragma unroll
@@ -236,8 +269,12 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
       if (row < nr) p.xsa[(rb + row) * X + k] = v;
     }
     __syncthreads();
-    // ---------------- e = elu(W_sa x + b)
-    dense16<BX>(XS, rw, p.Wsa, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    // ---------------- e = elu(W_sa x + b); meanwhile the GRU's first stream and the prior head's are opened
+    const int gtiles = (D + 15) >> 4;
+    const int gcol0 = min(wave * 16 + (lane & 15), D - 1), gcol1 = min((wave + kW) * 16 + (lane & 15), D - 1);
+    const bool g0 = wave < gtiles, g1 = wave + kW < gtiles;
+    wopen<BW>(w0, rw, g0, p.Wih, 3 * D, gcol0, p.Wih, 3 * D, D + gcol0, true, lane);
+    dense_run<BX>(XS, w1, rw, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
       if (!ok) return;
       const float bv = p.bsa[n];
 #pragma unroll
@@ -249,45 +286,51 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
       }
     });
     __syncthreads();
-    // ---------------- GRU: the gate pre-activations of a column tile stay in one wave
-    {
-      const int ntiles = (D + 15) >> 4;
-      for (int ct = wave; ct < ntiles; ct += kW) {
-        const int n = ct * 16 + (lane & 15);
-        const int col = min(n, D - 1);
-        // r and z only need gi + gh: both products accumulate into one tile
-        f32x4v ar = {0.f, 0.f, 0.f, 0.f}, az = ar, gin = ar, ghn_ = ar;
-        mma_pair_t<BW>(ar, az, HA, HA, rw, p.Wih, 3 * D, col, p.Wih, 3 * D, D + col, true, lane);
-        mma_pair_t<BW>(ar, az, Fc, Fc, rw, p.Whh, 3 * D, col, p.Whh, 3 * D, D + col, true, lane);
-        mma_pair_t<BW>(gin, ghn_, HA, Fc, rw, p.Wih, 3 * D, 2 * D + col, p.Whh, 3 * D, 2 * D + col, true, lane);
-        if (n < D) {
-          const float br = p.bih[n] + p.bhh[n], bz = p.bih[D + n] + p.bhh[D + n];
-          const float bin = p.bih[2 * D + n], bhn = p.bhh[2 * D + n];
+    // ---------------- GRU: the gate pre-activations of a column tile stay in one wave.  r and z only need
+    //                  gi + gh: both products accumulate into one tile.  Streams per tile: (W_ih r, z), (W_hh r, z),
+    //                  (W_ih n, W_hh n); window roles swap between the wave's two tiles.
+    auto gru_tile = [&](WWin& x, WWin& y, int col, int n, bool more, int ncol) __attribute__((always_inline)) {
+      f32x4v ar = {0.f, 0.f, 0.f, 0.f}, az = ar, gin = ar, ghn_ = ar;
+      wopen<BW>(y, rw, true, p.Whh, 3 * D, col, p.Whh, 3 * D, D + col, true, lane);
+      wrun<BW>(ar, az, HA, HA, x, rw, lane);
+      wopen<BW>(x, rw, true, p.Wih, 3 * D, 2 * D + col, p.Whh, 3 * D, 2 * D + col, true, lane);
+      wrun<BW>(ar, az, Fc, Fc, y, rw, lane);
+      // behind the last stream of this tile: the next tile's first stream, or the prior head's first layer
+      if (more) wopen<BW>(y, rw, true, p.Wih, 3 * D, ncol, p.Wih, 3 * D, D + ncol, true, lane);
+      else dense_open<BW>(y, rw, p.Wbp, Hd, wave, lane);
+      wrun<BW>(gin, ghn_, HA, Fc, x, rw, lane);
+      if (n < D) {
+        const float br = p.bih[n] + p.bhh[n], bz = p.bih[D + n] + p.bhh[D + n];
+        const float bin = p.bih[2 * D + n], bhn = p.bhh[2 * D + n];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = 4 * lq + r;
-            const float rg = sigmoidf(ar[r] + br);
-            const float zg = sigmoidf(az[r] + bz);
-            const float ghn = ghn_[r] + bhn;
-            const float ng = tanh_fast(gin[r] + bin + rg * ghn);
-            const float hprev = Fc[ai(n, m)];
-            const float hn = (1.f - zg) * ng + zg * hprev;
-            Fn[ai(n, m)] = hn;
-            if (m < nr) {
-              float* g = p.gates + (rb + m) * 4 * D;
-              g[n] = rg;
-              g[D + n] = zg;
-              g[2 * D + n] = ng;
-              g[3 * D + n] = ghn;
-              p.featx[((size_t)(t + 1) * N + r0 + m) * F + n] = hn;
-            }
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * lq + r;
+          const float rg = sigmoidf(ar[r] + br);
+          const float zg = sigmoidf(az[r] + bz);
+          const float ghn = ghn_[r] + bhn;
+          const float ng = tanh_fast(gin[r] + bin + rg * ghn);
+          const float hprev = Fc[ai(n, m)];
+          const float hn = (1.f - zg) * ng + zg * hprev;
+          Fn[ai(n, m)] = hn;
+          if (m < nr) {
+            float* g = p.gates + (rb + m) * 4 * D;
+            g[n] = rg;
+            g[D + n] = zg;
+            g[2 * D + n] = ng;
+            g[3 * D + n] = ghn;
+            p.featx[((size_t)(t + 1) * N + r0 + m) * F + n] = hn;
           }
         }
       }
-    }
+    };
+    if (g0) gru_tile(w0, w1, gcol0, wave * 16 + (lane & 15), g1, gcol1);
+    else dense_open<BW>(w1, rw, p.Wbp, Hd, wave, lane);
+    if (g1) gru_tile(w1, w0, gcol1, (wave + kW) * 16 + (lane & 15), false, gcol1);
+    wc = g1 ? w0 : w1;  // where the prior head's stream was opened
     __syncthreads();
     // ---------------- prior head
-    dense16<BW>(Fn, rw, p.Wbp, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_open<BW>(w1, rw, p.Wsp, 2 * S, wave, lane);
+    dense_run<BW>(Fn, wc, rw, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
       if (!ok) return;
       const float bv = p.bbp[n];
 #pragma unroll
@@ -299,7 +342,8 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
       }
     });
     __syncthreads();
-    dense16<BW>(HB, rw, p.Wsp, 2 * S, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_open<BF>(w0, rw, p.aW[0], Hd, wave, lane);  // the next step's first layer
+    dense_run<BW>(HB, w1, rw, 2 * S, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
       if (!ok) return;
       const float bv = p.bsp[n];
 #pragma unroll
@@ -366,6 +410,11 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
   for (int i = tid; i < lds_floats / 4; i += 512) reinterpret_cast<f32x4v*>(lds)[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+  WWin w0, w1;
+  dense_open<BS>(w0, rw, p.Wsp, Hd, wave, lane);
+  const int gtiles = (D + 15) >> 4;  // <= 2 * kW: results of tiles w, w+8 are held across a barrier
+  const bool g0 = wave < gtiles, g1 = wave + kW < gtiles;
+  const int gcol0 = min(wave * 16 + (lane & 15), D - 1), gcol1 = min((wave + kW) * 16 + (lane & 15), D - 1);
   for (int t = Hm - 1; t >= 0; --t) {
     const size_t rb = (size_t)t * N + r0;
     // ---- G += dfeat[t]
@@ -393,7 +442,8 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
     }
     __syncthreads();
     // ---- X1 = (d out @ W_sp) * elu'(hp)
-    dense16<BS>(SM, rw, p.Wsp, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_open<BW>(w1, rw, p.Wbp, D, wave, lane);
+    dense_run<BS>(SM, w0, rw, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
       if (!ok) return;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -404,7 +454,8 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
     });
     __syncthreads();
     // ---- X2 = d belief_{t+1} = Gb + X1 @ W_bp
-    dense16<BW>(X1, rw, p.Wbp, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    wopen<BW>(w0, rw, g0, p.Whh[0], D, gcol0, p.Wih[0], D, gcol0, true, lane);  // the gate products' first stream
+    dense_run<BW>(X1, w1, rw, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
       if (!ok) return;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -435,40 +486,43 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
       Gb[ai(n, row)] = dhp;
     }
     __syncthreads();
-    // ---- through W_hh into belief_t (new carry) and through W_ih into e; both from the same tiles
+    // ---- through W_hh into belief_t (new carry: ah) and through W_ih into e (ae); both from the same tiles.
+    //      Streams per tile: (W_hh r, W_ih r) on g_r, (z, z) on g_z, (W_hh n on g_n*r, W_ih n on g_n).
     {
-      const int ntiles = (D + 15) >> 4;  // <= 2 * kW: results of tiles w, w+8 are held across the barrier
-      f32x4v ah[2], ae[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        ae[i] = ah[i];
-        const int ct = wave + i * kW;
-        if (ct < ntiles) {
-          const int col = min(ct * 16 + (lane & 15), D - 1);
-          mma_pair_t<BW>(ah[i], ae[i], X2, X2, rw, p.Whh[0], D, col, p.Wih[0], D, col, true, lane);
-          mma_pair_t<BW>(ah[i], ae[i], X1, X1, rw, p.Whh[1], D, col, p.Wih[1], D, col, true, lane);
-          mma_pair_t<BW>(ah[i], ae[i], X4, X3, rw, p.Whh[2], D, col, p.Wih[2], D, col, true, lane);
-        }
-      }
+      f32x4v ah0 = {0.f, 0.f, 0.f, 0.f}, ae0 = ah0, ah1 = ah0, ae1 = ah0;
+      auto gate_tile = [&](WWin& x, WWin& y, f32x4v& ah, f32x4v& ae, int col, bool more, int ncol) __attribute__((always_inline)) {
+        wopen<BW>(y, rw, true, p.Whh[1], D, col, p.Wih[1], D, col, true, lane);
+        wrun<BW>(ah, ae, X2, X2, x, rw, lane);
+        wopen<BW>(x, rw, true, p.Whh[2], D, col, p.Wih[2], D, col, true, lane);
+        wrun<BW>(ah, ae, X1, X1, y, rw, lane);
+        wopen<BW>(y, rw, more, p.Whh[0], D, ncol, p.Wih[0], D, ncol, true, lane);
+        wrun<BW>(ah, ae, X4, X3, x, rw, lane);
+      };
+      if (g0) gate_tile(w0, w1, ah0, ae0, gcol0, g1, gcol1);
+      if (g1) gate_tile(w1, w0, ah1, ae1, gcol1, false, gcol1);
+      // both windows are free again: open the last layer of this step
+      dense_open<BW>(w0, rw, p.Wsa, X, wave, lane);
       __syncthreads();  // every wave has finished reading X1..X4
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int n = (wave + i * kW) * 16 + (lane & 15);
-        if (wave + i * kW < ntiles && n < D) {
+        const f32x4v& ah = i ? ah1 : ah0;
+        const f32x4v& ae = i ? ae1 : ae0;
+        if ((i ? g1 : g0) && n < D) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = 4 * lq + r;
-            Gb[ai(n, m)] += ah[i][r];
+            Gb[ai(n, m)] += ah[r];
             const float ev = m < nr ? p.e[(rb + m) * D + n] : 0.f;
-            X4[ai(n, m)] = ae[i][r] * elu_grad_from_out(ev);  // d pre-activation of fc_embed_state_action
+            X4[ai(n, m)] = ae[r] * elu_grad_from_out(ev);  // d pre-activation of fc_embed_state_action
           }
         }
       }
     }
     __syncthreads();
     // ---- d [state_t | action_t] = X4 @ W_sa
-    dense16<BW>(X4, rw, p.Wsa, X, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_open<BS>(w1, rw, p.Wsp, Hd, wave, lane);  // the next (earlier) step's first layer
+    dense_run<BW>(X4, w0, rw, X, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
       if (!ok) return;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -491,6 +545,12 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
       }
     }
     __syncthreads();
+    // window roles for the next iteration: its first layer was opened into w1
+    {
+      WWin tmp = w0;
+      w0 = w1;
+      w1 = tmp;
+    }
   }
   if (p.dfeat0) {
     for (int i = tid; i < kR * F; i += 512) {

@@ -350,12 +350,24 @@ __global__ __launch_bounds__(256, 2) void uconv_scatter_kernel(UScatArgs p) {
 }
 
 template <class G, class C>
+inline int launch_uconv_pack(const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!ws || ws_bytes < C::PACK_FLOATS * sizeof(float)) return REPO_E_WS_TOO_SMALL;
+  UPackArgs pa{w, (float*)ws};
+  hipLaunchKernelGGL((uconv_pack_kernel<G>), dim3((unsigned)((C::PACK_FLOATS + 1023) / 1024)), dim3(256), 0, s, pa);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+// `packed` != 0: ws already holds this layer's pack (repo_conv_up_pack); else it is written first.
+template <class G, class C>
 inline int launch_uconv_scatter(const float* small, const float* w, const float* bias, const float* aux, float* out,
-                                int64_t nimg, int epi, void* ws, size_t ws_bytes, hipStream_t s) {
+                                int64_t nimg, int epi, int packed, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!ws || ws_bytes < C::PACK_FLOATS * sizeof(float)) return REPO_E_WS_TOO_SMALL;
   float* wp = (float*)ws;
-  UPackArgs pa{w, wp};
-  hipLaunchKernelGGL((uconv_pack_kernel<G>), dim3((unsigned)((C::PACK_FLOATS + 1023) / 1024)), dim3(256), 0, s, pa);
+  if (!packed) {
+    const int rc = launch_uconv_pack<G, C>(w, ws, ws_bytes, s);
+    if (rc) return rc;
+  }
   const int ngi = (int)((nimg + C::GI - 1) / C::GI);
   UScatArgs a{small, wp, bias, aux, out, (int)nimg, epi, (unsigned)(nimg * G::CS * G::PS * sizeof(float)),
               (unsigned)(C::PACK_FLOATS * sizeof(float))};

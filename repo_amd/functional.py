@@ -55,11 +55,13 @@ def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False, side=None):
     fk = _Fork(side)
     d4 = ops.relu_mask(dembeds.reshape(n, 256, 2, 2).contiguous(), h4)
     fk.run(lambda: ops.conv_wgrad(ops.ENC4, d4, h3, dw=g[6], db=g[7], accumulate=accumulate))
-    d3 = ops.conv_up(ops.ENC4, d4, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h3)
+    # the three weight packs first (independent of the gradients): their launches do not sit between the convs
+    pk4, pk3, pk2 = ops.conv_up_pack(ops.ENC4, p[6]), ops.conv_up_pack(ops.ENC3, p[4]), ops.conv_up_pack(ops.ENC2, p[2])
+    d3 = ops.conv_up(ops.ENC4, d4, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h3, pack=pk4)
     fk.run(lambda: ops.conv_wgrad(ops.ENC3, d3, h2, dw=g[4], db=g[5], accumulate=accumulate))
-    d2 = ops.conv_up(ops.ENC3, d3, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h2)
+    d2 = ops.conv_up(ops.ENC3, d3, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h2, pack=pk3)
     fk.run(lambda: ops.conv_wgrad(ops.ENC2, d2, h1, dw=g[2], db=g[3], accumulate=accumulate))
-    d1 = ops.conv_up(ops.ENC2, d2, p[2], None, epi=ops.EPI_MUL_DRELU, aux=h1)
+    d1 = ops.conv_up(ops.ENC2, d2, p[2], None, epi=ops.EPI_MUL_DRELU, aux=h1, pack=pk2)
     ops.conv_wgrad(ops.ENC1, d1, obs, dw=g[0], db=g[1], accumulate=accumulate)
     fk.join()
 
@@ -69,11 +71,12 @@ def decoder_trunk_fwd(p, feat):
     """fc1 + the first three transposed convolutions (models/decoder.py:41-46).
     feat (rows, 230) = [belief|state]; p = [fc1.w, fc1.b, conv1.w, conv1.b, ..., conv4.w, conv4.b]."""
     rows = feat.shape[0]
+    pk2, pk3 = ops.conv_up_pack(ops.DEC2, p[4]), ops.conv_up_pack(ops.DEC3, p[6])
     h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
     w1 = p[2].view(p[2].shape[0], -1)  # (1024, 128*25): 1x1 -> 5x5 transposed conv is a GEMM
     h1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_RELU).view(rows, 128, 5, 5)
-    h2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_RELU)
-    h3 = ops.conv_up(ops.DEC3, h2, p[6], p[7], epi=ops.EPI_RELU)
+    h2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_RELU, pack=pk2)
+    h3 = ops.conv_up(ops.DEC3, h2, p[6], p[7], epi=ops.EPI_RELU, pack=pk3)
     return h0, h1, h2, h3
 
 

@@ -128,17 +128,27 @@ def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None):
     return out
 
 
-def conv_up(layer, small, w, bias=None, epi=EPI_NONE, aux=None, out=None):
+def conv_up_pack(layer, w):
+    """The fragment-ready weight copy conv_up works from (None for the 3-channel layers): pass it as `pack=`."""
+    nb = lib().repo_conv_up_workspace_bytes(layer)
+    if not nb:
+        return None
+    pack = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    check(lib().repo_conv_up_pack(layer, _ptr(_f32c(w)), _ptr(pack), nb, _stream()), "repo_conv_up_pack")
+    return pack
+
+
+def conv_up(layer, small, w, bias=None, epi=EPI_NONE, aux=None, out=None, pack=None):
     nimg = small.shape[0]
     (cb, hb, _), (cs, hs, _) = conv_shapes(layer)
     assert tuple(small.shape[1:]) == (cs, hs, hs) and small.is_contiguous(), small.shape
     if out is None:
         out = torch.empty(nimg, cb, hb, hb, dtype=torch.float32, device=small.device)
     nb = lib().repo_conv_up_workspace_bytes(layer)
-    ws = workspace(nb, small.device) if nb else None
+    ws = pack if pack is not None else (workspace(nb, small.device) if nb else None)
     check(
         lib().repo_conv_up(layer, nimg, _ptr(_f32c(small)), _ptr(_f32c(w)), _ptr(bias), _ptr(out), epi, _ptr(aux),
-                           _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+                           int(pack is not None), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
         "repo_conv_up",
     )
     return out
