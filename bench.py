@@ -324,6 +324,9 @@ def main():
 
         from repo_amd.parallel import DataParallel
 
+        if "RANK" not in os.environ:  # REPO_FORCE_DP=1 without a launcher: a one-rank group of our own
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=str(_free_port()))
         dist.init_process_group("nccl", device_id=dev)
         dp = DataParallel(dist.group.WORLD)
 
