@@ -33,7 +33,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define REPO_ABI_VERSION 2
+#define REPO_ABI_VERSION 3
 
 #define REPO_OK 0
 #define REPO_E_BADARG (-1)
@@ -207,9 +207,14 @@ int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd
  * (the torch.cat of the reference is a row of the caller's feature buffer, ld = ldx).
  * params / dparams: HOST arrays of 2*n_layers device pointers (fc1.weight, fc1.bias, ...).
  * hidden_out / hidden_acts: HOST arrays of n_layers-1 device pointers to (rows, hidden). */
+/* The reference head shapes (in_dim = 230, hidden = 200, 4 or 5 layers, out_dim <= 16) run the whole chain of a row
+ * tile in one kernel over packed weights kept in ws (csrc/mlp16.hip); other shapes run layer by layer and need
+ * no workspace (the query returns 0). */
+size_t repo_mlp_fwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
+                                    int n_layers);
 int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
                  const float* x, int64_t ldx, const float* const* params, float* const* hidden_out,
-                 float* out, int64_t ldo, hipStream_t stream);
+                 float* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t stream);
 /* dparams NULL: frozen weights (FreezeParameters, dreamer.py:306-317); dx NULL: detached input. */
 size_t repo_mlp_bwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
                                     int n_layers);

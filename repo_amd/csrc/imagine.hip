@@ -191,7 +191,7 @@ int philox_fill(float* out, long n, uint64_t seed, uint64_t offset, hipStream_t 
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
-// persistent row-tiled rollout (imagine_fused.hip)
+// persistent row-tiled rollout (imagine16.hip)
 bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers);
 size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
 size_t imagine_fused_bwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
@@ -208,18 +208,31 @@ int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
                       const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
                       float* dfeat0, void* ws, hipStream_t stream);
 
+// fused dense heads (mlp16.hip)
+bool mlp_fused_ok(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers);
+size_t mlp_fused_ws_floats(int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers);
+int mlp_fused_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int L, const float* x, int64_t ldx,
+                  const float* const* params, float* const* hidden_out, float* out, int64_t ldo, void* ws,
+                  hipStream_t stream);
+int mlp_fused_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int L, const float* const* params,
+                  const float* const* hidden_acts, const float* dout, int64_t lddout, float* const* dsave, float* dx,
+                  int64_t lddx, int accumulate_dx, void* ws, hipStream_t stream);
+
 }  // namespace repo
 
 using namespace repo;
 
 // =================================================================== MLP heads
-extern "C" int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
-                            const float* x, int64_t ldx, const float* const* params, float* const* hidden_out,
-                            float* out, int64_t ldo, hipStream_t stream) {
-  REPO_ARCH_GUARD();
-  REPO_REQUIRE(rows >= 0 && in_dim > 0 && hidden > 0 && out_dim > 0 && n_layers >= 1, REPO_E_SHAPE);
-  if (rows == 0) return REPO_OK;
-  REPO_REQUIRE(x && params && out && (n_layers == 1 || hidden_out), REPO_E_BADARG);
+// the fused kernels move biases and hidden activations as 16-byte quads
+static bool mlp_quads_aligned(int n_layers, const float* const* params, const float* const* hid) {
+  uintptr_t bits = 0;
+  for (int l = 0; l < n_layers - 1; ++l) bits |= (uintptr_t)params[2 * l + 1] | (uintptr_t)hid[l];
+  return (bits & 15) == 0;
+}
+
+static int mlp_fwd_layers(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers, const float* x,
+                          int64_t ldx, const float* const* params, float* const* hidden_out, float* out, int64_t ldo,
+                          hipStream_t stream) {
   const float* cur = x;
   int64_t ldc = ldx, kc = in_dim;
   for (int l = 0; l < n_layers; ++l) {
@@ -235,14 +248,45 @@ extern "C" int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
   return REPO_OK;
 }
 
-extern "C" size_t repo_mlp_bwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
+extern "C" size_t repo_mlp_fwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
                                                int n_layers) {
+  return mlp_fused_ok(rows, in_dim, hidden, out_dim, n_layers)
+             ? mlp_fused_ws_floats(in_dim, hidden, out_dim, n_layers) * sizeof(float)
+             : 0;
+}
+
+extern "C" int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
+                            const float* x, int64_t ldx, const float* const* params, float* const* hidden_out,
+                            float* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(rows >= 0 && in_dim > 0 && hidden > 0 && out_dim > 0 && n_layers >= 1, REPO_E_SHAPE);
+  if (rows == 0) return REPO_OK;
+  REPO_REQUIRE(x && params && out && (n_layers == 1 || hidden_out), REPO_E_BADARG);
+  // the fused kernel reads x through a 32-bit buffer descriptor
+  if (mlp_fused_ok(rows, in_dim, hidden, out_dim, n_layers) && (rows - 1) * ldx + in_dim < (int64_t(1) << 30) &&
+      mlp_quads_aligned(n_layers, params, hidden_out)) {
+    REPO_REQUIRE(ws && ws_bytes >= repo_mlp_fwd_workspace_bytes(rows, in_dim, hidden, out_dim, n_layers),
+                 REPO_E_WS_TOO_SMALL);
+    return mlp_fused_fwd(rows, in_dim, hidden, out_dim, n_layers, x, ldx, params, hidden_out, out, ldo, ws, stream);
+  }
+  return mlp_fwd_layers(rows, in_dim, hidden, out_dim, n_layers, x, ldx, params, hidden_out, out, ldo, stream);
+}
+
+// workspace: [pre-activation gradients: (n_layers - 1) x rows x hidden | weight-gradient slab | packs]
+static size_t mlp_bwd_slab_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers) {
   size_t slab = repo_gemm_wgrad_workspace_bytes(rows, hidden, in_dim);
   size_t s2 = repo_gemm_wgrad_workspace_bytes(rows, hidden, hidden);
   size_t s3 = repo_gemm_wgrad_workspace_bytes(rows, out_dim, n_layers > 1 ? hidden : in_dim);
   if (s2 > slab) slab = s2;
   if (s3 > slab) slab = s3;
-  return 2 * (size_t)rows * hidden * sizeof(float) + slab + 512;
+  return (slab + 255) & ~(size_t)255;
+}
+extern "C" size_t repo_mlp_bwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
+                                               int n_layers) {
+  const bool fused = mlp_fused_ok(rows, in_dim, hidden, out_dim, n_layers);
+  const size_t nd = fused ? (size_t)(n_layers - 1) : 2;
+  return nd * (size_t)rows * hidden * sizeof(float) + mlp_bwd_slab_bytes(rows, in_dim, hidden, out_dim, n_layers) +
+         (fused ? mlp_fused_ws_floats(in_dim, hidden, out_dim, n_layers) * sizeof(float) : 0) + 512;
 }
 
 extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
@@ -255,11 +299,30 @@ extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
   REPO_REQUIRE(x && params && dout && (n_layers == 1 || hidden_acts), REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_mlp_bwd_workspace_bytes(rows, in_dim, hidden, out_dim, n_layers),
                REPO_E_WS_TOO_SMALL);
+  const bool shape_ok = mlp_fused_ok(rows, in_dim, hidden, out_dim, n_layers);
+  const bool fused = shape_ok && mlp_quads_aligned(n_layers, params, hidden_acts) && ((uintptr_t)ws & 15) == 0;
+  const size_t nd = shape_ok ? (size_t)(n_layers - 1) : 2;
   float* d0 = (float*)ws;
-  float* d1 = d0 + (size_t)rows * hidden;
-  uintptr_t sl = ((uintptr_t)(d1 + (size_t)rows * hidden) + 255) & ~(uintptr_t)255;
+  uintptr_t sl = ((uintptr_t)(d0 + nd * (size_t)rows * hidden) + 255) & ~(uintptr_t)255;
   void* slab = (void*)sl;
-  const size_t slab_bytes = ws_bytes - (sl - (uintptr_t)ws);
+  const size_t slab_bytes = mlp_bwd_slab_bytes(rows, in_dim, hidden, out_dim, n_layers);
+  if (fused) {
+    // one kernel for the whole reverse chain; the weight gradients are GEMMs over the saved pre-activation gradients
+    float* dsave[8];
+    for (int l = 0; l < n_layers - 1; ++l) dsave[l] = d0 + (size_t)l * rows * hidden;
+    REPO_RC(mlp_fused_bwd(rows, in_dim, hidden, out_dim, n_layers, params, hidden_acts, dout, lddout,
+                          dparams ? dsave : nullptr, dx, lddx, accumulate_dx, (void*)(sl + slab_bytes), stream));
+    if (!dparams) return REPO_OK;
+    for (int l = n_layers - 1; l >= 0; --l) {
+      const bool last = l == n_layers - 1;
+      const int64_t n = last ? out_dim : hidden, k = (l == 0) ? in_dim : hidden;
+      REPO_RC(repo_gemm_wgrad(rows, n, k, last ? dout : dsave[l], last ? lddout : hidden,
+                              (l == 0) ? x : hidden_acts[l - 1], (l == 0) ? ldx : hidden, dparams[2 * l], k,
+                              dparams[2 * l + 1], accumulate_w, slab, slab_bytes, stream));
+    }
+    return REPO_OK;
+  }
+  float* d1 = d0 + (size_t)rows * hidden;
   const float* dcur = dout;
   int64_t lddc = lddout;
   for (int l = n_layers - 1; l >= 0; --l) {
@@ -368,7 +431,7 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
     // actor MLP on (detached) [belief, state]
     float* hid[8];
     for (int l = 0; l < n_actor_layers - 1; ++l) hid[l] = a_hidden + ((size_t)l * a_layer_rows + r0) * Hd;
-    REPO_RC(repo_mlp_fwd(N, F, Hd, 2 * A, n_actor_layers, ft, F, actor_params, hid, a_raw + r0 * 2 * A, 2 * A, stream));
+    REPO_RC(mlp_fwd_layers(N, F, Hd, 2 * A, n_actor_layers, ft, F, actor_params, hid, a_raw + r0 * 2 * A, 2 * A, stream));
     REPO_RC(repo_actor_head_fwd(N, A, S, a_raw + r0 * 2 * A, eps_act + r0 * A, ft + D, F, a_min_std, a_init_std,
                                 a_mean_scale, a_mean + r0 * A, a_std + r0 * A, xsa + r0 * X, stream));
     // belief update

@@ -1,0 +1,140 @@
+// Row-tile primitives shared by the persistent rollout (imagine16.hip) and the fused MLP heads (mlp16.hip):
+// 16-row activation tiles in LDS (k4-interleaved), k4-interleaved weight packs, v_mfma_f32_16x16x4_f32 with both
+// operands moved 16 bytes per lane per 4 k-steps, weight streams opened one stage ahead of their use.
+#pragma once
+#include "common.h"
+
+namespace repo {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kR = 16;      // rows per workgroup
+constexpr int kW = 8;       // waves per workgroup (512 threads)
+constexpr int kMaxBlk = 15; // K <= 240
+
+__host__ __device__ constexpr int pad16(int k) { return (k + 15) & ~15; }
+// k4-interleaved activation tile: element (k, row)
+__device__ __forceinline__ int ai(int k, int row) { return (((k >> 2) * kR + row) << 2) + (k & 3); }
+
+// ---- weight pack: dst[(kg*N + n)*4 + u] = W(n, 4kg+u) = src[n*sn + (4kg+u)*sk] for 4kg+u < K, else 0; kg < pad16(K)/4
+struct PackJob {
+  const float* src;
+  float* dst;
+  int N, K, sn, sk;
+};
+constexpr int kMaxJobs = 12;
+struct PackArgs {
+  PackJob job[kMaxJobs];
+  int njobs;
+};
+static __global__ __launch_bounds__(256) void pack16_kernel(PackArgs a) {
+  const PackJob j = a.job[blockIdx.y];
+  const int total = pad16(j.K) * j.N;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int u = i & 3, q = i >> 2;
+    const int n = q % j.N, k = 4 * (q / j.N) + u;
+    j.dst[i] = k < j.K ? j.src[(size_t)n * j.sn + (size_t)k * j.sk] : 0.f;
+  }
+}
+static inline size_t pack_floats(int64_t N, int64_t K) { return (size_t)pad16((int)K) * N; }
+// one launch for all jobs
+static inline int launch_pack(PackArgs& pa, hipStream_t s) {
+  int mx = 1;
+  for (int i = 0; i < pa.njobs; ++i) {
+    const int blocks = (pad16(pa.job[i].K) * pa.job[i].N + 255) / 256;
+    if (blocks > mx) mx = blocks;
+  }
+  if (mx > 256) mx = 256;
+  hipLaunchKernelGGL(pack16_kernel, dim3(mx, pa.njobs), dim3(256), 0, s, pa);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+
+// acc0 (+ acc1) += A[16 x K] * packed W column tile.  A0/A1: LDS tiles (k4-interleaved), W0/W1: packs with N0/N1
+// columns, col0/col1: this lane's (clamped) column.  The B fragments run kPD blocks (kPD * 8 MFMAs = ~1300 cycles,
+// an L2 round trip) ahead of the MFMAs in a rotating register window.
+constexpr int kPD = 4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+// A weight stream of one or two column tiles: its first kPD blocks are requested by wopen() -- which the caller
+// places BEFORE the barrier / the MFMA chain that precedes the stream's use, so no layer starts with an exposed
+// L2 round trip -- and wrun() keeps the window kPD blocks ahead.  W0/W1 are BYTE offsets of the packs inside the
+// buffer `rw` (wave-uniform): a block's address is lane part (VGPR, one per stream) + scalar offset -- a 64-bit
+// VGPR address per block and call site would be hoisted out of the step loop by the compiler and spill the rest.
+struct WWin {
+  f32x4v b0[kPD], b1[kPD];
+  unsigned v0, v1, W0, W1, s0, s1;
+  bool act, two;
+};
+__device__ __forceinline__ f32x4v wld(__amdgpu_buffer_rsrc_t rw, unsigned v, unsigned so) {
+  return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, v, so, 0));
+}
+template <int NBLK>
+__device__ __forceinline__ void wopen(WWin& w, __amdgpu_buffer_rsrc_t rw, bool act, unsigned W0, int N0, int col0,
+                                      unsigned W1, int N1, int col1, bool two, int lane) {
+  constexpr int PD = NBLK < kPD ? NBLK : kPD;
+  const int kq = lane >> 4;
+  w.act = act;
+  w.two = two;
+  w.v0 = 16u * (unsigned)(kq * N0 + col0);
+  w.v1 = 16u * (unsigned)(kq * N1 + col1);
+  w.W0 = W0;
+  w.W1 = W1;
+  w.s0 = 64u * (unsigned)N0;  // bytes per 16-k block of a pack
+  w.s1 = 64u * (unsigned)N1;
+  // always both tiles, also for an idle wave (clamped columns: the loads are valid): conditional stores into the
+  // window make the compiler keep it in scratch memory with run-time offsets
+#pragma unroll
+  for (int b = 0; b < PD; ++b) {
+    w.b0[b] = wld(rw, w.v0, W0 + b * w.s0);
+    w.b1[b] = wld(rw, w.v1, W1 + b * w.s1);
+  }
+}
+// acc0 (+ acc1) += A[16 x K] * the stream's column tile(s).  A0/A1: LDS tiles (k4-interleaved).
+template <int NBLK>
+__device__ __forceinline__ void wrun(f32x4v& acc0, f32x4v& acc1, const float* A0, const float* A1, WWin& w,
+                                     __amdgpu_buffer_rsrc_t rw, int lane) {
+  constexpr int PD = NBLK < kPD ? NBLK : kPD;
+  if (!w.act) return;
+  const int row = lane & 15, kq = lane >> 4;
+  const float* a0p = A0 + (kq * kR + row) * 4;
+  const float* a1p = A1 + (kq * kR + row) * 4;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const f32x4v a0 = *reinterpret_cast<const f32x4v*>(a0p + b * 16 * kR);
+    const f32x4v a1 = (A1 == A0) ? a0 : *reinterpret_cast<const f32x4v*>(a1p + b * 16 * kR);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], w.b0[b % PD][j], acc0, 0, 0, 0);
+      if (w.two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], w.b1[b % PD][j], acc1, 0, 0, 0);
+    }
+    if (b + PD < NBLK) {
+      w.b0[b % PD] = wld(rw, w.v0, w.W0 + (b + PD) * w.s0);
+      w.b1[b % PD] = wld(rw, w.v1, w.W1 + (b + PD) * w.s1);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the window: no hoisting of later blocks' loads
+  }
+}
+// Dense layer on the row tile: wave w owns column tiles w and w + 8.
+template <int NBLK>
+__device__ __forceinline__ void dense_open(WWin& w, __amdgpu_buffer_rsrc_t rw, unsigned W, int N, int wave, int lane) {
+  const int ntiles = (N + 15) >> 4;
+  const int n = lane & 15;
+  wopen<NBLK>(w, rw, wave < ntiles, W, N, min(wave * 16 + n, N - 1), W, N, min((wave + kW) * 16 + n, N - 1),
+              wave + kW < ntiles, lane);
+}
+// epi(valid, n, acc): n = this lane's column, acc[r] belongs to row 4*(lane>>4) + r.
+template <int NBLK, class Epi>
+__device__ __forceinline__ void dense_run(const float* A, WWin& w, __amdgpu_buffer_rsrc_t rw, int N, int wave, int lane,
+                                          Epi epi) {
+  if (!w.act) return;
+  const int c0 = wave * 16 + (lane & 15), c1 = c0 + kW * 16;
+  f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  wrun<NBLK>(acc0, acc1, A, A, w, rw, lane);
+  epi(c0 < N, c0, acc0);
+  if (w.two) epi(c1 < N, c1, acc1);
+}
+
+}  // namespace repo

@@ -309,9 +309,11 @@ def mlp_fwd(params, x, out=None, hid=None):
     if out is None:
         out = torch.empty(rows, out_dim, dtype=torch.float32, device=dev)
     pa, ha = ptr_array(params), ptr_array(hid)
+    nb = lib().repo_mlp_fwd_workspace_bytes(rows, in_dim, max(hidden, 1), out_dim, L)
+    ws = workspace(nb, dev) if nb else None
     check(
         lib().repo_mlp_fwd(rows, in_dim, max(hidden, 1), out_dim, L, _ptr(x), _ld(x), pa, ha, _ptr(out), _ld(out),
-                           _stream()),
+                           _ptr(ws), nb, _stream()),
         "repo_mlp_fwd",
     )
     return out, hid

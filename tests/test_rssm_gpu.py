@@ -85,7 +85,9 @@ def test_observe_fwd_bwd(ops, T, B, A):
     assert e < GTOL
 
 
-@pytest.mark.parametrize("mod,L,rows", [("reward_model", 4, 333), ("actor_model", 5, 1000), ("value_model", 4, 64)])
+# rows >= 16384 run 32-row tiles (csrc/mlp16.hip); 16400 and 17001 leave a ragged last tile
+@pytest.mark.parametrize("mod,L,rows", [("reward_model", 4, 333), ("actor_model", 5, 1000), ("value_model", 4, 64),
+                                        ("value_model", 4, 16400), ("actor_model", 5, 17001), ("reward_model", 4, 1)])
 def test_mlp_fwd_bwd(ops, mod, L, rows):
     A = 6
     rs = np.random.RandomState(rows)
@@ -107,6 +109,10 @@ def test_mlp_fwd_bwd(ops, mod, L, rows):
     # frozen weights / detached input variants run
     ops.mlp_bwd(cu(p), feat.detach().cuda(), hid, up.cuda(), dparams=None, dx=dx)
     assert l2err(dx, feat.grad) < GTOL
+    dparams = [torch.full_like(v, 7.0).cuda() for v in p.values()]
+    ops.mlp_bwd(cu(p), feat.detach().cuda(), hid, up.cuda(), dparams=dparams, dx=None)
+    for (k, v), g in zip(p.items(), dparams):
+        assert l2err(g, v.grad) < GTOL, k
 
 
 @pytest.mark.parametrize("Hm,N,A", [(4, 28, 6), (14, 300, 6), (2, 15, 7)])
