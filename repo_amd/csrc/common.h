@@ -128,4 +128,20 @@ struct NoiseSrc {
   __device__ __forceinline__ float at(size_t i) const { return p ? p[i] : philox_normal(seed, base + i); }
 };
 
+// Several dense weight gradients dW_i[n][k] = sum_m dY_i[m][n] X_i[m][k] (+ bias gradients) in one launch pair
+// (gemm.hip); at most kMaxWgradGroup - 1 jobs per call.
+constexpr int kMaxWgradGroup = 9;
+struct WgradDesc {
+  int64_t M, N, K;
+  const float* dY;
+  int64_t lddy;
+  const float* X;
+  int64_t ldx;
+  float* dW;
+  int64_t lddw;
+  float* db;
+};
+size_t gemm_wgrad_group_ws_bytes(const WgradDesc* d, int n);
+int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
 }  // namespace repo

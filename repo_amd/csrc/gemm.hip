@@ -245,6 +245,155 @@ static int wgrad_splits(long rows, long N, long K) {
   return (int)want;
 }
 
+// ---- several weight gradients in ONE launch pair (the layers of a head, the eight matrices of the scan): a dense 1-D grid
+// walks the concatenated (tile x, tile y, split) ranges of the jobs.  A 200 x 200 gradient alone is 16 tiles x 48 splits of a few microseconds each; back
+// to back, each launch drains before the next fills the chip, and the 1-row output layers get a launch of their own.
+struct WgradJobDev {
+  Dense2D A, B;
+  float* slab;
+  float* dW;
+  float* db;
+  int rows, N, K, rps, zstart, lddw;
+  int bstart, gx, gy;  // first flat tile id of the job, its tile grid
+};
+struct WgradJobs {
+  WgradJobDev job[kMaxWgradGroup];
+  int njobs;
+};
+struct VWgradGroupOp {
+  static constexpr bool A_VK = false;
+  static constexpr bool B_VK = false;
+  static constexpr int VW = 4;
+  Dense2D A, B;
+  float* slab;
+  int N_, K_, z, kb, ke, rows_, rps_;
+  WgradJobs g;
+
+  // The job table is a kernel argument: it is only ever indexed with compile-time constants (a run-time index
+  // would move the whole operator into scratch memory); the selection is a chain of scalar selects.
+  __device__ void decode(int t, int& bx, int& by, int& bz) {
+    WgradJobDev w = g.job[0];
+#pragma unroll
+    for (int i = 1; i < kMaxWgradGroup - 1; ++i)
+      if (i < g.njobs && t >= g.job[i].bstart) w = g.job[i];
+    const int local = t - w.bstart;
+    bx = local % w.gx;
+    by = (local / w.gx) % w.gy;
+    bz = local / (w.gx * w.gy);  // split index inside the job
+    A = w.A, B = w.B, slab = w.slab, N_ = w.N, K_ = w.K;
+    rows_ = w.rows, rps_ = w.rps;
+  }
+  __device__ void init(int zz) {
+    z = zz;
+    kb = zz * rps_;
+    ke = min(rows_, kb + rps_);
+  }
+  __device__ int M() const { return N_; }
+  __device__ int N() const { return K_ + 1; }
+  __device__ int kbeg() const { return kb; }
+  __device__ int kend() const { return ke; }
+  template <class V>
+  __device__ void fix_b(V& v, int n0) const {
+#pragma unroll
+    for (int i = 0; i < VW; ++i) v[i] = (n0 + i == K_) ? 1.f : v[i];
+  }
+  __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
+    float* c = slab + ((size_t)z * N_ + mb) * (K_ + 1) + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (mb + dm < M) c[dm * (K_ + 1)] = acc[r];
+    }
+  }
+  __device__ void finish() {}
+};
+
+__global__ void slab_reduce_group_kernel(WgradJobs g, int accumulate) {
+  WgradJobDev w = g.job[0];
+  int zend = g.job[1].zstart;
+#pragma unroll
+  for (int i = 1; i < kMaxWgradGroup - 1; ++i)
+    if (i == (int)blockIdx.y) w = g.job[i], zend = g.job[i + 1].zstart;  // job[njobs] is the end marker
+  const int splits = zend - w.zstart;
+  const int total = w.N * (w.K + 1);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int m = i / (w.K + 1), n = i % (w.K + 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed order: reproducible
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+      s0 += w.slab[(size_t)z * total + i];
+      s1 += w.slab[(size_t)(z + 1) * total + i];
+      s2 += w.slab[(size_t)(z + 2) * total + i];
+      s3 += w.slab[(size_t)(z + 3) * total + i];
+    }
+    for (; z < splits; ++z) s0 += w.slab[(size_t)z * total + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (n < w.K) {
+      float* p = w.dW + (size_t)m * w.lddw + n;
+      *p = accumulate ? *p + s : s;
+    } else if (w.db) {
+      w.db[m] = accumulate ? w.db[m] + s : s;
+    }
+  }
+}
+
+size_t gemm_wgrad_group_ws_bytes(const WgradDesc* d, int n) {
+  size_t b = 0;
+  for (int i = 0; i < n; ++i) b += (repo_gemm_wgrad_workspace_bytes(d[i].M, d[i].N, d[i].K) + 255) & ~(size_t)255;
+  return b;
+}
+
+int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n <= 0) return REPO_OK;
+  bool plain = n == 1 || n > kMaxWgradGroup - 1;
+  for (int i = 0; i < n; ++i) plain = plain || d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0;
+  if (plain) {  // degenerate shapes take the single-job path with its own checks
+    for (int i = 0; i < n; ++i) {
+      const int rc = repo_gemm_wgrad(d[i].M, d[i].N, d[i].K, d[i].dY, d[i].lddy, d[i].X, d[i].ldx, d[i].dW, d[i].lddw,
+                                     d[i].db, accumulate, ws, ws_bytes, stream);
+      if (rc) return rc;
+    }
+    return REPO_OK;
+  }
+  REPO_REQUIRE(ws && ws_bytes >= gemm_wgrad_group_ws_bytes(d, n), REPO_E_WS_TOO_SMALL);
+  VWgradGroupOp op{};
+  char* w = (char*)ws;
+  long nblocks = 0;
+  int z = 0, rmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgradDesc& q = d[i];
+    REPO_REQUIRE(q.dY && q.X && q.dW, REPO_E_BADARG);
+    REPO_REQUIRE(q.M < kMaxIdx && q.N < kMaxIdx && q.K < kMaxIdx - 1 && q.M * q.lddy < kMaxBufElems &&
+                     q.M * q.ldx < kMaxBufElems,
+                 REPO_E_SHAPE);
+    const int splits = wgrad_splits(q.M, q.N, q.K);
+    WgradJobDev& j = op.g.job[i];
+    j.A = Dense2D{q.dY, 4u * (unsigned)((q.M - 1) * q.lddy + q.N), (int)q.lddy};
+    j.B = Dense2D{q.X, 4u * (unsigned)((q.M - 1) * q.ldx + q.K), (int)q.ldx};
+    j.slab = (float*)w;
+    j.dW = q.dW, j.db = q.db, j.lddw = (int)q.lddw;
+    j.rows = (int)q.M, j.N = (int)q.N, j.K = (int)q.K;
+    j.rps = (int)((q.M + splits - 1) / splits);
+    j.zstart = z;
+    j.gx = (int)cdiv(q.K + 1, T64x64::BN), j.gy = (int)cdiv(q.N, T64x64::BM);
+    j.bstart = (int)nblocks;
+    nblocks += (long)j.gx * j.gy * splits;
+    z += splits;
+    w += (repo_gemm_wgrad_workspace_bytes(q.M, q.N, q.K) + 255) & ~(size_t)255;
+    const int total = (int)(q.N * (q.K + 1));
+    if (total > rmax) rmax = total;
+  }
+  op.g.job[n].zstart = z;  // end marker
+  op.g.job[n].bstart = (int)nblocks;
+  op.g.njobs = n;
+  const int rc = launch_vgemm_flat<T64x64>(op, nblocks, stream);
+  if (rc) return rc;
+  const int blocks = cdiv(rmax, 256) < 1024 ? cdiv(rmax, 256) : 1024;
+  hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(blocks, n), dim3(256), 0, stream, op.g, accumulate);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
 }  // namespace repo
 
 using namespace repo;

@@ -273,13 +273,30 @@ extern "C" int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
 }
 
 // workspace: [pre-activation gradients: (n_layers - 1) x rows x hidden | weight-gradient slab | packs]
+static int mlp_wgrad_jobs(WgradDesc* d, int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
+                          const float* x, int64_t ldx, const float* const* hidden_acts, const float* dout,
+                          int64_t lddout, float* const* dsave, float* const* dparams) {
+  for (int l = 0; l < n_layers; ++l) {
+    const bool last = l == n_layers - 1;
+    const int64_t n = last ? out_dim : hidden, k = (l == 0) ? in_dim : hidden;
+    d[l] = WgradDesc{rows, n, k, last ? dout : (dsave ? dsave[l] : nullptr), last ? lddout : hidden,
+                     (l == 0) ? x : (hidden_acts ? hidden_acts[l - 1] : nullptr), (l == 0) ? ldx : hidden,
+                     dparams ? dparams[2 * l] : nullptr, k, dparams ? dparams[2 * l + 1] : nullptr};
+  }
+  return n_layers;
+}
 static size_t mlp_bwd_slab_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers) {
-  size_t slab = repo_gemm_wgrad_workspace_bytes(rows, hidden, in_dim);
-  size_t s2 = repo_gemm_wgrad_workspace_bytes(rows, hidden, hidden);
-  size_t s3 = repo_gemm_wgrad_workspace_bytes(rows, out_dim, n_layers > 1 ? hidden : in_dim);
-  if (s2 > slab) slab = s2;
-  if (s3 > slab) slab = s3;
-  return (slab + 255) & ~(size_t)255;
+  if (n_layers > kMaxWgradGroup - 1) {  // layer by layer: the largest slab
+    size_t slab = repo_gemm_wgrad_workspace_bytes(rows, hidden, in_dim);
+    const size_t s2 = repo_gemm_wgrad_workspace_bytes(rows, hidden, hidden);
+    const size_t s3 = repo_gemm_wgrad_workspace_bytes(rows, out_dim, n_layers > 1 ? hidden : in_dim);
+    if (s2 > slab) slab = s2;
+    if (s3 > slab) slab = s3;
+    return (slab + 255) & ~(size_t)255;
+  }
+  WgradDesc d[kMaxWgradGroup];
+  const int n = mlp_wgrad_jobs(d, rows, in_dim, hidden, out_dim, n_layers, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr);
+  return gemm_wgrad_group_ws_bytes(d, n);
 }
 extern "C" size_t repo_mlp_bwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
                                                int n_layers) {
@@ -313,14 +330,10 @@ extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
     REPO_RC(mlp_fused_bwd(rows, in_dim, hidden, out_dim, n_layers, params, hidden_acts, dout, lddout,
                           dparams ? dsave : nullptr, dx, lddx, accumulate_dx, (void*)(sl + slab_bytes), stream));
     if (!dparams) return REPO_OK;
-    for (int l = n_layers - 1; l >= 0; --l) {
-      const bool last = l == n_layers - 1;
-      const int64_t n = last ? out_dim : hidden, k = (l == 0) ? in_dim : hidden;
-      REPO_RC(repo_gemm_wgrad(rows, n, k, last ? dout : dsave[l], last ? lddout : hidden,
-                              (l == 0) ? x : hidden_acts[l - 1], (l == 0) ? ldx : hidden, dparams[2 * l], k,
-                              dparams[2 * l + 1], accumulate_w, slab, slab_bytes, stream));
-    }
-    return REPO_OK;
+    WgradDesc jobs[kMaxWgradGroup];
+    const int nj = mlp_wgrad_jobs(jobs, rows, in_dim, hidden, out_dim, n_layers, x, ldx, hidden_acts, dout, lddout,
+                                  dsave, dparams);
+    return gemm_wgrad_group(jobs, nj, accumulate_w, slab, slab_bytes, stream);
   }
   float* d1 = d0 + (size_t)rows * hidden;
   const float* dcur = dout;

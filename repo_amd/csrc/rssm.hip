@@ -52,22 +52,43 @@ static int transpose_to(const float* src, int rows, int cols, int ld, float* dst
 // with W(n, k) = src[n*sn + k*sk].  Thread n of a stage then reads FOUR consecutive k of its output with one
 // coalesced 16-byte load (1 KB per wave) instead of four dword loads: the scan was bound by the CU's
 // vector-memory issue rate (~5.5k wave-level dword loads per step, ~12 cycles each), not by L2 latency.
-__global__ void pack_k4_kernel(const float* __restrict__ src, int N, int K, int sn, int sk, int total,
-                               float* __restrict__ dst) {
+struct K4Job {
+  const float* src;
+  float* dst;
+  int N, K, sn, sk;
+};
+constexpr int kMaxK4Jobs = 8;
+struct K4Jobs {
+  K4Job job[kMaxK4Jobs];
+  int n;
+};
+// one launch for all the matrices of a scan: blockIdx.y = job
+__global__ void pack_k4_kernel(K4Jobs js) {
+  const K4Job j = js.job[blockIdx.y];
+  const int total = ((j.K + 3) >> 2) * 4 * j.N;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int u = i & 3, q = i >> 2;
-    const int n = q % N, kg = q / N;
+    const int n = q % j.N, kg = q / j.N;
     const int k = 4 * kg + u;
-    dst[i] = k < K ? src[(size_t)n * sn + (size_t)k * sk] : 0.f;
+    j.dst[i] = k < j.K ? j.src[(size_t)n * j.sn + (size_t)k * j.sk] : 0.f;
   }
 }
 
 static size_t packed_k4_floats(int64_t N, int64_t K) { return (size_t)((K + 3) / 4) * 4 * N; }
 
-static int pack_k4(const float* src, int N, int K, int sn, int sk, float* dst, hipStream_t s) {
-  const int total = (int)packed_k4_floats(N, K);
-  const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
-  hipLaunchKernelGGL(pack_k4_kernel, dim3(blocks), dim3(256), 0, s, src, N, K, sn, sk, total, dst);
+// queue a pack; returns where the next pack may start
+static float* pack_k4_add(K4Jobs& js, const float* src, int N, int K, int sn, int sk, float* dst) {
+  js.job[js.n++] = K4Job{src, dst, N, K, sn, sk};
+  return dst + packed_k4_floats(N, K);
+}
+static int pack_k4_launch(const K4Jobs& js, hipStream_t s) {
+  int mx = 1;
+  for (int i = 0; i < js.n; ++i) {
+    const int blocks = (int)((packed_k4_floats(js.job[i].N, js.job[i].K) + 255) / 256);
+    if (blocks > mx) mx = blocks;
+  }
+  if (mx > 512) mx = 512;
+  hipLaunchKernelGGL(pack_k4_kernel, dim3(mx, js.n), dim3(256), 0, s, js);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? REPO_OK : (int)e;
 }
@@ -721,13 +742,16 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   float* WspT = w;  w += packed_k4_floats(s2, h);
   float* WsqT = w;
   int rc;
-  if ((rc = pack_k4(P[0], d, X, X, 1, WsaT, stream))) return rc;
-  if ((rc = pack_k4(P[2], 3 * d, d, d, 1, WihT, stream))) return rc;
-  if ((rc = pack_k4(P[3], 3 * d, d, d, 1, WhhT, stream))) return rc;
-  if ((rc = pack_k4(P[6], h, d, d, 1, WbpT, stream))) return rc;
-  if ((rc = pack_k4(P[10], h, d, (int)(D + E), 1, WbqT, stream))) return rc;
-  if ((rc = pack_k4(P[8], s2, h, h, 1, WspT, stream))) return rc;
-  if ((rc = pack_k4(P[12], s2, h, h, 1, WsqT, stream))) return rc;
+  K4Jobs packs;
+  packs.n = 0;
+  pack_k4_add(packs, P[0], d, X, X, 1, WsaT);
+  pack_k4_add(packs, P[2], 3 * d, d, d, 1, WihT);
+  pack_k4_add(packs, P[3], 3 * d, d, d, 1, WhhT);
+  pack_k4_add(packs, P[6], h, d, d, 1, WbpT);
+  pack_k4_add(packs, P[10], h, d, (int)(D + E), 1, WbqT);
+  pack_k4_add(packs, P[8], s2, h, h, 1, WspT);
+  pack_k4_add(packs, P[12], s2, h, h, 1, WsqT);
+  if ((rc = pack_k4_launch(packs, stream))) return rc;
   if (T == 0) return REPO_OK;
   // hoisted: eemb = embeds @ W_bq[:, D:]^T
   if ((rc = repo_gemm(0, 1, T * B, Hd, E, embeds, E, P[10] + D, D + E, nullptr, 1, eemb, Hd, REPO_EPI_NONE, nullptr, 0,
@@ -762,17 +786,39 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   return REPO_OK;
 }
 
+// The deferred weight / bias gradients of the scan as (T*B)-row GEMM jobs (G = dparams in plist order).
+static void obs_wgrad_jobs(WgradDesc* j, int64_t R_, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
+                           const float* featx, const float* xsa, const float* e, const float* hp, const float* hq,
+                           const float* doutp, const float* doutq, const float* dhp, const float* dhq,
+                           const float* dgi, const float* dgh, const float* de, float* const* G) {
+  const int64_t F = D + S, X = S + A;
+  auto g = [&](int i) -> float* { return G ? G[i] : nullptr; };
+  const float* bel = featx ? featx + (size_t)B * F : nullptr;  // belief_t = featx[t+1][:, :D]
+  // fc_state_prior / fc_state_posterior
+  j[0] = WgradDesc{R_, 2 * S, Hd, doutp, 2 * S, hp, Hd, g(8), Hd, g(9)};
+  j[1] = WgradDesc{R_, 2 * S, Hd, doutq, 2 * S, hq, Hd, g(12), Hd, g(13)};
+  // fc_embed_belief_prior; fc_embed_belief_posterior's belief columns [0, D) of its (Hd, D + E) weight
+  j[2] = WgradDesc{R_, Hd, D, dhp, Hd, bel, F, g(6), D, g(7)};
+  j[3] = WgradDesc{R_, Hd, D, dhq, Hd, bel, F, g(10), D + E, g(11)};
+  // GRU: weight_ih sees e, weight_hh sees belief_{t-1} = featx[t][:, :D]
+  j[4] = WgradDesc{R_, 3 * D, D, dgi, 3 * D, e, D, g(2), D, g(4)};
+  j[5] = WgradDesc{R_, 3 * D, D, dgh, 3 * D, featx, F, g(3), D, g(5)};
+  // fc_embed_state_action
+  j[6] = WgradDesc{R_, D, X, de, D, xsa, X, g(0), X, g(1)};
+}
+
 extern "C" size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S, int64_t E) {
   // deltas + the largest wgrad slab
   const size_t rows = (size_t)T * B;
   size_t deltas = rows * (size_t)(4 * S + 2 * Hd + 6 * D + D);
-  size_t slab = 0;
-  const int64_t shapes[8][2] = {{2 * S, Hd}, {2 * S, Hd}, {Hd, D}, {Hd, D}, {Hd, E}, {3 * D, D}, {3 * D, D}, {D, S + A}};
-  for (auto& s : shapes) {
-    size_t b = repo_gemm_wgrad_workspace_bytes(T * B, s[0], s[1]);
-    if (b > slab) slab = b;
-  }
+  // the seven recurrent-path weight gradients share one launch pair (one slab each); the (Hd x E) one runs alone
+  WgradDesc jobs[7];
+  obs_wgrad_jobs(jobs, T * B, B, A, D, Hd, S, E, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 nullptr, nullptr, nullptr, nullptr, nullptr);
+  size_t slab = gemm_wgrad_group_ws_bytes(jobs, 7);
+  const size_t big = repo_gemm_wgrad_workspace_bytes(T * B, Hd, E);
+  if (big > slab) slab = big;
   const size_t packs = bwd_pack_floats(A, D, Hd, S) * sizeof(float);  // live only during the scan kernel
   if (packs > slab) slab = packs;
   return deltas * sizeof(float) + slab + 256;
@@ -814,20 +860,21 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
   {  // packed weights at the head of the slab region: dead before the first weight-gradient GEMM uses it
     float* pw = (float*)slab;
     const int d = (int)D, h = (int)Hd, s2 = (int)(2 * S), X_ = (int)(S + A);
-    int rc0;
+    K4Jobs packs;
+    packs.n = 0;
     auto put = [&](const float* src, int N, int K, int ld, const float** dstp) {
       *dstp = pw;
-      const int rc_ = pack_k4(src, N, K, 1, ld, pw, stream);
-      pw += packed_k4_floats(N, K);
-      return rc_;
+      pw = pack_k4_add(packs, src, N, K, 1, ld, pw);
     };
-    if ((rc0 = put(P[8], h, s2, h, &a.Wsp))) return rc0;
-    if ((rc0 = put(P[12], h, s2, h, &a.Wsq))) return rc0;
-    if ((rc0 = put(P[6], d, h, d, &a.Wbp))) return rc0;
-    if ((rc0 = put(P[10], d, h, (int)(D + E), &a.Wbq))) return rc0;
-    if ((rc0 = put(P[3], d, 3 * d, d, &a.Whh))) return rc0;
-    if ((rc0 = put(P[2], d, 3 * d, d, &a.Wih))) return rc0;
-    if ((rc0 = put(P[0], (int)S, d, X_, &a.Wsa))) return rc0;
+    put(P[8], h, s2, h, &a.Wsp);
+    put(P[12], h, s2, h, &a.Wsq);
+    put(P[6], d, h, d, &a.Wbp);
+    put(P[10], d, h, (int)(D + E), &a.Wbq);
+    put(P[3], d, 3 * d, d, &a.Whh);
+    put(P[2], d, 3 * d, d, &a.Wih);
+    put(P[0], (int)S, d, X_, &a.Wsa);
+    const int rc0 = pack_k4_launch(packs, stream);
+    if (rc0) return rc0;
   }
   a.featx = featx; a.nonterms = nonterms; a.e = e; a.gates = gates; a.hp = hp; a.hq = hq;
   a.prior_std = prior_std; a.post_std = post_std;
@@ -849,21 +896,13 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
 
   // deferred weight/bias gradients: (T*B)-row MFMA GEMMs
   float* const* G = dparams;
-  const int64_t F = D + S, X = S + A, R_ = (int64_t)rows;
+  const int64_t R_ = (int64_t)rows;
   int rc;
-  // fc_state_prior / fc_state_posterior
-  if ((rc = repo_gemm_wgrad(R_, 2 * S, Hd, doutp, 2 * S, hp, Hd, G[8], Hd, G[9], accumulate, slab, slab_bytes, stream))) return rc;
-  if ((rc = repo_gemm_wgrad(R_, 2 * S, Hd, doutq, 2 * S, hq, Hd, G[12], Hd, G[13], accumulate, slab, slab_bytes, stream))) return rc;
-  // fc_embed_belief_prior: input belief_t = featx[t+1][:, :D]
-  if ((rc = repo_gemm_wgrad(R_, Hd, D, dhp, Hd, featx + (size_t)B * F, F, G[6], D, G[7], accumulate, slab, slab_bytes, stream))) return rc;
-  // fc_embed_belief_posterior: columns [0,D) from the belief, [D,D+E) from the embedding
-  if ((rc = repo_gemm_wgrad(R_, Hd, D, dhq, Hd, featx + (size_t)B * F, F, G[10], D + E, G[11], accumulate, slab, slab_bytes, stream))) return rc;
+  WgradDesc jobs[7];
+  obs_wgrad_jobs(jobs, R_, B, A, D, Hd, S, E, featx, xsa, e, hp, hq, doutp, doutq, dhp, dhq, dgi, dgh, de, G);
+  if ((rc = gemm_wgrad_group(jobs, 7, accumulate, slab, slab_bytes, stream))) return rc;
+  // fc_embed_belief_posterior, columns [D, D+E): the embedding's share
   if ((rc = repo_gemm_wgrad(R_, Hd, E, dhq, Hd, embeds, E, G[10] + D, D + E, nullptr, accumulate, slab, slab_bytes, stream))) return rc;
-  // GRU: weight_ih sees e, weight_hh sees belief_{t-1} = featx[t][:, :D]
-  if ((rc = repo_gemm_wgrad(R_, 3 * D, D, dgi, 3 * D, e, D, G[2], D, G[4], accumulate, slab, slab_bytes, stream))) return rc;
-  if ((rc = repo_gemm_wgrad(R_, 3 * D, D, dgh, 3 * D, featx, F, G[3], D, G[5], accumulate, slab, slab_bytes, stream))) return rc;
-  // fc_embed_state_action
-  if ((rc = repo_gemm_wgrad(R_, D, X, de, D, xsa, X, G[0], X, G[1], accumulate, slab, slab_bytes, stream))) return rc;
   // gradient into the encoder embedding: d embeds = dhq @ W_bq[:, D:]
   if (dembeds)
     if ((rc = repo_gemm(0, 0, R_, E, Hd, dhq, Hd, P[10] + D, D + E, nullptr, 1, dembeds, E, REPO_EPI_NONE, nullptr, 0, 0, stream))) return rc;

@@ -66,6 +66,12 @@ struct Dense2D {
 //   Dense2D A, B;  void init(int z);  int M(), N(), kbeg(), kend();
 //   template <class V> void fix_b(V& v, int n0) const;   // hook on a loaded B vector (n-contiguous)
 //   void store_col(int mb, int n, const f32x16& acc, int M);  void finish();
+// An Op may own the mapping flat tile id -> (tile x, tile y, z): void decode(int t, int& bx, int& by, int& bz) const.
+template <class Op, class = void>
+struct HasTileDecode : std::false_type {};
+template <class Op>
+struct HasTileDecode<Op, std::void_t<decltype(&Op::decode)>> : std::true_type {};
+
 template <class Op, class T>
 __global__ __launch_bounds__(T::NT) void vgemm_kernel(Op op) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT, VW = Op::VW;
@@ -102,9 +108,13 @@ __global__ __launch_bounds__(T::NT) void vgemm_kernel(Op op) {
     const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const int q = total >> 3, r = total & 7, xc = L & 7;
     const int t = xc * q + min(xc, r) + (L >> 3);
-    bx = t % gx;
-    by = (t / gx) % gy;
-    bz = t / (gx * gy);
+    if constexpr (HasTileDecode<Op>::value) {
+      op.decode(t, bx, by, bz);  // a dense 1-D grid over several problems (grouped weight gradients)
+    } else {
+      bx = t % gx;
+      by = (t / gx) % gy;
+      bz = t / (gx * gy);
+    }
   }
   op.init(bz);
   const int M = op.M(), N = op.N();
@@ -307,6 +317,15 @@ __global__ __launch_bounds__(T::NT) void vgemm_kernel(Op op) {
 #endif
   }
   op.finish();
+}
+
+template <class T, class Op>
+inline int launch_vgemm_flat(const Op& op, long blocks, hipStream_t s) {
+  if (blocks <= 0) return REPO_OK;
+  if (blocks > 2147483647L) return REPO_E_SHAPE;
+  hipLaunchKernelGGL((vgemm_kernel<Op, T>), dim3((unsigned)blocks), dim3(T::NT), 0, s, op);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
 }
 
 template <class T, class Op>
