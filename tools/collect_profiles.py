@@ -11,6 +11,8 @@ pairs = [
     ("pmc_c3/summary.txt", "r02_pmc_3channel_layers.txt"),
     ("pmc_mlp/summary.txt", "r02_pmc_mlp_heads.txt"),
     ("r02_bench_final.json", "r02_bench_final.json"),
+    ("r02_bench_c4_c5.json", "r02_bench_c4_c5.json"),
+    ("lane_time.txt", "r02_lane_time.txt"),
 ]
 for src, dst in pairs:
     s = os.path.join(G, src)
