@@ -313,8 +313,9 @@ struct DTileFor;
 template <> struct DTileFor<GEnc1> { using Down = DTile<32, 256, 3, 1, 4>;   using Wgrad = WTile<32, 64, 1, 2, 1, 8>; };
 template <> struct DTileFor<GEnc2> { using Down = DTile<64, 128, 2, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 1, 7>; };
 template <> struct DTileFor<GEnc3> { using Down = DTile<128, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 2, 6>; };
-template <> struct DTileFor<GEnc4> { using Down = DTile<128, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 16, 2>; };
-template <> struct DTileFor<GDec2> { using Down = DTile<64, 128, 4, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 4, 5>; };
+// enc4 forward has only 9800 output pixels: 128 x 128 tiles are 154 workgroups on 256 CUs (171 us); 32 x 64: 125 us
+template <> struct DTileFor<GEnc4> { using Down = DTile<32, 64, 2, 1, 2>;     using Wgrad = WTile<64, 128, 2, 2, 16, 2>; };
+template <> struct DTileFor<GDec2> { using Down = DTile<128, 128, 4, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 4, 5>; };
 template <> struct DTileFor<GDec3> { using Down = DTile<64, 128, 2, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 1, 7>; };
 template <> struct DTileFor<GDec4> { using Down = DTile<32, 256, 3, 1, 4>;   using Wgrad = WTile<32, 128, 1, 4, 1, 6>; };
 
