@@ -18,8 +18,14 @@
 //     for all ten matrices): the B fragments of four k-steps are one 16-byte global load, issued for the whole
 //     K range of a column-tile pair before its first MFMA;
 //   * a wave owns column tiles w and w+8 of a layer and runs them as two interleaved accumulator chains
-//     (the GRU pairs r with z and the two n products).
-// Padding columns of the activation tiles (K -> multiple of 16) are zeroed once and never written.
+//     (the GRU pairs r with z and the two n products);
+//   * the product is formed transposed (weights = the MFMA's A operand, rowtile.h): a lane's accumulator is a
+//     "quad", 4 consecutive columns of one row -- one ds_write_b128 into the next layer's tile, one 16-byte raw-buffer
+//     store per saved activation (lane offset invariant over the steps, step offset scalar: per-site 64-bit
+//     addresses would be hoisted out of the step loop and spilled), biases read as quads from a packed copy behind
+//     the weights.
+// Padding columns of the activation tiles (K -> multiple of 16) only ever hold finite values and meet zero rows of
+// the packed weights.
 // (S + A) may be odd (ManiSkill's A = 7): K is padded, not paired.
 //
 // Reference: TransitionModel.imagine + ActorModel.get_action (models/rssm.py:148-184,
@@ -36,10 +42,9 @@ struct ImgFwdArgs {
   ImgDims d;
   const float* wpack;  // all packs, contiguous
   unsigned wbytes;
-  unsigned aW[5];      // byte offsets of the packed actor weights
-  const float* ab[5];
+  unsigned aW[5], aB[5];  // byte offsets of the packed actor weights / biases
   unsigned Wsa, Wih, Whh, Wbp, Wsp;
-  const float *bsa, *bih, *bhh, *bbp, *bsp;
+  unsigned Bsa, Bih, Bhh, Bbp, Bsp;
   const float *belief0, *state0;
   NoiseSrc eps_act, eps_prior;
   float min_std, a_min_std, a_init_std, a_mean_scale;
@@ -64,11 +69,16 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lq = lane >> 4;
+  const int lq = lane >> 4, lm = lane & 15;  // a lane's quad: tile row lm, columns 16 tile + 4 lq .. + 3
   const int r0 = blockIdx.x * kR;
   const int nr = min(kR, N - r0);
   const size_t rowsAll = p.a_layer_rows;  // row stride between the saved actor layers
   const __amdgpu_buffer_rsrc_t rw = wrsrc(p.wpack, p.wbytes);
+  // saved activations, written as quads: lane part of the offset (row r0 + lm) per row stride, step part scalar
+  const __amdgpu_buffer_rsrc_t q_hid = arsrc(p.a_hidden), q_raw = arsrc(p.a_raw), q_e = arsrc(p.e),
+                               q_gates = arsrc(p.gates), q_featx = arsrc(p.featx), q_hp = arsrc(p.hp);
+  const unsigned lrow = (unsigned)(r0 + min(lm, nr - 1));
+  const bool lst = lm < nr;  // this lane's row exists
 
   for (int i = tid; i < lds_floats / 4; i += 512) reinterpret_cast<f32x4v*>(lds)[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -91,43 +101,37 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
   dense_open<BF>(w0, rw, p.aW[0], Hd, wave, lane);
   for (int t = 0; t < Hm; ++t) {
     const size_t rb = (size_t)t * N + r0;  // first global row of this tile at step t
+    const unsigned tN = (unsigned)(t * N);  // rows before this step
     // ---------------- actor trunk: 4 ELU layers + linear head
-    auto hidden_epi = [&](float* dst, const float* bias, float* save) {
-      return [=](bool ok, int n, const f32x4v& acc) {
+    auto hidden_epi = [&](float* dst, unsigned bias, int layer) {
+      return [=](bool ok, int n0, const f32x4v& acc) {
         if (!ok) return;
-        const float bv = bias[n];
+        const f32x4v bv = ldbias(rw, bias, n0);
+        f32x4v v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 4 * lq + r;
-          const float v = elu(acc[r] + bv);
-          dst[ai(n, m)] = v;
-          if (m < nr) save[(rb + m) * Hd + n] = v;
-        }
+        for (int r = 0; r < 4; ++r) v[r] = elu(acc[r] + bv[r]);
+        stq(dst, n0, lm, v);
+        if (lst) bstq(q_hid, 4u * (lrow * Hd + n0), 4u * (unsigned)((layer * rowsAll + tN) * Hd), v, 4);
       };
     };
     dense_open<BW>(w1, rw, p.aW[1], Hd, wave, lane);
-    dense_run<BF>(Fc, w0, rw, Hd, wave, lane, hidden_epi(HA, p.ab[0], p.a_hidden));
+    dense_run<BF>(Fc, w0, rw, Hd, wave, lane, hidden_epi(HA, p.aB[0], 0));
     __syncthreads();
     dense_open<BW>(w0, rw, p.aW[2], Hd, wave, lane);
-    dense_run<BW>(HA, w1, rw, Hd, wave, lane, hidden_epi(HB, p.ab[1], p.a_hidden + rowsAll * Hd));
+    dense_run<BW>(HA, w1, rw, Hd, wave, lane, hidden_epi(HB, p.aB[1], 1));
     __syncthreads();
     dense_open<BW>(w1, rw, p.aW[3], Hd, wave, lane);
-    dense_run<BW>(HB, w0, rw, Hd, wave, lane, hidden_epi(HA, p.ab[2], p.a_hidden + 2 * rowsAll * Hd));
+    dense_run<BW>(HB, w0, rw, Hd, wave, lane, hidden_epi(HA, p.aB[2], 2));
     __syncthreads();
     dense_open<BW>(w0, rw, p.aW[4], 2 * A, wave, lane);
-    dense_run<BW>(HA, w1, rw, Hd, wave, lane, hidden_epi(HB, p.ab[3], p.a_hidden + 3 * rowsAll * Hd));
+    dense_run<BW>(HA, w1, rw, Hd, wave, lane, hidden_epi(HB, p.aB[3], 3));
     __syncthreads();
     dense_open<BX>(w1, rw, p.Wsa, D, wave, lane);
-    dense_run<BW>(HB, w0, rw, 2 * A, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_run<BW>(HB, w0, rw, 2 * A, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
-      const float bv = p.ab[4][n];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * lq + r;
-        const float v = acc[r] + bv;
-        SM[ai(n, m)] = v;
-        if (m < nr) p.a_raw[(rb + m) * 2 * A + n] = v;
-      }
+      const f32x4v v = acc + ldbias(rw, p.aB[4], n0);
+      stq(SM, n0, lm, v);
+      if (lst) bstq(q_raw, 4u * (lrow * 2 * A + n0), 4u * tN * 2 * A, v, 2 * A - n0);
     });
     __syncthreads();
     // ---------------- tanh-Normal action sample; x = [state, action]
@@ -156,16 +160,14 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
     const int gcol0 = min(wave * 16 + (lane & 15), D - 1), gcol1 = min((wave + kW) * 16 + (lane & 15), D - 1);
     const bool g0 = wave < gtiles, g1 = wave + kW < gtiles;
     wopen<BW>(w0, rw, g0, p.Wih, 3 * D, gcol0, p.Wih, 3 * D, D + gcol0, true, lane);
-    dense_run<BX>(XS, w1, rw, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_run<BX>(XS, w1, rw, D, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
-      const float bv = p.bsa[n];
+      const f32x4v bv = ldbias(rw, p.Bsa, n0);
+      f32x4v v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * lq + r;
-        const float v = elu(acc[r] + bv);
-        HA[ai(n, m)] = v;
-        if (m < nr) p.e[(rb + m) * D + n] = v;
-      }
+      for (int r = 0; r < 4; ++r) v[r] = elu(acc[r] + bv[r]);
+      stq(HA, n0, lm, v);
+      if (lst) bstq(q_e, 4u * (lrow * D + n0), 4u * tN * D, v, 4);
     });
     __syncthreads();
     // ---------------- GRU: the gate pre-activations of a column tile stay in one wave.  r and z only need
@@ -181,55 +183,53 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
       if (more) wopen<BW>(y, rw, true, p.Wih, 3 * D, ncol, p.Wih, 3 * D, D + ncol, true, lane);
       else dense_open<BW>(y, rw, p.Wbp, Hd, wave, lane);
       wrun<BW>(gin, ghn_, HA, Fc, x, rw, lane);
-      if (n < D) {
-        const float br = p.bih[n] + p.bhh[n], bz = p.bih[D + n] + p.bhh[D + n];
-        const float bin = p.bih[2 * D + n], bhn = p.bhh[2 * D + n];
+      if (n < D) {  // n = the quad's first column.  One gate at a time: few live registers beside the windows
+        constexpr int nv = 4;  // D % 4 == 0 (imagine_fused_ok): whole quads
+        const unsigned gv = 4u * (lrow * 4 * D + n), gs = 4u * tN * 4 * D;
+        const bool st = lst;
+        f32x4v rg = ar + ldbias(rw, p.Bih, n) + ldbias(rw, p.Bhh, n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 4 * lq + r;
-          const float rg = sigmoidf(ar[r] + br);
-          const float zg = sigmoidf(az[r] + bz);
-          const float ghn = ghn_[r] + bhn;
-          const float ng = tanh_fast(gin[r] + bin + rg * ghn);
-          const float hprev = Fc[ai(n, m)];
-          const float hn = (1.f - zg) * ng + zg * hprev;
-          Fn[ai(n, m)] = hn;
-          if (m < nr) {
-            float* g = p.gates + (rb + m) * 4 * D;
-            g[n] = rg;
-            g[D + n] = zg;
-            g[2 * D + n] = ng;
-            g[3 * D + n] = ghn;
-            p.featx[((size_t)(t + 1) * N + r0 + m) * F + n] = hn;
-          }
-        }
+        for (int r = 0; r < 4; ++r) rg[r] = sigmoidf(rg[r]);
+        if (st) bstq(q_gates, gv, gs, rg, nv);
+        const f32x4v ghn = ghn_ + ldbias(rw, p.Bhh + 8u * D, n);
+        if (st) bstq(q_gates, gv + 12u * D, gs, ghn, nv);
+        f32x4v ng = gin + ldbias(rw, p.Bih + 8u * D, n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ng[r] = tanh_fast(ng[r] + rg[r] * ghn[r]);
+        if (st) bstq(q_gates, gv + 8u * D, gs, ng, nv);
+        f32x4v zg = az + ldbias(rw, p.Bih + 4u * D, n) + ldbias(rw, p.Bhh + 4u * D, n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zg[r] = sigmoidf(zg[r]);
+        if (st) bstq(q_gates, gv + 4u * D, gs, zg, nv);
+        const f32x4v hprev = ldq(Fc, n, lm);
+        f32x4v hn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hn[r] = (1.f - zg[r]) * ng[r] + zg[r] * hprev[r];
+        stq(Fn, n, lm, hn);
+        if (st) bstq(q_featx, 4u * (lrow * F + n), 4u * (tN + N) * F, hn, nv);
       }
     };
-    if (g0) gru_tile(w0, w1, gcol0, wave * 16 + (lane & 15), g1, gcol1);
+    if (g0) gru_tile(w0, w1, gcol0, wave * 16 + 4 * lq, g1, gcol1);
     else dense_open<BW>(w1, rw, p.Wbp, Hd, wave, lane);
-    if (g1) gru_tile(w1, w0, gcol1, (wave + kW) * 16 + (lane & 15), false, gcol1);
+    if (g1) gru_tile(w1, w0, gcol1, (wave + kW) * 16 + 4 * lq, false, gcol1);
     wc = g1 ? w0 : w1;  // where the prior head's stream was opened
     __syncthreads();
     // ---------------- prior head
     dense_open<BW>(w1, rw, p.Wsp, 2 * S, wave, lane);
-    dense_run<BW>(Fn, wc, rw, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_run<BW>(Fn, wc, rw, Hd, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
-      const float bv = p.bbp[n];
+      const f32x4v bv = ldbias(rw, p.Bbp, n0);
+      f32x4v v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * lq + r;
-        const float v = elu(acc[r] + bv);
-        HB[ai(n, m)] = v;
-        if (m < nr) p.hp[(rb + m) * Hd + n] = v;
-      }
+      for (int r = 0; r < 4; ++r) v[r] = elu(acc[r] + bv[r]);
+      stq(HB, n0, lm, v);
+      if (lst) bstq(q_hp, 4u * (lrow * Hd + n0), 4u * tN * Hd, v, 4);
     });
     __syncthreads();
     dense_open<BF>(w0, rw, p.aW[0], Hd, wave, lane);  // the next step's first layer
-    dense_run<BW>(HB, w1, rw, 2 * S, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_run<BW>(HB, w1, rw, 2 * S, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
-      const float bv = p.bsp[n];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) SM[ai(n, 4 * lq + r)] = acc[r] + bv;
+      stq(SM, n0, lm, acc + ldbias(rw, p.Bsp, n0));
     });
     __syncthreads();
     for (int i = tid; i < kR * S; i += 512) {
@@ -284,10 +284,12 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lq = lane >> 4;
+  const int lq = lane >> 4, lm = lane & 15;  // a lane's quad: tile row lm, columns 16 tile + 4 lq .. + 3
   const int r0 = blockIdx.x * kR;
   const int nr = min(kR, N - r0);
   const __amdgpu_buffer_rsrc_t rw = wrsrc(p.wpack, p.wbytes);
+  const __amdgpu_buffer_rsrc_t q_hp = arsrc(p.hp), q_e = arsrc(p.e);  // saved activations, read as quads
+  const unsigned lrow = (unsigned)(r0 + min(lm, nr - 1));
 
   for (int i = tid; i < lds_floats / 4; i += 512) reinterpret_cast<f32x4v*>(lds)[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
   const int gcol0 = min(wave * 16 + (lane & 15), D - 1), gcol1 = min((wave + kW) * 16 + (lane & 15), D - 1);
   for (int t = Hm - 1; t >= 0; --t) {
     const size_t rb = (size_t)t * N + r0;
+    const unsigned tN = (unsigned)(t * N);
     // ---- G += dfeat[t]
     for (int i = tid; i < kR * F; i += 512) {
       const int row = i / F, f = i % F;
@@ -325,25 +328,20 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
     __syncthreads();
     // ---- X1 = (d out @ W_sp) * elu'(hp)
     dense_open<BW>(w1, rw, p.Wbp, D, wave, lane);
-    dense_run<BS>(SM, w0, rw, Hd, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_run<BS>(SM, w0, rw, Hd, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
+      const f32x4v h = bldq(q_hp, 4u * (lrow * Hd + n0), 4u * tN * Hd, 4);
+      f32x4v v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * lq + r;
-        const float h = m < nr ? p.hp[(rb + m) * Hd + n] : 0.f;
-        X1[ai(n, m)] = acc[r] * elu_grad_from_out(h);
-      }
+      for (int r = 0; r < 4; ++r) v[r] = acc[r] * elu_grad_from_out(h[r]);
+      stq(X1, n0, lm, v);
     });
     __syncthreads();
     // ---- X2 = d belief_{t+1} = Gb + X1 @ W_bp
     wopen<BW>(w0, rw, g0, p.Whh[0], D, gcol0, p.Wih[0], D, gcol0, true, lane);  // the gate products' first stream
-    dense_run<BW>(X1, w1, rw, D, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_run<BW>(X1, w1, rw, D, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * lq + r;
-        X2[ai(n, m)] = acc[r] + Gb[ai(n, m)];
-      }
+      stq(X2, n0, lm, acc + ldq(Gb, n0, lm));
     });
     __syncthreads();
     // ---- GRU gates (element-wise): X2 <- g_r, X1 <- g_z, X3 <- g_n, X4 <- g_n * r, Gb <- d * z
@@ -387,30 +385,29 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
       __syncthreads();  // every wave has finished reading X1..X4
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int n = (wave + i * kW) * 16 + (lane & 15);
+        const int n0 = (wave + i * kW) * 16 + 4 * lq;
         const f32x4v& ah = i ? ah1 : ah0;
         const f32x4v& ae = i ? ae1 : ae0;
-        if ((i ? g1 : g0) && n < D) {
+        if ((i ? g1 : g0) && n0 < D) {
+          stq(Gb, n0, lm, ldq(Gb, n0, lm) + ah);
+          const f32x4v ev = bldq(q_e, 4u * (lrow * D + n0), 4u * tN * D, 4);
+          f32x4v v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = 4 * lq + r;
-            Gb[ai(n, m)] += ah[r];
-            const float ev = m < nr ? p.e[(rb + m) * D + n] : 0.f;
-            X4[ai(n, m)] = ae[r] * elu_grad_from_out(ev);  // d pre-activation of fc_embed_state_action
-          }
+          for (int r = 0; r < 4; ++r) v[r] = ae[r] * elu_grad_from_out(ev[r]);
+          stq(X4, n0, lm, v);  // d pre-activation of fc_embed_state_action
         }
       }
     }
     __syncthreads();
     // ---- d [state_t | action_t] = X4 @ W_sa
     dense_open<BS>(w1, rw, p.Wsp, Hd, wave, lane);  // the next (earlier) step's first layer
-    dense_run<BW>(X4, w0, rw, X, wave, lane, [=](bool ok, int n, const f32x4v& acc) {
+    dense_run<BW>(X4, w0, rw, X, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * lq + r;
-        if (n < S) Gs[ai(n, m)] = acc[r];
-        else SM[ai(n, m)] = acc[r];
+      for (int r = 0; r < 4; ++r) {  // a quad may straddle the state | action boundary
+        const int n = n0 + r;
+        if (n < S) Gs[ai(n, lm)] = acc[r];
+        else if (n < X) SM[ai(n, lm)] = acc[r];
       }
     });
     __syncthreads();
@@ -449,13 +446,17 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
 constexpr int kBF = 15, kBW = 13, kBX = 3, kBS = 4;
 bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers) {
   auto blk = [](int64_t k) { return pad16((int)k) >> 4; };
-  return n_actor_layers == 5 && blk(D) == kBW && blk(Hd) == kBW && blk(D + S) == kBF && blk(S + A) == kBX &&
+  return n_actor_layers == 5 && D % 4 == 0 && Hd % 4 == 0 && blk(D) == kBW && blk(Hd) == kBW && blk(D + S) == kBF &&
+         blk(S + A) == kBX &&
          blk(2 * S) == kBS && 2 * A <= 16 && (Hm + 1) * N * 4 * D < kMaxIdx;
 }
 
 size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
   return pack_floats(Hd, D + S) + 3 * pack_floats(Hd, Hd) + pack_floats(2 * A, Hd) + pack_floats(D, S + A) +
-         2 * pack_floats(3 * D, D) + pack_floats(Hd, D) + pack_floats(2 * S, Hd);
+         2 * pack_floats(3 * D, D) + pack_floats(Hd, D) + pack_floats(2 * S, Hd) +
+         // bias vectors: 4 actor hidden + head, fc_embed_state_action, the GRU's two, prior hidden, prior out
+         5 * pack_floats(1, Hd) + pack_floats(1, 2 * A) + pack_floats(1, D) + 2 * pack_floats(1, 3 * D) +
+         pack_floats(1, 2 * S);
 }
 size_t imagine_fused_bwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
   return pack_floats(Hd, 2 * S) + pack_floats(D, Hd) + 6 * pack_floats(D, D) + pack_floats(S + A, D);
@@ -484,18 +485,22 @@ int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
   const int nout[5] = {(int)Hd, (int)Hd, (int)Hd, (int)Hd, (int)(2 * A)};
   for (int l = 0; l < 5; ++l) {
     a.aW[l] = add(ap[2 * l], nout[l], kin[l], kin[l], 1);
-    a.ab[l] = ap[2 * l + 1];
+    a.aB[l] = add(ap[2 * l + 1], 1, nout[l], 0, 1);  // a vector: copied, zero-padded to 16
   }
   a.Wsa = add(rp[0], (int)D, X, X, 1);
   a.Wih = add(rp[2], (int)(3 * D), (int)D, (int)D, 1);
   a.Whh = add(rp[3], (int)(3 * D), (int)D, (int)D, 1);
   a.Wbp = add(rp[6], (int)Hd, (int)D, (int)D, 1);
   a.Wsp = add(rp[8], (int)(2 * S), (int)Hd, (int)Hd, 1);
+  a.Bsa = add(rp[1], 1, (int)D, 0, 1);
+  a.Bih = add(rp[4], 1, (int)(3 * D), 0, 1);
+  a.Bhh = add(rp[5], 1, (int)(3 * D), 0, 1);
+  a.Bbp = add(rp[7], 1, (int)Hd, 0, 1);
+  a.Bsp = add(rp[9], 1, (int)(2 * S), 0, 1);
   a.wpack = w_begin;
   a.wbytes = (unsigned)((w - w_begin) * sizeof(float));
   int rc = launch_pack(pa, stream);
   if (rc) return rc;
-  a.bsa = rp[1]; a.bih = rp[4]; a.bhh = rp[5]; a.bbp = rp[7]; a.bsp = rp[9];
   a.belief0 = belief0; a.state0 = state0; a.eps_act = eps_act; a.eps_prior = eps_prior;
   a.min_std = min_std; a.a_min_std = a_min_std; a.a_init_std = a_init_std; a.a_mean_scale = a_mean_scale;
   a.featx = featx; a.prior_mean = prior_mean; a.prior_std = prior_std; a.a_hidden = a_hidden; a.a_raw = a_raw;

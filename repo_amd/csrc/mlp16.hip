@@ -2,8 +2,8 @@
 //
 // A head is in_dim -> hidden (ELU) x (L-1) -> out_dim.  Layer by layer through the GEMM engine every hidden
 // activation is written to HBM and read back by the next launch, and a 200-wide layer is too small a GEMM to fill
-// the chip (0.35-0.4 of the fp32 MFMA peak in isolation, 4-5 launches per call).  Here a workgroup owns 16 or 32 rows
-// for the whole chain: activations stay in LDS (k4-interleaved tiles, rowtile.h), weights stream from L2 as packed
+// the chip (0.35-0.4 of the fp32 MFMA peak in isolation, 4-5 launches per call).  Here a (persistent) workgroup takes
+// 16 or 32 rows at a time through the whole chain: activations stay in LDS (k4-interleaved tiles, rowtile.h), weights stream from L2 as packed
 // 16-byte fragments one stage ahead of their use, and the hidden activations leave the CU once, as the values the
 // backward pass needs.  The reverse chain (d out -> d pre-activations -> d input) has the same shape with the
 // transposed packs; it emits the per-layer pre-activation gradients for the weight-gradient GEMMs.

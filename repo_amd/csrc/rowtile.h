@@ -22,7 +22,7 @@ struct PackJob {
   float* dst;
   int N, K, sn, sk;
 };
-constexpr int kMaxJobs = 12;
+constexpr int kMaxJobs = 24;  // weight matrices + bias vectors of one call
 struct PackArgs {
   PackJob job[kMaxJobs];
   int njobs;
@@ -92,7 +92,11 @@ __device__ __forceinline__ void wopen(WWin& w, __amdgpu_buffer_rsrc_t rw, bool a
     w.b1[b] = wld(rw, w.v1, W1 + b * w.s1);
   }
 }
-// acc0 (+ acc1) += A[16 x K] * the stream's column tile(s).  A0/A1: LDS tiles (k4-interleaved).
+// acc0 (+ acc1) += (A[16 x K] * the stream's column tile(s))^T.  A0/A1: LDS tiles (k4-interleaved).  The weights
+// are the MFMA's A operand and the activations its B operand (the two fragments have the same lane layout), so the
+// accumulator is transposed: lane l holds tile row l % 16 and the FOUR CONSECUTIVE columns 4 * (l / 16) + r of the
+// column tile -- a "quad": one 16-byte LDS access in the k4-interleaved tile of the next layer, one 16-byte global
+// access in a row-major activation.
 template <int NBLK>
 __device__ __forceinline__ void wrun(f32x4v& acc0, f32x4v& acc1, const float* A0, const float* A1, WWin& w,
                                      __amdgpu_buffer_rsrc_t rw, int lane) {
@@ -107,8 +111,8 @@ __device__ __forceinline__ void wrun(f32x4v& acc0, f32x4v& acc1, const float* A0
     const f32x4v a1 = (A1 == A0) ? a0 : *reinterpret_cast<const f32x4v*>(a1p + b * 16 * kR);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], w.b0[b % PD][j], acc0, 0, 0, 0);
-      if (w.two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], w.b1[b % PD][j], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.b0[b % PD][j], a0[j], acc0, 0, 0, 0);
+      if (w.two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.b1[b % PD][j], a1[j], acc1, 0, 0, 0);
     }
     if (b + PD < NBLK) {
       w.b0[b % PD] = wld(rw, w.v0, w.W0 + (b + PD) * w.s0);
@@ -125,16 +129,55 @@ __device__ __forceinline__ void dense_open(WWin& w, __amdgpu_buffer_rsrc_t rw, u
   wopen<NBLK>(w, rw, wave < ntiles, W, N, min(wave * 16 + n, N - 1), W, N, min((wave + kW) * 16 + n, N - 1),
               wave + kW < ntiles, lane);
 }
-// epi(valid, n, acc): n = this lane's column, acc[r] belongs to row 4*(lane>>4) + r.
+// epi(valid, n0, acc): acc[r] = element (row lane % 16, column n0 + r) of the layer's output, n0 = 16 tile + 4 (lane / 16);
+// valid = n0 < N (columns n0 + r >= N of a ragged last quad hold zeros from the padded pack).
 template <int NBLK, class Epi>
 __device__ __forceinline__ void dense_run(const float* A, WWin& w, __amdgpu_buffer_rsrc_t rw, int N, int wave, int lane,
                                           Epi epi) {
   if (!w.act) return;
-  const int c0 = wave * 16 + (lane & 15), c1 = c0 + kW * 16;
+  const int c0 = wave * 16 + 4 * (lane >> 4), c1 = c0 + kW * 16;
   f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
   wrun<NBLK>(acc0, acc1, A, A, w, rw, lane);
   epi(c0 < N, c0, acc0);
   if (w.two) epi(c1 < N, c1, acc1);
+}
+
+// ---- quads.  Tile side: columns n0 .. n0+3 (n0 % 4 == 0) of tile row m are one 16-byte word.
+__device__ __forceinline__ f32x4v ldq(const float* T, int n0, int m) {
+  return *reinterpret_cast<const f32x4v*>(T + ((n0 >> 2) * kR + m) * 4);
+}
+__device__ __forceinline__ void stq(float* T, int n0, int m, const f32x4v& v) {
+  *reinterpret_cast<f32x4v*>(T + ((n0 >> 2) * kR + m) * 4) = v;
+}
+// Global side: a quad of a row-major activation through a raw buffer (dword alignment is all a buffer access
+// needs): voff = this lane's byte offset (32 bits, invariant over the step loop -- a 64-bit address per store site
+// would be hoisted out of that loop and spilled), soff = the step's byte offset (scalar); nv = valid columns of the
+// quad (>= 4: all).
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t arsrc(const float* p) {  // whole address space behind p
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xfffffffcu, 0x00020000);
+}
+__device__ __forceinline__ void bstq(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4v& v, int nv) {
+  if (nv >= 4) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, soff, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < nv) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), r, voff + 4u * i, soff, 0);
+  }
+}
+__device__ __forceinline__ f32x4v bldq(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int nv) {
+  if (nv >= 4) return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  f32x4v v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (i < nv) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + 4u * i, soff, 0));
+  return v;
+}
+// bias quad: the bias vectors are packed behind the weights (N = 1 jobs: copied, zero-padded to 16), so a quad is one
+// aligned 16-byte buffer load whose lane offset does not depend on the vector
+__device__ __forceinline__ f32x4v ldbias(__amdgpu_buffer_rsrc_t rw, unsigned boff, int n0) {
+  return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, 4u * (unsigned)n0, boff, 0));
 }
 
 }  // namespace repo
