@@ -285,8 +285,8 @@ def rendezvous_only(world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--algo", default=None, help="override the config's algorithm (repo | dreamer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl_$TAG
 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$TAG -- python3 $R/bench.py --no-cpu-baseline --steps 12 --warmup 4 "$@" > /tmp/tl_$TAG.log 2>&1
 python3 - <<PY > $R/gpurun_out/${TAG}_timeline.txt
-import csv, glob, re
+import csv, glob, os, re
 csv.field_size_limit(1 << 30)
 f = glob.glob('/tmp/tl_$TAG/*/*_kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
@@ -28,7 +28,7 @@ busy = {}
 for s, e, n, q, st in ev[i0:i1 + 40]:
     key = (q, st)
     busy[key] = busy.get(key, 0) + (e - s)
-    if any(k in n for k in ('observe', 'imagine', 'clip_adam', 'dconv_dec4_nll', 'uconv_scatter', 'dconv_wgrad', 'dconv_down', 'tanh_normal', 'lambda', 'kl_kernel', 'index', 'Index')) :
+    if os.environ.get('TIMELINE_ALL') or any(k in n for k in ('observe', 'imagine', 'clip_adam', 'dconv_dec4_nll', 'uconv_scatter', 'dconv_wgrad', 'dconv_down', 'tanh_normal', 'lambda', 'kl_kernel', 'index', 'Index')) :
         print(f"{(s-t0)/1e3:9.1f} {(e-t0)/1e3:9.1f} {(e-s)/1e3:8.1f}  {q:>5s} {st:>6s}  {n}")
 print("# busy time per (queue, stream) over the window, us:", {k: round(v / 1e3) for k, v in busy.items()})
 PY
