@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
     dense_open<BW>(w1, rw, p.Wbp, D, wave, lane);
     dense_run<BS>(SM, w0, rw, Hd, wave, lane, [=](bool ok, int n0, const f32x4v& acc) {
       if (!ok) return;
-      const f32x4v h = bldq(q_hp, 4u * (lrow * Hd + n0), 4u * tN * Hd, 4);
+      const f32x4v h = bldq(q_hp, 4u * (lrow * Hd + n0), 4u * tN * Hd);
       f32x4v v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[r] * elu_grad_from_out(h[r]);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
         const f32x4v& ae = i ? ae1 : ae0;
         if ((i ? g1 : g0) && n0 < D) {
           stq(Gb, n0, lm, ldq(Gb, n0, lm) + ah);
-          const f32x4v ev = bldq(q_e, 4u * (lrow * D + n0), 4u * tN * D, 4);
+          const f32x4v ev = bldq(q_e, 4u * (lrow * D + n0), 4u * tN * D);
           f32x4v v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = ae[r] * elu_grad_from_out(ev[r]);

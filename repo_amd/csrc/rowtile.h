@@ -158,21 +158,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t arsrc(const float* p) {  // wh
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xfffffffcu, 0x00020000);
 }
 __device__ __forceinline__ void bstq(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4v& v, int nv) {
+  // The elements of a ragged quad are copied out BEFORE the branch and pinned in registers of their own: with the
+  // extraction inside the else-branch the compiler (ROCm 7.2) stored element 0 three times (the other side of the
+  // branch ends the vector's live range).
+  float e0 = v[0], e1 = v[1], e2 = v[2];
+  asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2));
   if (nv >= 4) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, soff, 0);
   } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if (i < nv) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), r, voff + 4u * i, soff, 0);
+    if (nv > 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e0), r, voff, soff, 0);
+    if (nv > 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e1), r, voff + 4u, soff, 0);
+    if (nv > 2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e2), r, voff + 8u, soff, 0);
   }
 }
-__device__ __forceinline__ f32x4v bldq(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int nv) {
-  if (nv >= 4) return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-  f32x4v v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    if (i < nv) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + 4u * i, soff, 0));
-  return v;
+__device__ __forceinline__ f32x4v bldq(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {  // a whole quad
+  return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 // bias quad: the bias vectors are packed behind the weights (N = 1 jobs: copied, zero-padded to 16), so a quad is one
 // aligned 16-byte buffer load whose lane offset does not depend on the vector

@@ -162,6 +162,14 @@ def test_imagine_fwd_bwd(ops, Hm, N, A):
         e = relerr(g, w)
         log(f"imagine Hm={Hm} N={N} {n}: {e:.2e}")
         assert e < FTOL
+    # everything the forward saves for the backward is an output of the entry point: the actor's raw head outputs
+    # (2A columns: a ragged last quad for A = 7) and its hidden activations against the oracle's MLP on the same rows
+    feat_all = sv.featx[:Hm].reshape(Hm * N, D + S).cpu()
+    with torch.no_grad():
+        raw_want = ro.mlp_head({k: v.detach() for k, v in ap.items()}, feat_all[:, :D], feat_all[:, D:], 5)
+    e = relerr(sv.a_raw[:Hm * N], raw_want)
+    log(f"imagine Hm={Hm} N={N} A={A} saved actor raw outputs: {e:.2e}")
+    assert e < FTOL
     ub, us, um, usd = (rnd(rs, *x.shape, scale=0.1) for x in (ib, istate, im, isd))
     ((ib * ub).sum() + (istate * us).sum() + (im * um).sum() + (isd * usd).sum()).backward()
     dfeat = torch.cat([ub, us], dim=2).cuda().contiguous()
