@@ -34,8 +34,11 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+# dmabuf IPC between the ranks' processes (RCCL); read when the HIP runtime starts, so set before the first GPU call
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
