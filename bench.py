@@ -13,11 +13,15 @@ the sampler draws indices on the host exactly like the reference, the 30.7 MB ba
 device), so `value` is the rate with inputs resident in HBM; the same K steps on ONE resident batch are
 timed afterwards and reported as `resident_batch_ms` (what round 1's line measured).
 
-N > 1: data parallel over batch rows, weak scaling (B=50 per GPU, global batch 50*N), RCCL all-reduce of
-the flat gradient buffers.  `python bench.py --gpus N` starts its own ranks (one child process per GPU via
-torch.distributed.run, before this process touches the GPU); when an external launcher already set
-RANK/WORLD_SIZE it runs as that rank.  Rank 0 prints ONE JSON line; `n_gpus` is the number of ranks the
-process group saw.
+N > 1: data parallel over batch rows, RCCL all-reduce of the flat gradient buffers (model gradient in two
+buckets overlapped with the encoder backward, actor + critic in one).  `value` is WEAK scaling (B=50 per GPU,
+global batch 50*N); the same line carries a `strong` object: ONE global batch of 50 sequences dealt 7,7,6,...
+over the ranks (BASELINE's "updates/sec (B=50 ...) at 1/2/4/8"), each rank sampling its shard from its ring,
+timed the same way (barrier + synchronize on both sides, max over ranks), plus the per-rank time spent inside
+the all-reduces (`allreduce_ms`, HIP events around the collectives of the weak run).  `python bench.py --gpus N`
+starts its own ranks (one child process per GPU via torch.distributed.run, before this process touches the
+GPU); when an external launcher already set RANK/WORLD_SIZE it runs as that rank.  Rank 0 prints ONE JSON
+line; `n_gpus` is the number of ranks the process group saw.
 
 `roofline` is for the dominant kernel (the largest single launch: the decoder's 64->32 transposed
 convolution, `uconv_scatter_kernel<GDec3>`): algorithmic FLOPs of that launch / its average duration measured
@@ -153,6 +157,53 @@ class LaunchTimer:
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
 
 
+class AllReduceTimer:
+    """HIP events around every gradient all-reduce of this rank during the timed updates: the blocking ones are
+    bracketed on the calling stream; a bucket begun asynchronously is timed from its begin to the point the
+    calling stream has waited for it (so the figure is the exchange's span, part of which overlaps the encoder
+    backward)."""
+
+    def __init__(self, dp):
+        self.dp, self.pairs = dp, []
+        self._orig = (dp.all_reduce, dp.all_reduce_begin, dp.all_reduce_end)
+        t = self
+
+        def all_reduce(x):
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = t._orig[0](x)
+            e1.record(s)
+            t.pairs.append((x.numel() * 4, e0, e1))
+            return out
+
+        def begin(x, stream=None):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            w = t._orig[1](x, stream=stream)
+            return (w, x.numel() * 4, e0)
+
+        def end(works):
+            t._orig[2]([w for w, _, _ in works])
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            for _, nbytes, e0 in works:
+                t.pairs.append((nbytes, e0, e1))
+
+        dp.all_reduce, dp.all_reduce_begin, dp.all_reduce_end = all_reduce, begin, end
+
+    def stop(self):
+        self.dp.all_reduce, self.dp.all_reduce_begin, self.dp.all_reduce_end = self._orig
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        by = {}
+        for nbytes, e0, e1 in self.pairs:
+            by.setdefault(nbytes, []).append(e0.elapsed_time(e1))
+        return {"rank": 0, "per_update_by_bucket_bytes": {str(k): round(sum(v) / steps, 4) for k, v in sorted(by.items())},
+                "note": "rank 0; span from issue to the consumer stream's join, summed per update"}
+
+
 def dominant_kernel_isolated(nimg, iters=20):
     """The same launch alone on an idle GPU (no other stream running): the kernel's own speed."""
     from repo_amd import ops
@@ -174,22 +225,41 @@ def dominant_kernel_isolated(nimg, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
+def under_profiler():
+    """rocprofv3 preloads its tool library into the profiled process: the isolated re-runs of the dominant
+    kernel are skipped then, so that its row in the kernel trace holds the launches INSIDE the updates only."""
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("HSA_TOOLS_LIB", "")
+    return "rocprof" in pre or "ROCPROFILER_REGISTER_FORCE_LOAD" in os.environ or os.environ.get("REPO_BENCH_NO_ISOLATED") == "1"
+
+
+ROCPROF_SUMMARY = os.path.join(ROOT, "profiles", "dominant_kernel_rocprof.json")
+
+
 def roofline(timer, nimg):
     """Decoder conv3 (64x13x13 -> 32x30x30, k6 s2): the largest single launch of the update (61.05 GFLOP at
-    nimg=2450: every (input pixel, cin, cout, tap) MAC once)."""
+    nimg=2450: every (input pixel, cin, cout, tap) MAC once).  `frac` uses the HIP-event
+    duration of the launches inside the timed updates; `kernel_ms_rocprof` is the same kernel's average in the
+    committed rocprofv3 --kernel-trace of the same command (in-update launches only)."""
     flop = 2.0 * nimg * 169 * 64 * 32 * 36
     ms = timer.mean_ms()
-    iso = dominant_kernel_isolated(nimg)
+    iso = None if under_profiler() else dominant_kernel_isolated(nimg)
     achieved = flop / (ms * 1e-3) / 1e12
     out = {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
         "kernel": "uconv_scatter_kernel<Geo<32,64,30,6>> (decoder conv3 forward)",
         "ms_per_launch": round(ms, 4), "launches_timed": len(timer.pairs), "flop_per_launch": flop,
-        "timing": "HIP events on the launch stream inside the timed updates (other streams of the update run beside it)",
-        "isolated_ms_per_launch": round(iso, 4),
-        "isolated_frac": round(flop / (iso * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+        "timing": "HIP events on the launch stream inside the timed updates (other streams of the update run "
+                  "beside it); frac = flop_per_launch / ms_per_launch / peak",
     }
+    if iso is not None:
+        out["isolated_ms_per_launch"] = round(iso, 4)
+        out["isolated_frac"] = round(flop / (iso * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+    if os.path.exists(ROCPROF_SUMMARY):
+        rp = json.load(open(ROCPROF_SUMMARY))
+        if rp.get("nimg") == nimg:
+            out["kernel_ms_rocprof"] = rp.get("avg_ms_in_update")
+            out["kernel_ms_rocprof_source"] = rp.get("source")
     if os.path.exists(PMC_SUMMARY):
         pmc = json.load(open(PMC_SUMMARY))
         if pmc.get("nimg") == nimg:
@@ -199,7 +269,7 @@ def roofline(timer, nimg):
     return out
 
 
-def _cpu_baseline_worker(q, threads, warm, timed):
+def _cpu_baseline_worker(q, threads, warm, timed, B, A, algo):
     """Child process: the CPU oracle on the full synthetic batch."""
     import time as _t
 
@@ -209,9 +279,8 @@ def _cpu_baseline_worker(q, threads, warm, timed):
     from oracle import fixtures as fx
     from oracle.repo_oracle import OracleAgent
 
-    B, A = 50, 6
     batch = synthetic_batch(1234, B, A)
-    cfg = fx.default_config(algo="repo", batch_size=B, chunk_size=L, horizon=H)
+    cfg = fx.default_config(algo=algo, batch_size=B, chunk_size=L, horizon=H)
     agent = OracleAgent(cfg, A, seed=7)
     noise = fx.make_noise(L, B, H, A, seed=1)
     for _ in range(warm):
@@ -222,17 +291,17 @@ def _cpu_baseline_worker(q, threads, warm, timed):
     q.put((_t.perf_counter() - t0) / timed)
 
 
-def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0):
+def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0, B=50, A=6, algo="repo"):
     """the CPU oracle (PyTorch fp32 restatement of the reference update, validated against the
     reference's goldens) on the SAME full workload -- B=50, L=50, H=15 -- 2 warm-up + 3 timed updates on
-    this box's host cores, in a child process that is killed after `timeout_s`."""
+    this box's host cores, in a child process that is killed after `timeout_s` (any --config: its B, A, algo)."""
     import multiprocessing as mp
 
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = threads or max(1, min(avail, 32))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_cpu_baseline_worker, args=(q, threads, warm, timed))
+    p = ctx.Process(target=_cpu_baseline_worker, args=(q, threads, warm, timed, B, A, algo))
     p.start()
     p.join(timeout_s)
     base = {"value": None, "unit": "updates/s", "cores": threads, "kind": "port"}
@@ -246,7 +315,7 @@ def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0):
         return {**base, "sample": f"oracle child exited with code {p.exitcode} before reporting"}
     return {
         **base, "value": round(1.0 / dt, 5),
-        "sample": f"{timed} timed updates after {warm} warm-up on the full batch (B=50, L={L}, H={H}, A=6), "
+        "sample": f"{timed} timed updates after {warm} warm-up on the full batch (algo={algo}, B={B}, L={L}, H={H}, A={A}), "
                   f"{dt:.2f} s per update; PyTorch {torch.__version__} CPU, {threads} threads of {avail} available cores",
     }
 
@@ -389,17 +458,45 @@ def main():
     main_loop(args.warmup)
     from repo_amd import ops
 
+    ar = AllReduceTimer(dp) if dp is not None else None
     timer = LaunchTimer(ops.DEC3)
     with timer:
         dt = timed(main_loop, args.steps)
+    if ar is not None:
+        ar.stop()
     run_resident(2)
     dt_res = timed(run_resident, args.steps)
+
+    # N > 1: the same line also carries STRONG scaling -- one global batch of B sequences dealt 7,7,6,... over
+    # the ranks, every rank sampling its shard from its own ring (a collective-free re-shard: reset_counts()
+    # on all ranks, then the first global_count() of the next update gathers the new shard sizes)
+    strong = None
+    if dp is not None and world > 1 and not args.strong:
+        from repo_amd.parallel import shard_rows
+
+        lo, hi = shard_rows(B, world, rank)
+        if hi > lo:
+            Bl_weak = Bl
+            Bl = cfg.batch_size = hi - lo
+            agent.synchronize()
+            dp.reset_counts()
+            run_from_ring(max(3, args.warmup // 2))
+            dt_s = timed(run_from_ring, args.steps)
+            strong = {"value": round(args.steps / dt_s, 3), "unit": "updates/s", "ms_per_step": round(dt_s / args.steps * 1e3, 3),
+                      "global_batch": B, "shards": [b - a for a, b in (shard_rows(B, world, r) for r in range(world))],
+                      "algorithmic_tflops": round(FLOP_PER_UPDATE_B50 * B / 50.0 * args.steps / dt_s / 1e12, 2)}
+            Bl = cfg.batch_size = Bl_weak
+            dp.reset_counts()
+        else:
+            strong = {"value": None, "note": f"B={B} < {world} ranks: an empty shard"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         nranks = dp.world_size if dp is not None else 1
         value = (1 if args.strong else nranks) * args.steps / dt
-        flop = FLOP_PER_UPDATE_B50 * (Bl if args.strong else B) / 50.0
+        # FLOPs of one update of the GLOBAL batch this line's `value` counts: B sequences (--strong: one global
+        # batch sharded over the ranks) or B per rank (weak)
+        flop = FLOP_PER_UPDATE_B50 * B / 50.0
         line = {
             "metric": "world-model+imagine updates/sec (B=50,L=50,64x64x3)" if args.config != "c4" else
                       "world-model+imagine updates/sec (B=32,L=50,64x64x3,A=7)",
@@ -421,15 +518,19 @@ def main():
                 "global_batch": B if args.strong else B * nranks, "per_gpu_batch": Bl,
                 "seq_len": L, "horizon": H, "ring_frames": RING_FRAMES,
                 "parallelism": f"dp{nranks}", "sequences_per_s": round(value * B, 2),
-                "algorithmic_tflops": round(flop * args.steps / dt * (1 if args.strong else nranks) / 1e12, 2),
-                "frac_of_fp32_mfma_peak_all_gpus": round(flop * args.steps / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "algorithmic_tflops": round(flop * value / 1e12, 2),
+                "frac_of_fp32_mfma_peak_all_gpus": round(flop * value / 1e12 / FP32_MFMA_PEAK_TFLOPS / nranks, 4),
             },
             "resident_batch_ms": round(dt_res / args.steps * 1e3, 3),
             "last_scalars": {k: round(float(v), 6) for k, v in agent.last_scalars.items()},
         }
         line["roofline"] = roofline(timer, (L - 1) * Bl)
-        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
-            line["cpu_baseline"] = cpu_baseline()
+        if strong is not None:
+            line["strong"] = strong
+        if ar is not None:
+            line["allreduce_ms"] = ar.summary(args.steps)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B=B, A=A, algo=algo)
         print(json.dumps(line), flush=True)
     if dp is not None:
         dp.barrier()

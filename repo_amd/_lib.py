@@ -42,6 +42,11 @@ def parse_header(path=HEADER):
                 mm = re.match(r"(.+?)(\w+)$", a)
                 params.append((mm.group(1).strip(), mm.group(2)))
         protos[name] = (ret.replace(" ", ""), params)
+    # every declaration must have been understood: a prototype the pattern above fails to match would silently
+    # lose its argtypes (ctypes would then pass 64-bit pointers as C ints)
+    declared = set(re.findall(r"\b(repo_\w+)\s*\(", txt))
+    if declared != set(protos):
+        raise RepoHipError(f"include/repo_hip.h: unparsed prototypes {sorted(declared ^ set(protos))}")
     return protos
 
 

@@ -48,7 +48,7 @@ def _as_video(frames, fps):
     a plain (frames, fps) record."""
     try:
         from common.logger import Video  # the application's own logger module, if any
-    except Exception:  # noqa: BLE001
+    except (ImportError, AttributeError):  # no such module / a `common` package without a Video class
         from ...common.utils import Video
     return Video(frames, fps)
 
@@ -69,7 +69,10 @@ class Dreamer:
         self.noise_source = None  # tests inject pre-drawn noise here
         # the update's reparameterisation noise is drawn INSIDE the kernels (counter-based Philox: include/repo_hip.h,
         # "reparameterisation noise"); the stream is keyed by torch's seed at construction and the agent owns the
-        # counter.  REPO_NOISE=torch restores torch.randn tensors (the round-1 behaviour).
+        # counter.  Seed torch BEFORE constructing the agent (torch.manual_seed afterwards does not move this
+        # stream; `seed_noise()` does); two agents built under one seed share one stream unless re-seeded.  A
+        # resumed run continues BEHIND the noise its optimiser steps already consumed (load_param_dict).
+        # REPO_NOISE=torch restores torch.randn tensors (the round-1 behaviour).
         self._noise_seed = int(torch.initial_seed()) & ((1 << 64) - 1)
         self._noise_counter = 0
         self._noise_in_kernel = os.environ.get("REPO_NOISE", "philox") == "philox"
@@ -146,11 +149,24 @@ class Dreamer:
         self.actor_model = ActorModel(
             config.belief_size, config.state_size, config.hidden_size, action_size, config.dense_activation_function
         ).to(dev)
-        self.actor_optimizer = FlatAdam(self.actor_model.parameters(), lr=config.actor_lr)
         self.value_model = ValueModel(
             config.belief_size, config.state_size, config.hidden_size, config.dense_activation_function
         ).to(dev)
-        self.value_optimizer = FlatAdam(self.value_model.parameters(), lr=config.value_lr)
+        # the actor's and the critic's flat gradients are the two halves of ONE buffer: a data-parallel job
+        # exchanges them as a single 1.18 MB bucket
+        na = FlatAdam.padded_numel(list(self.actor_model.parameters()))
+        nv = FlatAdam.padded_numel(list(self.value_model.parameters()))
+        self._ac_grad = torch.zeros(na + nv, dtype=torch.float32, device=dev)
+        self.actor_optimizer = FlatAdam(self.actor_model.parameters(), lr=config.actor_lr, grad=self._ac_grad[:na])
+        self.value_optimizer = FlatAdam(self.value_model.parameters(), lr=config.value_lr, grad=self._ac_grad[na:])
+        # model gradient buckets of a data-parallel job, in the order the backward finishes them: [decoder +
+        # reward head) is final when the decoder backward joins, [encoder + RSSM) after the encoder backward
+        n_head = len(list(self.encoder.parameters())) + len(list(self.transition_model.parameters()))
+        self._model_cut = self.model_optimizer.offsets[n_head]
+        self._model_works = []
+        # REPO_DP_BUCKETS=1: the whole 20.7 MB model gradient as ONE all-reduce after the backward (the round-2
+        # exchange; kept for A/B runs on a multi-GPU node and for the bucketed-equals-single test)
+        self._dp_two_buckets = os.environ.get("REPO_DP_BUCKETS", "2") != "1"
 
     def _pg(self, module):
         """(params, grads) of a module as detached tensors / flat-gradient views, state_dict order."""
@@ -172,6 +188,15 @@ class Dreamer:
         if self._noise_in_kernel:
             return None
         return torch.randn(*shape, device=self.device)
+
+    # one update draws 2*T*B*S + Hm*N*(A+S) + 100*Hm*N*A normals (21.3 M at B=50, L=50, H=15, A=6): a resumed run
+    # skips 2**26 per optimiser step already taken, so it never replays the noise of the run that wrote the checkpoint
+    _NOISE_STRIDE_PER_STEP = 1 << 26
+
+    def seed_noise(self, seed):
+        """Re-key the in-kernel Philox stream of the update's reparameterisation noise and rewind its counter."""
+        self._noise_seed = int(seed) & ((1 << 64) - 1)
+        self._noise_counter = 0
 
     def _draw(self, n):
         """Reserve n normals of the agent's Philox stream: (seed, offset) for one op."""
@@ -257,6 +282,7 @@ class Dreamer:
             for fn in wgrads:
                 fn()
             main.wait_stream(side)
+            self._model_bucket_begin(tail=True)   # decoder + reward-head gradients are final
             Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
             return
         # RePo: the decoder is a probe on detached latents (repo.py:46-48), so its backward is
@@ -271,14 +297,34 @@ class Dreamer:
                                  min_std=self.transition_model.min_std_dev)
         Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, side=self._wgrad_stream)
         main.wait_stream(side)
+        self._model_bucket_begin(tail=True)   # decoder + reward-head gradients are final (15.7 MB of 20.7)
         Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
+
+    def _model_bucket_begin(self, tail):
+        """Data parallel: start the SUM all-reduce of one of the two model-gradient buckets on RCCL's stream,
+        ordered behind everything enqueued so far on the current stream (every writer of the bucket has been
+        joined into it).  The decoder + reward bucket goes out while the encoder backward still computes."""
+        if self.dp is None or not self._dp_two_buckets:
+            return
+        g, cut = self.model_optimizer.grad, self._model_cut
+        if not tail:   # the last bucket: nothing left to overlap it with, exchanged in line
+            self._allreduce(g[:cut])
+            return
+        # the reverse scan's side stream is idle from here to the end of the backward: the bucket rides on it
+        self._model_works.append(self.dp.all_reduce_begin(g[cut:], stream=self._side_stream))
 
     def _model_step(self):
         # the optimiser step WRITES the world-model parameters the previous update's imagination
         # may still be reading on the actor-critic stream
         if self._ev_ac_done is not None:
             torch.cuda.current_stream(self.device).wait_event(self._ev_ac_done)
-        self._allreduce(self.model_optimizer.grad)
+        if self.dp is not None and self._dp_two_buckets:
+            self._model_bucket_begin(tail=False)  # encoder + RSSM
+            works, self._model_works = self._model_works, []
+            assert len(works) == 1, "model gradient buckets: the decoder bucket was not started by the backward"
+            self.dp.all_reduce_end(works)
+        elif self.dp is not None:
+            self._allreduce(self.model_optimizer.grad)
         self.model_optimizer.clip_and_step(self.c.grad_clip_norm)
 
     def _prep_batch(self, obs, actions, rewards, nonterms):
@@ -362,8 +408,8 @@ class Dreamer:
         with torch.cuda.stream(side):
             v_sums, dv2 = ops.scalar_nll(v_pred.view(-1)[:nv], returns.view(-1), None, 1.0 / ((Hm - 1) * gN))
             ops.mlp_bwd(pv, feats[:nv], [h[:nv] for h in v_hid], dv2.view(nv, 1), dparams=gv, dx=None)
-            self._allreduce(self.value_optimizer.grad)
-            self.value_optimizer.clip_and_step(c.grad_clip_norm)
+            if self.dp is None:
+                self.value_optimizer.clip_and_step(c.grad_clip_norm)
         # gradient at the actor trunk's output, all (Hm+1)*N rows: rollout path on steps 0..Hm-1
         # (written by the reverse rollout), entropy path on steps 1..Hm (added on top)
         d_out = torch.zeros((Hm + 1) * N, 2 * A, device=dev)
@@ -378,7 +424,12 @@ class Dreamer:
         #    same forward activations, and the chain is linear in the output gradient
         x_all = sv.featx.reshape((Hm + 1) * N, F_)
         ops.mlp_bwd(pa, x_all, [sv.a_hidden[l] for l in range(nl)], d_out, dparams=ga, accumulate_w=False, dx=None)
-        self._allreduce(self.actor_optimizer.grad)
+        if self.dp is not None:
+            # ONE bucket for both optimisers (their gradients are the halves of self._ac_grad); the critic's
+            # backward is joined first, both steps follow the exchange
+            main.wait_stream(side)
+            self._allreduce(self._ac_grad)
+            self.value_optimizer.clip_and_step(c.grad_clip_norm)
         self.actor_optimizer.clip_and_step(c.grad_clip_norm)
         main.wait_stream(side)
         self._pending_ac = (ret_sum, ent_sum, lat_sum, v_sums, Hm, gN)
@@ -401,7 +452,8 @@ class Dreamer:
         if dual is not None:
             parts.append(dual)
         buf = torch.cat([p.reshape(-1) for p in parts])
-        self._allreduce_scalars(buf, n_sum=9)
+        # the leading entries (losses) are per-rank partial sums; the gradient norms behind them are already global
+        self._allreduce_scalars(buf, n_sum=sum(p.numel() for p in parts[:5]))
         n = buf.numel()
         self._log_host[:n].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
@@ -458,7 +510,7 @@ class Dreamer:
     def _allreduce_scalars(self, buf, n_sum):
         """Loss sums are per-rank partial sums; gradient norms (already global) are not summed."""
         if self.dp is not None:
-            self.dp.all_reduce_prefix(buf, 9)
+            self.dp.all_reduce_prefix(buf, n_sum)
 
     # ------------------------------------------------------------------ update loop
     def update(self, batch, join=True):
@@ -684,6 +736,9 @@ class Dreamer:
         self.model_optimizer.load_state_dict(params["model_optimizer"])
         self.actor_optimizer.load_state_dict(params["actor_optimizer"])
         self.value_optimizer.load_state_dict(params["value_optimizer"])
+        # the checkpoint keeps the reference's key layout (no noise state in it): resume behind every normal the
+        # saved run can have drawn, instead of replaying the first updates' noise at offset 0
+        self._noise_counter = max(self._noise_counter, self.model_optimizer.step_count * self._NOISE_STRIDE_PER_STEP)
 
     def load_offline_data(self):
         """Replace the replay ring by the concatenation of every `buffer*.npz` under c.offline_dir

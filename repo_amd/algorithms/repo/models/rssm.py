@@ -42,7 +42,14 @@ class TransitionModel(nn.Module):
 
         if observations is None:
             # open-loop rollout under GIVEN actions (reference rssm.py:118: the next step is fed the prior sample):
-            # -> [beliefs, prior_states, prior_means, prior_std_devs].  Forward values only.
+            # -> [beliefs, prior_states, prior_means, prior_std_devs].  FORWARD VALUES ONLY: the kernel's prior-only
+            # mode has no backward, so a caller that expects the reference's differentiable branch is told so
+            # instead of silently receiving detached tensors.
+            if torch.is_grad_enabled() and any(
+                    t is not None and t.requires_grad for t in (prev_belief, prev_state, actions, nonterminals)):
+                raise NotImplementedError(
+                    "TransitionModel.observe(observations=None) computes forward values only (no backward through "
+                    "the open-loop rollout); call it under torch.no_grad() or detach its inputs")
             return self._observe_prior_only(prev_belief, prev_state, actions, nonterminals, noise)
         return observe_apply(self, prev_belief, prev_state, actions, observations, nonterminals, noise)
 

@@ -36,7 +36,15 @@ def adam_param_group(lr, betas, eps, n_params):
 class FlatAdam:
     """Adam over a flat parameter buffer with fused global-norm clipping."""
 
-    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+    @staticmethod
+    def padded_numel(params):
+        """Length of the flat buffer FlatAdam lays these parameters out in (16-byte aligned sub-views)."""
+        return sum((p.numel() + 3) // 4 * 4 for p in params)
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, grad=None):
+        """grad: optional caller-owned storage for the flat gradient (padded_numel floats) -- the agents
+        lay the actor's and the critic's gradients out in ONE buffer so that a data-parallel job exchanges
+        them with one collective."""
         self.params = list(params)
         assert self.params, "FlatAdam needs at least one parameter"
         self.lr, self.betas, self.eps = float(lr), tuple(betas), float(eps)
@@ -50,7 +58,10 @@ class FlatAdam:
             off += (n + 3) // 4 * 4
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        if grad is None:
+            grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        assert grad.shape == (off,) and grad.dtype == torch.float32 and grad.is_contiguous(), (grad.shape, off)
+        self.grad = grad
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -137,6 +137,9 @@ class SequenceReplayBuffer:
         self._pushed_total = getattr(self, "_pushed_total", 0) + self.capacity
         if getattr(self, "_mirror", None) is not None:
             self._mirror["synced"] = self._pushed_total - self.capacity - 1  # => everything is stale
+            bufs = self._mirror["bufs"]
+            if bufs is not None and bufs[0].shape[0] != self.capacity:
+                self._mirror["bufs"] = None  # load() / adopt_offline() changed the capacity: reallocate the mirror
 
     def _mirror_flush(self, stream):
         m = self._mirror

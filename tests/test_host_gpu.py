@@ -93,6 +93,79 @@ def test_device_mirror_batches_equal_host_sampling():
     check(6)
 
 
+def _mirror_sampling_buffer(dev):
+    """A ring whose sample() goes through the DEVICE path: indices drawn on the host exactly like the reference
+    (one np.random.choice), frames gathered on the GPU from the HBM mirror, handed back as host arrays."""
+    from repo_amd.common.buffers import SequenceReplayBuffer
+    from tests.golden import gen_golden_host as gh
+
+    class MirrorSampled(SequenceReplayBuffer):
+        def sample(self, batch_size, seq_len):
+            h = self.prefetch(batch_size, seq_len, dev)
+            got = self.acquire(h, batch_size, seq_len, dev)
+            torch.cuda.synchronize()
+            out = tuple(g.cpu().numpy() for g in got)
+            self.release(h, batch_size, seq_len, dev)
+            return out
+
+    def make(cap):
+        b = MirrorSampled(cap, gh.OBS_SHAPE, gh.ACT_SHAPE, obs_type=np.uint8)
+        b.enable_device_mirror(dev)
+        return b
+
+    return make
+
+
+def test_device_mirror_sampler_bit_exact_vs_reference_golden():
+    """Row a1 pinned on the GPU path: the script that produced tests/golden/buffer_sample.npz from the REFERENCE's
+    SequenceReplayBuffer (push, sample before / after the ring wraps, save -> load -> sample), replayed with every
+    batch gathered on the device from the HBM mirror, reproduces the reference's batches bit for bit."""
+    import tempfile
+
+    from tests.golden import gen_golden_host as gh
+
+    want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "buffer_sample.npz"))
+    got = {}
+    with tempfile.TemporaryDirectory() as td:
+        gh.drive_sampler(_mirror_sampling_buffer(torch.device("cuda", 0)), got, td)
+    assert sorted(got) == sorted(want.files)
+    for k in want.files:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, (k, got[k].dtype, got[k].shape)
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_offline_adoption_through_device_mirror_matches_reference_golden():
+    """Row f3 pinned on the GPU path: rings adopted from offline files (reference dreamer.py:566-596) equal the
+    reference-generated arrays, and batches gathered from their HBM mirror -- re-allocated at the adopted
+    capacity -- are those arrays at the host-drawn indices."""
+    import tempfile
+
+    from tests.golden import gen_golden_host as gh
+
+    dev = torch.device("cuda", 0)
+    want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "offline_data.npz"))
+    make = _mirror_sampling_buffer(dev)
+    with tempfile.TemporaryDirectory() as td:
+        files = gh.write_offline_files(make, td)
+        for trunc in (1000, 14):
+            b = make(4)
+            np.random.seed(1)
+            for tr in gh.host_stream(5, 3):
+                b.push(*tr)
+            b.sample(1, 2)   # allocates the mirror at capacity 4: adoption must re-allocate it
+            for f in files:
+                b.adopt_offline([os.path.join(td, f)], trunc)
+                ref = {k: want[f"t{trunc}/{f}/{k}"] for k in ("observations", "actions", "rewards", "dones")}
+                assert np.array_equal(b.observations, ref["observations"])
+                np.random.seed(7)
+                inds = b._sample_inds(3, 5)
+                np.random.seed(7)
+                o, a, r, d = b.sample(3, 5)
+                for g, k in ((o, "observations"), (a, "actions"), (r, "rewards"), (d, "dones")):
+                    w = ref[k][inds].reshape(5, 3, *ref[k].shape[1:])
+                    assert np.array_equal(g, w.astype(g.dtype)), (trunc, f, k)
+
+
 def test_train_agent_runs_from_buffer():
     agent, cfg = make_agent("repo", 8, 4, 5, 6)
     cfg.train_steps = 3
@@ -249,8 +322,18 @@ class ThreadDP:
         self.all_reduce(buf[:n])
         return buf
 
+    # the agent's bucketed exchange (Dreamer._model_bucket_begin): begun in the same order on every rank; the
+    # stand-in completes each bucket at once, RCCL completes it on its own stream
+    def all_reduce_begin(self, t, stream=None):
+        self.sh.setdefault("buckets", [[] for _ in range(self.world_size)])[self.rank].append(t.numel())
+        self.all_reduce(t)
+        return None
 
-def _run_sharded(algo, L, B, H, A, world, batch, nz, seed=7):
+    def all_reduce_end(self, works):
+        assert all(w is None for w in works)
+
+
+def _run_sharded(algo, L, B, H, A, world, batch, nz, seed=7, two_buckets=True):
     """One update of `world` row shards (repo_amd.parallel.shard_rows) in threads on one GPU.
     Returns (agents, their last_scalars)."""
     import threading
@@ -277,6 +360,7 @@ def _run_sharded(algo, L, B, H, A, world, batch, nz, seed=7):
     for r, (lo, hi) in enumerate(bounds):
         agents[r], _ = make_agent(algo, L, hi - lo, H, A, seed=seed)
         agents[r].dp = ThreadDP(r, world, shared, Fraction(B, hi - lo))
+        agents[r]._dp_two_buckets = two_buckets
         agents[r].noise_source = shard_noise(lo, hi)
 
     def run(r):
@@ -296,6 +380,7 @@ def _run_sharded(algo, L, B, H, A, world, batch, nz, seed=7):
         t.join(600)
     assert not errs, errs
     torch.cuda.synchronize()
+    agents[0].dp_buckets_seen = shared.get("buckets")
     return agents, scal
 
 
@@ -319,6 +404,32 @@ def test_data_parallel_two_shards_equal_full_batch():
         assert e < 2e-5 and ea < 2e-5
     assert torch.equal(agents[0].model_optimizer.flat, agents[1].model_optimizer.flat)  # replicas stay identical
     assert abs(float(agents[0].log_beta) - float(full.log_beta)) < 1e-6
+
+
+def test_bucketed_model_exchange_equals_single_bucket():
+    """The model gradient leaves as two buckets -- decoder + reward head (begun when the decoder backward joins),
+    then encoder + RSSM -- and actor + critic as one: parameters after the update are bit-identical to the
+    single-all-reduce exchange, on both replicas, for RePo (detached decoder) and Dreamer (attached)."""
+    L, B, H, A = 8, 6, 5, 6
+    batch, _ = dev_batch(L, B, A, 23)
+    nz, _ = dev_noise(L, B, H, A, 24)
+    for algo in ("repo", "dreamer"):
+        two, s2 = _run_sharded(algo, L, B, H, A, 2, batch, nz, two_buckets=True)
+        one, s1 = _run_sharded(algo, L, B, H, A, 2, batch, nz, two_buckets=False)
+        opt = two[0].model_optimizer
+        cut, n = two[0]._model_cut, opt.numel
+        assert 0 < cut < n and cut == opt.offsets[len(list(two[0].encoder.parameters())) +
+                                                  len(list(two[0].transition_model.parameters()))]
+        assert two[0].dp_buckets_seen[0] == [n - cut] == two[0].dp_buckets_seen[1], two[0].dp_buckets_seen
+        assert one[0].dp_buckets_seen is None
+        assert s2[0] == s1[0] and s2[0] == s2[1]
+        for r in range(2):
+            for name in ("model_optimizer", "actor_optimizer", "value_optimizer"):
+                assert torch.equal(getattr(two[r], name).flat, getattr(one[r], name).flat), (algo, r, name)
+        # actor and critic gradients are the two halves of ONE exchanged buffer
+        a = two[0]
+        assert a.actor_optimizer.grad.data_ptr() == a._ac_grad.data_ptr()
+        assert a.value_optimizer.grad.data_ptr() == a._ac_grad.data_ptr() + 4 * a.actor_optimizer.numel
 
 
 def test_config3_eight_uneven_shards_equal_full_batch_b50():

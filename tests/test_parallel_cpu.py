@@ -1,6 +1,7 @@
 """world_size-2 gloo tests (CPU) of the data-parallel exchange in repo_amd/parallel.py: uneven row shards +
-SUM all-reduces of the flat gradients scaled by local/global rows reproduce the full-batch update of all
-three optimisers and the dual variable; attach() broadcasts; global_count() is consistent across ranks."""
+SUM all-reduces of the flat gradients scaled by local/global rows -- the model gradient as two asynchronous
+buckets, actor + critic as one -- reproduce the full-batch update of all three optimisers and the dual variable;
+attach() broadcasts; global_count() is consistent across ranks."""
 import os
 import socket
 import sys
@@ -65,36 +66,52 @@ def _shard_noise(noise, L, B, H, A, lo, hi):
     }
 
 
-def _exchange_and_step(dp, params, grads, weight, opt, max_norm, drop=False):
-    """The product's exchange step for one optimiser (repo_amd/algorithms/repo/dreamer.py:_model_step):
-    local mean-loss gradients * local/global rows -> ONE sum all-reduce of the flat buffer -> global-norm
-    clip -> Adam.  Returns the pre-clip global norm."""
+def _apply_step(params, grads, flat, opt, max_norm):
+    """Global-norm clip + Adam on the exchanged flat gradient.  Returns the pre-clip global norm."""
     from oracle.repo_oracle import clip_grad_norm
 
-    flat = torch.cat([g.reshape(-1) for g in grads]) * weight
-    if not drop:
-        dp.all_reduce(flat)
     off = 0
     for p_, g in zip(params, grads):
         p_.grad = flat[off:off + g.numel()].view_as(g).clone()
         off += g.numel()
     total = clip_grad_norm(params, max_norm)
     opt.step()
-    return float(total), flat.numpy().copy()
+    return float(total)
+
+
+def _exchange_buckets(dp, flat, buckets, drop):
+    """The product's exchange of one flat gradient buffer (repo_amd/algorithms/repo/dreamer.py:
+    _model_bucket_begin / _model_step): one asynchronous SUM all-reduce per bucket, begun in the order the
+    backward finishes the buckets, all joined before the clip.  `buckets` = [(name, lo, hi)], `drop` names one
+    to leave out.  With nothing dropped the result must equal ONE all-reduce of the whole buffer, bit for bit."""
+    single = flat.clone()
+    works = [dp.all_reduce_begin(flat[lo:hi]) for name, lo, hi in buckets if name != drop]
+    dp.all_reduce_end(works)
+    if drop is None or drop not in [b[0] for b in buckets]:
+        dp.all_reduce(single)
+        assert torch.equal(single, flat), "bucketed exchange differs from the single-bucket exchange"
+    return flat
 
 
 def _dp_oracle_update(agent, dp, shard, noise, nb, B, drop=None):
-    """One full RePo update of a row shard with the product's three exchange points (+ the KL sum for the
-    dual step + the prefix all-reduce of the logged sums).  `drop` names an exchange to leave out."""
+    """One full RePo update of a row shard with the product's exchange points: the model gradient as two
+    buckets (decoder + reward head first, then encoder + RSSM), the KL sum for the dual step, actor and critic
+    gradients as ONE bucket, and the prefix all-reduce of the logged sums.  `drop` names an exchange to leave out."""
     c = agent.c
     w = nb / B
     t = {k: torch.as_tensor(np.ascontiguousarray(v)) for k, v in noise.items()}
     obs, act, rew, done = (torch.as_tensor(np.ascontiguousarray(x)) for x in shard)
     beliefs, post, scal = agent.train_dynamics(obs, act, rew, 1 - done, t["obs_prior"], t["obs_post"], apply=False)
     grads = {}
-    n0, grads["model"] = _exchange_and_step(dp, agent.model_params, agent.last["model_grads"], w, agent.model_opt,
-                                            c.grad_clip_norm, drop == "model")
-    norms = [n0]
+    mg = agent.last["model_grads"]
+    flat = torch.cat([g.reshape(-1) for g in mg]) * w
+    # the product cuts between the RSSM's and the decoder's parameters; the oracle keeps the same order
+    # (encoder, RSSM, decoder, reward head), so the cut is the size of the first two groups
+    n_head = sum(t_.numel() for mod in ("encoder", "transition_model") for t_ in agent.p[mod].values())
+    assert 0 < n_head < flat.numel()
+    _exchange_buckets(dp, flat, [("model_tail", n_head, flat.numel()), ("model_head", 0, n_head)], drop)
+    norms = [_apply_step(agent.model_params, mg, flat, agent.model_opt, c.grad_clip_norm)]
+    grads["model"] = flat.numpy().copy()
     kl = torch.tensor([scal["train/kl_div"] * nb], dtype=torch.float64)
     if drop != "kl":
         dp.all_reduce(kl)
@@ -103,9 +120,13 @@ def _dp_oracle_update(agent, dp, shard, noise, nb, B, drop=None):
     agent.beta_opt.step()
     ac = agent.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1), t["img_act"], t["img_prior"], t["entropy"],
                                   apply=False)
-    for name, ps, opt in (("actor", agent.actor_params, agent.actor_opt), ("value", agent.value_params, agent.value_opt)):
-        n_, grads[name] = _exchange_and_step(dp, ps, agent.last[name + "_grads"], w, opt, c.grad_clip_norm, drop == name)
-        norms.append(n_)
+    ag, vg = agent.last["actor_grads"], agent.last["value_grads"]
+    flat = torch.cat([g.reshape(-1) for g in ag + vg]) * w   # Dreamer._ac_grad: [actor | critic]
+    _exchange_buckets(dp, flat, [("actor_critic", 0, flat.numel())], drop)
+    na = sum(g.numel() for g in ag)
+    norms.append(_apply_step(agent.actor_params, ag, flat[:na], agent.actor_opt, c.grad_clip_norm))
+    norms.append(_apply_step(agent.value_params, vg, flat[na:], agent.value_opt, c.grad_clip_norm))
+    grads["actor"], grads["value"] = flat[:na].numpy().copy(), flat[na:].numpy().copy()
     # logged scalars: per-rank partial sums in the prefix, already-global norms behind it
     keys = ["train/obs_loss", "train/reward_loss", "train/kl_div"]
     sums = [scal[k] * nb for k in keys] + [ac[k] * nb for k in sorted(ac)]
@@ -239,11 +260,12 @@ def test_dp_uneven_shards_reproduce_full_batch_update():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("drop,expect", [("model", "params/model"), ("actor", "params/actor"),
-                                         ("value", "params/value"), ("kl", "log_beta"),
-                                         ("scalars", "train/obs_loss")])
+@pytest.mark.parametrize("drop,expect", [("model_tail", "params/model"), ("model_head", "params/model"),
+                                         ("actor_critic", "params/actor"), ("actor_critic", "params/value"),
+                                         ("kl", "log_beta"), ("scalars", "train/obs_loss")])
 def test_dp_dropping_any_exchange_is_detected(drop, expect):
-    """The comparison above is not vacuous: leaving out any one of the five exchanges breaks it."""
+    """The comparison above is not vacuous: leaving out any one of the exchanges (either model bucket, the
+    actor+critic bucket, the KL sum, the logged sums) breaks it."""
     L, B, H, A, world = 5, 5, 3, 6, 2
     want = _full_batch(L, B, H, A)
     got = _run_world(L, B, H, A, world, drop=drop)

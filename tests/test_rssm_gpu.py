@@ -360,6 +360,66 @@ def test_update_with_in_kernel_noise_equals_explicit_tensors(A, fused):
             assert torch.equal(getattr(drawn, name).flat, getattr(fed, name).flat), (u, name)
 
 
+def test_full_size_pipelined_in_kernel_noise_equals_explicit_tensors_20_updates():
+    """BASELINE config 2 shapes (B=50, L=50, H=15): 20 PIPELINED updates (update(join=False), as train_agent()
+    issues them) whose kernels draw their Philox noise equal, bit for bit, 20 updates fed the materialised
+    tensors of the same (seed, offset) ranges: scalars of every update and all parameters at the end."""
+    from repo_amd import ops
+    from tests.test_update_gpu import dev_batch, make_agent
+
+    L, B, H, A = 50, 50, 15, 6
+    T, S, Hm = L - 1, 30, H - 1
+    N = T * B
+    dev = torch.device("cuda")
+    batches = [dev_batch(L, B, A, 500 + i)[0] for i in range(3)]
+    drawn, _ = make_agent("repo", L, B, H, A)
+    fed, _ = make_agent("repo", L, B, H, A)
+    seed = 20261003
+    drawn.seed_noise(seed)
+    per_update = 2 * T * B * S + Hm * N * (A + S) + 100 * Hm * N * A
+    s_drawn, s_fed = [], []
+    for u in range(20):
+        drawn.update(batches[u % 3], join=False)
+        s_drawn.append(dict(drawn.last_scalars) if u % 5 == 4 else None)  # reading scalars syncs: only now and then
+    drawn.synchronize()
+    assert drawn._noise_counter == 20 * per_update
+    for u in range(20):
+        off = u * per_update
+        o_img, o_ent = off + 2 * T * B * S, off + 2 * T * B * S + Hm * N * (A + S)
+        fed.noise_source = {
+            "obs_prior": ops.philox_normal(T * B * S, seed, off, dev).view(T, B, S),
+            "obs_post": ops.philox_normal(T * B * S, seed, off + T * B * S, dev).view(T, B, S),
+            "img_act": ops.philox_normal(Hm * N * A, seed, o_img, dev).view(Hm, N, A),
+            "img_prior": ops.philox_normal(Hm * N * S, seed, o_img + Hm * N * A, dev).view(Hm, N, S),
+            "entropy": ops.philox_normal(100 * Hm * N * A, seed, o_ent, dev).view(Hm * N, A, 100).permute(2, 0, 1).contiguous(),
+        }
+        fed.update(batches[u % 3], join=False)
+        s_fed.append(dict(fed.last_scalars) if u % 5 == 4 else None)
+    fed.synchronize()
+    torch.cuda.synchronize()
+    assert s_drawn == s_fed
+    assert all(np.isfinite(v) for v in s_fed[-1].values())
+    for name in ("model_optimizer", "actor_optimizer", "value_optimizer"):
+        assert torch.equal(getattr(drawn, name).flat, getattr(fed, name).flat), name
+    assert float(drawn.log_beta) == float(fed.log_beta)
+
+
+def test_observe_with_grad_inputs_and_no_observations_raises():
+    """observe(observations=None) is forward-only here; the reference's branch is differentiable (rssm.py:112-146):
+    a caller that would backpropagate through it is told, instead of getting detached tensors silently."""
+    from tests.test_update_gpu import make_agent
+
+    agent, _ = make_agent("repo", 8, 4, 5, 6)
+    b0 = torch.zeros(2, 200, device="cuda", requires_grad=True)
+    s0 = torch.zeros(2, 30, device="cuda")
+    act = torch.zeros(3, 2, 6, device="cuda")
+    with pytest.raises(NotImplementedError):
+        agent.transition_model.observe(b0, s0, act, None, None)
+    with torch.no_grad():
+        assert len(agent.transition_model.observe(b0, s0, act, None, None)) == 4
+    assert len(agent.transition_model.observe(b0.detach(), s0, act, None, None)) == 4
+
+
 def test_observe_without_observations_prior_only_rollout():
     """TransitionModel.observe(observations=None) (reference rssm.py:112-146): open-loop rollout under given actions,
     the next step fed the nonterminal-masked PRIOR sample; four outputs."""

@@ -165,8 +165,8 @@ def test_update_matches_oracle_latents_and_grads(algo):
         ):
             e = ((got.cpu() - want).norm() / want.norm()).item()
             log(f"[oracle {algo}] update {u} flat grad {name}: l2 rel {e:.2e}")
-            # normwise: a handful of ReLU units within rounding of zero flip between fp32 runs
-            assert e < (5e-3 if u == 0 else 5e-2), (name, e)
+            # normwise (a ReLU unit within rounding of zero may flip between two fp32 runs); observed 2e-7 .. 3e-6
+            assert e < 1e-3, (name, e)
 
 
 def test_full_size_update_properties():

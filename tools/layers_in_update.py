@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-kernel table of the update AS IT RUNS (both lanes and the side streams sharing the GPU), from the
+rocprofv3 --kernel-trace --stats CSV of `bench.py --steps K` (tools/prof_bench.sh): calls per update, average
+duration, and -- for the conv kernels, whose FLOPs follow from the geometry in the kernel's name -- TFLOP/s and
+the fraction of the fp32-MFMA peak at that in-update duration.  Next to profiles/rNN_layers_isolated.txt this
+shows what concurrency costs each kernel.
+
+    python tools/layers_in_update.py <kernel_stats.csv> <updates in the trace> [--json profiles/dominant_kernel_rocprof.json]
+"""
+import csv
+import json
+import re
+import sys
+
+PEAK = 157.3
+NIMG = 2450
+
+
+def conv_flop(name):
+    m = re.search(r"Geo<(\d+), (\d+), (\d+), (\d+)>", name)
+    if not m:
+        return None
+    cb, cs, hb, ks = map(int, m.groups())
+    hs = (hb - ks) // 2 + 1
+    return 2.0 * NIMG * cs * hs * hs * cb * ks * ks
+
+
+def main():
+    path, nupd = sys.argv[1], float(sys.argv[2])
+    rows = list(csv.DictReader(open(path)))
+    tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"# kernels of the update as it runs (rocprofv3 --kernel-trace --stats of bench.py, {nupd:.0f} updates in the trace)")
+    print(f"# sum of kernel time per update: {tot_ns / nupd / 1e6:.2f} ms")
+    print(f"# {'calls/upd':>9} {'avg us':>9} {'us/upd':>9} {'TFLOP/s':>8} {'frac':>6}  kernel")
+    dom = None
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+        name = re.sub(r"\(.*", "", re.sub(r"repo::|void ", "", r["Name"]))
+        calls = int(r["Calls"]) / nupd
+        avg = float(r["AverageNs"]) / 1e3
+        if calls < 0.5 or float(r["TotalDurationNs"]) / nupd < 2e3:
+            continue
+        fl = conv_flop(name) if ("conv" in name and "pack" not in name and "reduce" not in name) else None
+        tf = fl / (avg * 1e-6) / 1e12 if fl else None
+        print(f"  {calls:9.1f} {avg:9.1f} {float(r['TotalDurationNs']) / nupd / 1e3:9.1f} "
+              f"{(f'{tf:8.1f}' if tf else '       -')} {(f'{tf / PEAK:6.3f}' if tf else '     -')}  {name[:100]}")
+        if name.startswith("uconv_scatter_kernel<Geo<32, 64, 30, 6>"):
+            dom = {"kernel": "uconv_scatter_kernel<GDec3>", "nimg": NIMG, "avg_ms_in_update": round(avg / 1e3, 4),
+                   "calls_per_update": round(calls, 2),
+                   "frac_at_rocprof_duration": round(tf / PEAK, 4)}
+    if "--json" in sys.argv and dom:
+        out = sys.argv[sys.argv.index("--json") + 1]
+        dom["source"] = f"rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps {nupd:.0f} (tools/prof_bench.sh; isolated re-runs skipped under the profiler)"
+        json.dump(dom, open(out, "w"), indent=1)
+        print("# wrote", out, dom)
+
+
+if __name__ == "__main__":
+    main()
