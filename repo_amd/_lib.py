@@ -10,7 +10,8 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "repo_hip.h")
-LIB_PATH = os.path.join(HERE, "librepo_hip.so")
+# REPO_HIP_LIB: developer knob -- load another build of the library (A/B runs of kernel variants in one process tree)
+LIB_PATH = os.environ.get("REPO_HIP_LIB") or os.path.join(HERE, "librepo_hip.so")
 
 _CT = {
     "int": ctypes.c_int,

@@ -313,14 +313,56 @@ struct DTileFor;
 // the 3-channel layers are one channel chunk per workgroup (no pipelining inside it): 8 waves per tile and short
 // weight-gradient bands measured best (tile sweep, round 2: enc1 fwd 148 -> 140 us, enc1 wgrad 224 -> 171,
 // dec4 dgrad 311-338 -> 247, dec4 wgrad 210 -> 201)
-template <> struct DTileFor<GEnc1> { using Down = DTile<32, 512, 3, 1, 8>;   using Wgrad = WTile<32, 64, 1, 2, 1, 4>; };
-template <> struct DTileFor<GEnc2> { using Down = DTile<64, 128, 2, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 1, 7>; };
-template <> struct DTileFor<GEnc3> { using Down = DTile<128, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 2, 6>; };
+#ifndef REPO_WT_ENC1
+#define REPO_WT_ENC1 WTile<32, 64, 1, 2, 1, 4, 2>
+#endif
+#ifndef REPO_DT_ENC1
+#define REPO_DT_ENC1 DTile<32, 512, 3, 1, 8>
+#endif
+template <> struct DTileFor<GEnc1> { using Down = REPO_DT_ENC1; using Wgrad = REPO_WT_ENC1; };
+#ifndef REPO_WT_ENC2
+#define REPO_WT_ENC2 WTile<64, 128, 2, 2, 1, 7, 2>
+#endif
+#ifndef REPO_DT_ENC2
+#define REPO_DT_ENC2 DTile<64, 128, 2, 2, 2>
+#endif
+template <> struct DTileFor<GEnc2> { using Down = REPO_DT_ENC2; using Wgrad = REPO_WT_ENC2; };
+#ifndef REPO_WT_ENC3
+#define REPO_WT_ENC3 WTile<64, 128, 2, 2, 2, 6>
+#endif
+#ifndef REPO_DT_ENC3
+#define REPO_DT_ENC3 DTile<128, 128, 2, 2, 2>
+#endif
+template <> struct DTileFor<GEnc3> { using Down = REPO_DT_ENC3; using Wgrad = REPO_WT_ENC3; };
 // enc4 forward has only 9800 output pixels: 128 x 128 tiles are 154 workgroups on 256 CUs (171 us); 32 x 64: 125 us
-template <> struct DTileFor<GEnc4> { using Down = DTile<32, 64, 2, 1, 2>;     using Wgrad = WTile<64, 128, 2, 2, 16, 2>; };
-template <> struct DTileFor<GDec2> { using Down = DTile<128, 128, 4, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 4, 5>; };
-template <> struct DTileFor<GDec3> { using Down = DTile<64, 128, 2, 2, 2>;   using Wgrad = WTile<64, 128, 2, 2, 1, 7>; };
-template <> struct DTileFor<GDec4> { using Down = DTile<32, 256, 3, 1, 8>;   using Wgrad = WTile<32, 128, 1, 4, 1, 2>; };
+#ifndef REPO_WT_ENC4
+#define REPO_WT_ENC4 WTile<64, 128, 2, 2, 8, 2>
+#endif
+#ifndef REPO_DT_ENC4
+#define REPO_DT_ENC4 DTile<32, 64, 2, 1, 2>
+#endif
+template <> struct DTileFor<GEnc4> { using Down = REPO_DT_ENC4; using Wgrad = REPO_WT_ENC4; };
+#ifndef REPO_WT_DEC2
+#define REPO_WT_DEC2 WTile<64, 128, 2, 2, 4, 5>
+#endif
+#ifndef REPO_DT_DEC2
+#define REPO_DT_DEC2 DTile<128, 128, 4, 2, 2, 1>
+#endif
+template <> struct DTileFor<GDec2> { using Down = REPO_DT_DEC2; using Wgrad = REPO_WT_DEC2; };
+#ifndef REPO_WT_DEC3
+#define REPO_WT_DEC3 WTile<64, 128, 2, 2, 1, 7>
+#endif
+#ifndef REPO_DT_DEC3
+#define REPO_DT_DEC3 DTile<64, 128, 2, 2, 2>
+#endif
+template <> struct DTileFor<GDec3> { using Down = REPO_DT_DEC3; using Wgrad = REPO_WT_DEC3; };
+#ifndef REPO_WT_DEC4
+#define REPO_WT_DEC4 WTile<32, 128, 1, 4, 1, 2>
+#endif
+#ifndef REPO_DT_DEC4
+#define REPO_DT_DEC4 DTile<32, 256, 3, 1, 8>
+#endif
+template <> struct DTileFor<GDec4> { using Down = REPO_DT_DEC4; using Wgrad = REPO_WT_DEC4; };
 
 // A handful of frames (the acting path encodes ONE per environment step): the throughput tiles leave 1-2
 // workgroups walking 16-64 dependent channel chunks (enc4: 147 us for one frame).  Latency tiles use 32

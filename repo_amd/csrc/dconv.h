@@ -19,9 +19,12 @@
 
 namespace repo {
 
-template <int BM_, int BN_, int CK_, int WM_, int WN_>
+// LDWPAD: padding of the weight slice's LDS rows.  The k-major staging stores (4 dwords of one weight row to 4
+// LDS rows) conflict by the row pitch: 2 suits k-per-chunk / 4 = 8 or 18 rows per lane group, 1 suits 25 (dec2:
+// 322 -> 309 us, A/B on one box)
+template <int BM_, int BN_, int CK_, int WM_, int WN_, int LDWPAD_ = 2>
 struct DTile {
-  static constexpr int BM = BM_, BN = BN_, CK = CK_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, CK = CK_, WM = WM_, WN = WN_, LDWPAD = LDWPAD_;
   static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   static constexpr int NT = WM * WN * 64;
   static_assert(TM >= 1 && TN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave grid mismatch");
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   constexpr int KSL = CK * G::KK;  // k per chunk
   constexpr int NSL = G::CB / CK;
   static_assert(G::CB % CK == 0 && KSL % 4 == 0, "channel chunk must divide CB and give k % 4 == 0");
-  constexpr int LDW = BM + 2;
+  constexpr int LDW = BM + T::LDWPAD;
   // ---- patch geometry: a tile is BN consecutive pixels of (img, sy, sx); image i of the tile needs
   // input rows [2*f_i, 2*l_i + KS) -- full width, hence ONE contiguous span per (image, channel)
   constexpr int ROWS_FULL = 2 * (G::HS - 1) + G::KS;
@@ -306,9 +309,12 @@ struct WgradArgs {
   unsigned small_bytes, big_bytes;
 };
 
-template <int BM_, int BN_, int WM_, int WN_, int GI_, int RB_>
+// SPREAD: 0 = the next chunk's global loads are issued back to back in front of the MFMA loop; n > 0 = one at a
+// time between the k-pairs of its first 1/n (A/B on one box, round 3: enc1 171 -> 164 us, enc2 370 -> 360 with
+// n = 2; dec3 542 -> 572, enc3 226 -> 230: per layer)
+template <int BM_, int BN_, int WM_, int WN_, int GI_, int RB_, int SPREAD_ = 0>
 struct WTile {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, GI = GI_, RB = RB_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, GI = GI_, RB = RB_, SPREAD = SPREAD_;
   static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN), NT = WM * WN * 64;
   static_assert(TM >= 1 && TN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave grid mismatch");
 };
@@ -412,17 +418,33 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
 
   f32x4 rav[A_PER];
   typename Patch4<BigT>::raw_t rbv[B_PER];
-  auto gload = [&](int c) __attribute__((always_inline)) {
+  // global loads of chunk c, one staged vector (piece q of NLD) at a time: the pieces of chunk c+1 are issued
+  // BETWEEN the row blocks of chunk c's MFMA loop -- issued back to back in front of it they queue in the CU's
+  // vector-memory front end (in-kernel stamps: 1800-3100 cycles per chunk in which the wave issues nothing else)
+  constexpr int NLD = A_PER + B_PER;
+  int ld_img0 = 0, ld_abias = 0, ld_bbias = 0;
+  auto gload_begin = [&](int c) __attribute__((always_inline)) {
     const int grp = c / NB, band = c % NB;
-    const int img0 = img_beg + grp * GI, r0 = band * RB;
-    const int abias = img0 * G::CS * G::PS + r0 * G::WS, bbias = img0 * G::CB * G::PB + 2 * r0 * G::WB;
+    const int r0 = band * RB;
+    ld_img0 = img_beg + grp * GI;
+    ld_abias = ld_img0 * G::CS * G::PS + r0 * G::WS;
+    ld_bbias = ld_img0 * G::CB * G::PB + 2 * r0 * G::WB;
+  };
+  auto gload_piece = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < A_PER; ++j)
-      rav[j] = VecLoad<4>::load(rsm, img0 + ag[j] < img_end ? 4u * (unsigned)(aoff[j] + abias) : kOobOffset);
+      if (j == q)
+        rav[j] = VecLoad<4>::load(rsm, ld_img0 + ag[j] < img_end ? 4u * (unsigned)(aoff[j] + ld_abias) : kOobOffset);
 #pragma unroll
     for (int j = 0; j < B_PER; ++j)
-      rbv[j] = Patch4<BigT>::load(
-          rbg, img0 + bg[j] < img_end ? (unsigned)Patch4<BigT>::BYTES * (unsigned)(boff[j] + bbias) : kOobOffset);
+      if (j + A_PER == q)
+        rbv[j] = Patch4<BigT>::load(
+            rbg, ld_img0 + bg[j] < img_end ? (unsigned)Patch4<BigT>::BYTES * (unsigned)(boff[j] + ld_bbias) : kOobOffset);
+  };
+  auto gload = [&](int c) __attribute__((always_inline)) {
+    gload_begin(c);
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) gload_piece(q);
   };
   auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -432,35 +454,58 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
     for (int j = 0; j < B_PER; ++j)
       if ((B_NV % NT == 0) || tid + j * NT < B_NV) *reinterpret_cast<f32x4*>(Bl + blds[j]) = Patch4<BigT>::cvt(rbv[j]);
   };
-  auto compute = [&](int c) __attribute__((always_inline)) {
+  // K of a chunk = the pixels (g, sy, sx) of `small`, walked as FLAT pairs kf = sy*WS + sx over a band (the A copy
+  // is one contiguous run per (image, channel), so A needs no row logic at all): pairing inside rows instead
+  // pads every odd-width row with a phantom k (WS = 5: 6 MFMA k-slots per 5 pixels, 13: 14 per 13).  B of pixel
+  // kf sits at 2*sy*BRP + 2*sx: the odd k of a pair is 2 floats on, or -- when the pair straddles a row end --
+  // 2*BRP - 2*WS + 2 floats on; which of the two is a compile-time property of the pair, so each B tile keeps two
+  // per-lane bases (same row / straddling) and the pair's offset is an immediate.
+  int bbase_w[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bbase_w[j] = bbase[j] - 2 * lh + lh * (2 * BRP - 2 * G::WS + 2);
+  constexpr int RL = G::HS - (NB - 1) * RB;  // rows of the last band
+  auto compute = [&](auto rows_tag, int c) __attribute__((always_inline)) {
+    constexpr int ROWS = decltype(rows_tag)::value;
+    constexpr int NK = ROWS * G::WS, NP = (NK + 1) / 2;
     const int band = c % NB;
     const int R = min(RB, G::HS - band * RB);
-#pragma unroll 1
+#pragma unroll
     for (int g = 0; g < GI; ++g) {
-#pragma unroll 1
-      for (int sy = 0; sy < R; ++sy) {
-        const float* ar = Al + g * BM * AP + sy * G::WS;
-        const float* br = Bl + g * CBT * BP + 2 * sy * BRP;
+      const float* ar = Al + g * BM * AP;
+      const float* br = Bl + g * CBT * BP;
 #pragma unroll
-        for (int sp = 0; sp < SXP; ++sp) {
-          float av[TM], bv[TN];
+      for (int pp = 0; pp < NP; ++pp) {
+        const int k0 = 2 * pp;
+        const int off0 = 2 * (k0 / G::WS) * BRP + 2 * (k0 % G::WS);
+        const bool straddle = (k0 % G::WS) == G::WS - 1;  // the odd k of the pair is the next row's first pixel
+        const bool half = k0 + 1 >= NK;                    // ... or does not exist (odd pixel count): zero both sides
+        float av[TM], bv[TN];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            av[i] = ar[abase[i] + 2 * sp];
-            if (G::WS % 2 == 1 && sp == SXP - 1) av[i] = lh ? 0.f : av[i];
-          }
+        for (int i = 0; i < TM; ++i) {
+          av[i] = ar[abase[i] + k0];
+          if (half) av[i] = lh ? 0.f : av[i];
+        }
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            bv[j] = br[bbase[j] + 4 * sp];
-            // the non-existent second k of an odd row's last pair reads past the row (for the band's last
-            // row: past the copy, i.e. uninitialised LDS); 0 * NaN would poison the sum, so zero both sides
-            if (G::WS % 2 == 1 && sp == SXP - 1) bv[j] = lh ? 0.f : bv[j];
-          }
+        for (int j = 0; j < TN; ++j) {
+          bv[j] = (straddle && !half) ? br[bbase_w[j] + off0] : br[bbase[j] + off0];
+          // a phantom k reads past the band's copy (uninitialised LDS): 0 * NaN would poison the sum
+          if (half) bv[j] = lh ? 0.f : bv[j];
+        }
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        // next chunk's loads, spread over the first 1/SPREAD of the pairs (pinned: the scheduler otherwise
+        // sinks them all to the end of the loop, where they have no time left to land before the LDS stores)
+        constexpr int NSLOT = GI * NP;
+        constexpr int SSLOT = (NSLOT + cmax(T::SPREAD, 1) - 1) / cmax(T::SPREAD, 1);
+        const int slot = g * NP + pp;
+        if (T::SPREAD && slot < SSLOT && slot * NLD / SSLOT < (slot + 1) * NLD / SSLOT) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = slot * NLD / SSLOT; q < (slot + 1) * NLD / SSLOT; ++q) gload_piece(q);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -474,15 +519,27 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
     }
   };
 
+  REPO_STAMP_DECL
   if (nch > 0) {
     gload(0);
+    REPO_STAMP(5);
     for (int c = 0; c < nch; ++c) {
       lstore();
+      REPO_STAMP(2);
       __syncthreads();
-      gload(min(c + 1, nch - 1));
-      __builtin_amdgcn_sched_barrier(0);
-      compute(c);
+      REPO_STAMP(3);
+      gload_begin(min(c + 1, nch - 1));
+      if (!T::SPREAD) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) gload_piece(q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      REPO_STAMP(0);
+      if (RL == RB || c % NB != NB - 1) compute(std::integral_constant<int, RB>{}, c);
+      else compute(std::integral_constant<int, RL>{}, c);
+      REPO_STAMP(1);
       __syncthreads();
+      REPO_STAMP(3);
     }
   }
 
@@ -514,6 +571,7 @@ __global__ __launch_bounds__(T::NT) void dconv_wgrad_kernel(WgradArgs p) {
       p.slab[((size_t)z * G::CS + m0 + tid) * LDS_ + NW] = s;
     }
   }
+  REPO_STAMP_FLUSH(nch);
 }
 
 template <class G, class BigT, class T>

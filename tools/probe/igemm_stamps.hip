@@ -10,6 +10,8 @@
 #include "../../repo_amd/csrc/conv.hip"
 #endif
 
+namespace repo { int arch_status() { return 0; } }  // the probe links no api.hip
+
 static void report(const char* name, double flop, float ms) {
   unsigned long long h[8];
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(repo::g_igemm_stamps), sizeof(h));
@@ -61,7 +63,7 @@ int main() {
       (void)hipFree(A); (void)hipFree(B); (void)hipFree(C);
     }
 #else
-  const long n = 2500;
+  const long n = 2450;
   // layer ids as in include/repo_hip.h: 0..3 encoder conv1..4, 4..6 decoder conv2..4
   struct { int id; const char* nm; long cb, cs, hb, hs, ks; } L[] = {
       {1, "enc2", 32, 64, 31, 14, 4}, {2, "enc3", 64, 128, 14, 6, 4}, {3, "enc4", 128, 256, 6, 2, 4},
@@ -76,9 +78,6 @@ int main() {
     char nm[64];
     float ms = run([&] { return repo_conv_down(l.id, n, big, 0, w, nullptr, small, 0, nullptr, 0); });
     snprintf(nm, sizeof nm, "%s down", l.nm);
-    report(nm, flop, ms);
-    ms = run([&] { return repo_conv_up(l.id, n, small, w, nullptr, big, 0, nullptr, 0); });
-    snprintf(nm, sizeof nm, "%s up", l.nm);
     report(nm, flop, ms);
     ms = run([&] { return repo_conv_wgrad(l.id, n, small, big, 0, dw, nullptr, 0, ws, wsb, 0); });
     snprintf(nm, sizeof nm, "%s wgrad", l.nm);
