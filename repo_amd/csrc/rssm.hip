@@ -171,18 +171,52 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
   }
   __syncthreads();
 
+  // Every step is a chain of ten dependent stages; a global load issued where its value is needed adds its
+  // whole latency (an L2 / HBM round trip, longer when other kernels share the chip) to that chain.  So: the
+  // biases live in registers for the whole scan, and the per-step operands (nonterminal / action of the x
+  // vector, the hoisted embed contribution) are fetched one step AHEAD, while the previous step computes.
+  const bool feat_thr = tid < D, hid_thr = tid < Hd, out_thr = tid < 4 * S;
+  const float b_sa = feat_thr ? p.bsa[tid] : 0.f;
+  float b_g[6];
+#pragma unroll
+  for (int g = 0; g < 6; ++g) b_g[g] = feat_thr ? (g < 3 ? p.bih[g * D + tid] : p.bhh[(g - 3) * D + tid]) : 0.f;
+  const float b_bp = hid_thr ? p.bbp[tid] : 0.f, b_bq = hid_thr ? p.bbq[tid] : 0.f;
+  const float b_out = out_thr ? (tid >= 2 * S ? p.bsq[tid - 2 * S] : p.bsp[tid]) : 0.f;
+  // x-vector role of this thread (R * X <= blockDim): element (xr, xk)
+  const int xr = tid / X, xk = tid % X;
+  const bool x_thr = tid < R * X && xr < nr;
+  auto load_x = [&](int t) __attribute__((always_inline)) {
+    const size_t row = (size_t)t * B + b0 + xr;
+    return x_thr ? (xk < S ? p.nonterms[row] : p.actions[row * A + (xk - S)]) : 0.f;
+  };
+  float em_next[R];
+  auto load_em = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      em_next[r] = (hid_thr && r < nr) ? p.eemb[((size_t)t * B + b0 + r) * Hd + tid] : 0.f;
+  };
+  float x_next = T > 0 ? load_x(0) : 0.f;
+  if (T > 0) load_em(0);
+
   int cur = 0;
   for (int t = 0; t < T; ++t) {
     const size_t row0 = (size_t)t * B + b0;  // flattened (t, b0)
+    const float x_in = x_next;
+    float em[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) em[r] = em_next[r];
+    if (t + 1 < T) {
+      x_next = load_x(t + 1);
+      load_em(t + 1);
+    }
     // ---- x = [state * nonterm, action]
-    for (int i = tid; i < R * X; i += blockDim.x) {
-      const int r = i / X, k = i % X;
+    if (tid < R * X) {
       float v = 0.f;
-      if (r < nr) {
-        v = k < S ? st[r][k] * p.nonterms[row0 + r] : p.actions[(row0 + r) * A + (k - S)];
-        p.xsa[(row0 + r) * X + k] = v;
+      if (x_thr) {
+        v = xk < S ? st[xr][xk] * x_in : x_in;
+        p.xsa[(row0 + xr) * X + xk] = v;
       }
-      xs[r][k] = v;
+      xs[xr][xk] = v;
     }
     __syncthreads();
     // ---- e = elu(W_sa x + b)
@@ -206,7 +240,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
     if (tid < D) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float acc = p.bsa[tid];
+        float acc = b_sa;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) acc += part[q][0][r][tid];
         const float v = elu(acc);
@@ -260,7 +294,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
         float g6[6];
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-          float sacc = g < 3 ? p.bih[g * D + tid] : p.bhh[(g - 3) * D + tid];
+          float sacc = b_g[g];
 #pragma unroll
           for (int q = 0; q < KQ; ++q) sacc += part[q][g][r][tid];
           g6[g] = sacc;
@@ -314,7 +348,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
     if (tid < Hd) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float ap = p.bbp[tid], aq = p.bbq[tid] + (r < nr ? p.eemb[(row0 + r) * Hd + tid] : 0.f);
+        float ap = b_bp, aq = b_bq + em[r];
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           ap += part[q][0][r][tid];
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       const int o = post ? tid - 2 * S : tid;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float acc = post ? p.bsq[o] : p.bsp[o];
+        float acc = b_out;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) acc += part[q][0][r][tid];
         outs[r][tid] = acc;
@@ -458,38 +492,98 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
   for (int i = tid; i < R * kMaxS2; i += blockDim.x) (&dst[0][0])[i] = 0.f;
   __syncthreads();
 
+  // The saved activations and upstream gradients a step reads (each a dependent global load in front of one of
+  // its eight stages) are fetched one step AHEAD into registers: in the update this scan shares the chip with the
+  // decoder's backward, and a load issued where its value is needed then costs 1-2 us of the chain.
+  struct StepIn {
+    float dfb[R], g_r[R], g_z[R], g_n[R], g_hn[R], hprev[R], ev[R];  // feature threads (tid < D)
+    float hp[R], hq[R];                                              // hidden threads (tid < Hd)
+    float o_dsmp, o_dm, o_dsd, o_sd;                                 // output-delta role (tid < R * 2S)
+    float nt[R];                                                     // tid < S
+  };
+  const int orr = tid / (2 * S), oq = tid % (2 * S);
+  const bool o_thr = tid < R * 2 * S && orr < nr, o_post = oq >= S;
+  const int o_s = o_post ? oq - S : oq;
+  // one register set: each group of fields is re-loaded for step t-1 right after step t's last use of it
+  StepIn in;
+  auto load_top = [&](int t) __attribute__((always_inline)) {  // consumed by the first stage
+    const size_t row0 = (size_t)t * B + b0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) in.dfb[r] = (tid < D && r < nr && p.dfeat) ? p.dfeat[(row0 + r) * F + tid] : 0.f;
+    in.o_dsmp = in.o_dm = in.o_dsd = in.o_sd = 0.f;
+    if (o_thr) {
+      const size_t o = (row0 + orr) * S + o_s;
+      if (o_post) {
+        in.o_dsmp = p.dfeat ? p.dfeat[(row0 + orr) * F + D + o_s] : 0.f;
+        in.o_dm = p.dqm ? p.dqm[o] : 0.f;
+        in.o_dsd = p.dqs ? p.dqs[o] : 0.f;
+        in.o_sd = p.post_std[o];
+      } else {
+        in.o_dsmp = p.dprior_state ? p.dprior_state[o] : 0.f;
+        in.o_dm = p.dpm ? p.dpm[o] : 0.f;
+        in.o_dsd = p.dps ? p.dps[o] : 0.f;
+        in.o_sd = p.prior_std[o];
+      }
+    }
+  };
+  auto load_hid = [&](int t) __attribute__((always_inline)) {
+    const size_t row0 = (size_t)t * B + b0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ha = tid < Hd && r < nr;
+      in.hp[r] = ha ? p.hp[(row0 + r) * Hd + tid] : 0.f;
+      in.hq[r] = ha ? p.hq[(row0 + r) * Hd + tid] : 0.f;
+    }
+  };
+  auto load_gru = [&](int t) __attribute__((always_inline)) {
+    const size_t row0 = (size_t)t * B + b0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool fa = tid < D && r < nr;
+      const float* g = p.gates + (row0 + r) * 4 * D;
+      in.g_r[r] = fa ? g[tid] : 0.f;
+      in.g_z[r] = fa ? g[D + tid] : 0.f;
+      in.g_n[r] = fa ? g[2 * D + tid] : 0.f;
+      in.g_hn[r] = fa ? g[3 * D + tid] : 0.f;
+      in.hprev[r] = fa ? p.featx[((size_t)t * B + b0 + r) * F + tid] : 0.f;
+    }
+  };
+  auto load_e = [&](int t) __attribute__((always_inline)) {
+    const size_t row0 = (size_t)t * B + b0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) in.ev[r] = (tid < D && r < nr) ? p.e[(row0 + r) * D + tid] : 0.f;
+  };
+  auto load_nt = [&](int t) __attribute__((always_inline)) {
+    const size_t row0 = (size_t)t * B + b0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) in.nt[r] = (tid < S && r < nr) ? p.nonterms[row0 + r] : 0.f;
+  };
+  if (T > 0) {
+    load_top(T - 1);
+    load_hid(T - 1);
+    load_gru(T - 1);
+    load_e(T - 1);
+    load_nt(T - 1);
+  }
+
   for (int t = T - 1; t >= 0; --t) {
     const size_t row0 = (size_t)t * B + b0;
+    const int tn = t > 0 ? t - 1 : 0;  // the step whose operands are fetched behind each stage (t = 0: a harmless re-read)
     // ---- total gradient on belief_t; heads' output-layer deltas
     if (tid < D) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float g = dh[r][tid];
-        if (p.dfeat && r < nr) g += p.dfeat[(row0 + r) * F + tid];
-        dbel[r][tid] = g;
-      }
+      for (int r = 0; r < R; ++r) dbel[r][tid] = dh[r][tid] + in.dfb[r];
     }
-    for (int i = tid; i < R * 2 * S; i += blockDim.x) {
-      const int r = i / (2 * S), q = i % (2 * S);
-      const bool post = q >= S;
-      const int s = post ? q - S : q;
+    if (tid < R * 2 * S) {
+      const int r = orr, s = o_s;
+      const bool post = o_post;
       float dm = 0.f, draw = 0.f;
       if (r < nr) {
         const size_t o = (row0 + r) * S + s;
-        float dsmp, dsd, sd, eps;
-        if (post) {
-          dsmp = dst[r][s] + (p.dfeat ? p.dfeat[(row0 + r) * F + D + s] : 0.f);
-          dm = p.dqm ? p.dqm[o] : 0.f;
-          dsd = p.dqs ? p.dqs[o] : 0.f;
-          sd = p.post_std[o];
-          eps = p.eps_post.at(o);
-        } else {
-          dsmp = p.dprior_state ? p.dprior_state[o] : 0.f;
-          dm = p.dpm ? p.dpm[o] : 0.f;
-          dsd = p.dps ? p.dps[o] : 0.f;
-          sd = p.prior_std[o];
-          eps = p.eps_prior.at(o);
-        }
+        float dsmp = in.o_dsmp + (post ? dst[r][s] : 0.f), dsd = in.o_dsd;
+        const float sd = in.o_sd;
+        const float eps = post ? p.eps_post.at(o) : p.eps_prior.at(o);
+        dm = in.o_dm;
         dm += dsmp;
         dsd = fmaf(dsmp, eps, dsd);
         // d softplus(raw)/d raw = sigmoid(raw) = 1 - exp(-softplus(raw))
@@ -502,6 +596,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
       douts[r][base + s] = dm;
       douts[r][base + S + s] = draw;
     }
+    load_top(tn);
     __syncthreads();
     // ---- back through the output layers to the hidden pre-activations
     if (j < Hd) {
@@ -540,8 +635,8 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
         }
         float vp = 0.f, vq = 0.f;
         if (r < nr) {
-          vp = ap * elu_grad_from_out(p.hp[(row0 + r) * Hd + tid]);
-          vq = aq * elu_grad_from_out(p.hq[(row0 + r) * Hd + tid]);
+          vp = ap * elu_grad_from_out(in.hp[r]);
+          vq = aq * elu_grad_from_out(in.hq[r]);
           p.dhp[(row0 + r) * Hd + tid] = vp;
           p.dhq[(row0 + r) * Hd + tid] = vq;
         }
@@ -549,6 +644,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
         dhqs[r][tid] = vq;
       }
     }
+    load_hid(tn);
     __syncthreads();
     // ---- into belief_t (k-split partial sums over the hidden index)
     if (j < D) {
@@ -579,9 +675,8 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
         for (int q = 0; q < KQ; ++q) db_ += part[q][0][r][tid];
         float g_r = 0.f, g_z = 0.f, g_n = 0.f, g_hn = 0.f, dhprev = 0.f;
         if (r < nr) {
-          const float* g = p.gates + (row0 + r) * 4 * D;
-          const float rg = g[tid], zg = g[D + tid], ng = g[2 * D + tid], ghn = g[3 * D + tid];
-          const float hprev = p.featx[((size_t)t * B + b0 + r) * F + tid];
+          const float rg = in.g_r[r], zg = in.g_z[r], ng = in.g_n[r], ghn = in.g_hn[r];
+          const float hprev = in.hprev[r];
           const float dn = db_ * (1.f - zg);
           const float dz = db_ * (hprev - ng);
           dhprev = db_ * zg;
@@ -607,6 +702,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
         dh[r][tid] = dhprev;
       }
     }
+    load_gru(tn);
     __syncthreads();
     // ---- through W_hh into belief_{t-1}, through W_ih into e (k-split over the 3D gate index)
     if (j < D) {
@@ -646,12 +742,13 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
         dh[r][tid] = ah;
         float v = 0.f;
         if (r < nr) {
-          v = ae * elu_grad_from_out(p.e[(row0 + r) * D + tid]);
+          v = ae * elu_grad_from_out(in.ev[r]);
           p.de[(row0 + r) * D + tid] = v;
         }
         des[r][tid] = v;
       }
     }
+    load_e(tn);
     __syncthreads();
     // ---- through W_sa into the previous posterior state (masked by nonterminal)
     if (j < S) {
@@ -677,9 +774,10 @@ __global__ __launch_bounds__(256 * KQ) void observe_bwd_kernel(ObsBwdArgs p) {
         float acc = 0.f;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) acc += part[q][0][r][tid];
-        dst[r][tid] = r < nr ? acc * p.nonterms[row0 + r] : 0.f;
+        dst[r][tid] = r < nr ? acc * in.nt[r] : 0.f;
       }
     }
+    load_nt(tn);
     __syncthreads();
   }
   if (p.dprev_belief)
