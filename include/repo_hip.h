@@ -33,7 +33,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define REPO_ABI_VERSION 3
+#define REPO_ABI_VERSION 4
 
 #define REPO_OK 0
 #define REPO_E_BADARG (-1)
@@ -48,6 +48,10 @@ typedef struct ihipStream_t* hipStream_t;
 #define REPO_EPI_RELU 2      /* F.relu                                          */
 #define REPO_EPI_MUL_DELU 3  /* multiply by elu'(x) given aux = elu(x)          */
 #define REPO_EPI_MUL_DRELU 4 /* multiply by relu'(x) given aux = relu(x)        */
+#define REPO_EPI_MUL_MASK4 5 /* multiply by relu'(x) given aux = the QUAD MASK of relu(x) (bytes): bit (o & 3) of
+                                byte (o >> 2) is relu(x)[o] > 0, o = flat element index; written by
+                                repo_decoder_out_nll for the decoder's last hidden activation, read by
+                                repo_conv_down (8.8 MB of mask instead of 282 MB of activations at 2450 frames)   */
 
 int repo_abi_version(void);
 const char* repo_strerror(int code);
@@ -108,10 +112,11 @@ int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t ld
  *   down : small = gather(big)      encoder forward / decoder backward-data
  *   up   : big   = scatter(small)   decoder forward / encoder backward-data
  *   wgrad: dw = corr(small, big)    both
- * epi: REPO_EPI_NONE (+bias if given), REPO_EPI_RELU (+bias), REPO_EPI_MUL_DRELU (aux has
- * the output's shape).  `big_is_u8` != 0: big is uint8 pixels (encoder conv1 only). */
+ * epi: REPO_EPI_NONE (+bias if given), REPO_EPI_RELU (+bias), REPO_EPI_MUL_DRELU (aux: fp32, the
+ * output's shape), REPO_EPI_MUL_MASK4 (aux: the output's quad mask, numel/4 bytes).
+ * `big_is_u8` != 0: big is uint8 pixels (encoder conv1 only). */
 int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
-                   const float* bias, float* small, int epi, const float* aux, hipStream_t stream);
+                   const float* bias, float* small, int epi, const void* aux, hipStream_t stream);
 /* `up` works from a fragment-ready copy of the layer's weights in `ws` (layers 1..5; 0 bytes for the 3-channel
  * layers 0 and 6): at least repo_conv_up_workspace_bytes(layer).  repo_conv_up_pack writes that copy; repo_conv_up
  * writes it itself first unless ws_is_packed != 0 (the weights change once per optimiser step, not per call). */
@@ -131,11 +136,15 @@ int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big
  *   recon = up(layer 6)(h3) + bias;  d = recon - target
  *   dpre[img][c][y][x] = d * grad_scale          (gradient w.r.t. recon of the mean loss)
  *   loss_sum += 0.5*d*d   (per-workgroup partials in ws, reduced into *loss_sum in order)
- * recon and dpre may each be NULL.  target is uint8 (target_is_u8) or fp32 in [-1,1]. */
+ * recon and dpre may each be NULL.  target is uint8 (target_is_u8) or fp32 in [-1,1].
+ * relu_mask4 (nullable, nimg*32*900/4 bytes): the quad mask of h3 (REPO_EPI_MUL_MASK4) -- the kernel has every
+ * element of h3 in registers on its way to LDS anyway, and the layer's data gradient (repo_conv_down, layer 6)
+ * then needs h3 for nothing else. */
 size_t repo_decoder_out_nll_workspace_bytes(int64_t nimg);
 int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* w, const float* bias,
                          const void* target, int target_is_u8, float grad_scale, float* recon,
-                         float* dpre, float* loss_sum, void* ws, size_t ws_bytes, hipStream_t stream);
+                         float* dpre, unsigned char* relu_mask4, float* loss_sum, void* ws, size_t ws_bytes,
+                         hipStream_t stream);
 
 /* out[c] (+)= sum over n and p of x[n][c][p]   (bias gradient of an NCHW activation) */
 size_t repo_channel_sum_workspace_bytes(int64_t nimg, int64_t C, int64_t P);

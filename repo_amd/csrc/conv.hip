@@ -485,12 +485,14 @@ using namespace repo;
   }
 
 extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
-                              const float* bias, float* small, int epi, const float* aux, hipStream_t stream) {
+                              const float* bias, float* small, int epi, const void* aux_, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(big && w && small, REPO_E_BADARG);
-  REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU || (epi == REPO_EPI_MUL_DRELU && aux), REPO_E_BADARG);
+  REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU ||
+                   ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_MASK4) && aux_), REPO_E_BADARG);
+  const float* aux = (const float*)aux_;  // fp32 activations, or the quad mask's bytes (REPO_EPI_MUL_MASK4)
   if (big_is_u8) {
     REPO_REQUIRE(layer == 0, REPO_E_BADARG);
     return conv_down_t<GEnc1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, stream);
@@ -545,11 +547,11 @@ extern "C" size_t repo_decoder_out_nll_workspace_bytes(int64_t nimg) {
 
 template <class TgtT>
 static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, const float* bias, const TgtT* target,
-                             float grad_scale, float* recon, float* dpre, float* loss_sum, void* ws,
-                             hipStream_t stream) {
+                             float grad_scale, float* recon, float* dpre, unsigned char* mask4, float* loss_sum,
+                             void* ws, hipStream_t stream) {
   using G = GDec4;
   const int nparts = dec4_nll_grid(nimg);
-  NllArgs a{h3, w, bias, target, recon, dpre, (float*)ws, grad_scale, (int)nimg,
+  NllArgs a{h3, w, bias, target, recon, dpre, mask4, (float*)ws, grad_scale, (int)nimg,
             (unsigned)(nimg * G::CS * G::PS * sizeof(float))};
   hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
   REPO_CHECK_LAUNCH();
@@ -563,17 +565,18 @@ static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, cons
 
 extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* w, const float* bias,
                                     const void* target, int target_is_u8, float grad_scale, float* recon, float* dpre,
-                                    float* loss_sum, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                    unsigned char* relu_mask4, float* loss_sum, void* ws, size_t ws_bytes,
+                                    hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
   REPO_REQUIRE(h3 && w && target, REPO_E_BADARG);
   REPO_REQUIRE(nimg * (int64_t)GDec4::CS * GDec4::PS < kMaxBufElems, REPO_E_SHAPE);
   REPO_REQUIRE(ws && ws_bytes >= repo_decoder_out_nll_workspace_bytes(nimg), REPO_E_WS_TOO_SMALL);
   if (target_is_u8)
-    return decoder_out_nll_t<uint8_t>(nimg, h3, w, bias, (const uint8_t*)target, grad_scale, recon, dpre, loss_sum, ws,
-                                      stream);
-  return decoder_out_nll_t<float>(nimg, h3, w, bias, (const float*)target, grad_scale, recon, dpre, loss_sum, ws,
-                                  stream);
+    return decoder_out_nll_t<uint8_t>(nimg, h3, w, bias, (const uint8_t*)target, grad_scale, recon, dpre, relu_mask4,
+                                      loss_sum, ws, stream);
+  return decoder_out_nll_t<float>(nimg, h3, w, bias, (const float*)target, grad_scale, recon, dpre, relu_mask4, loss_sum,
+                                  ws, stream);
 }
 
 static inline int chansum_splits(int64_t nimg, int64_t C, int64_t P) {

@@ -84,6 +84,8 @@ struct Patch4<uint8_t> {
   }
 };
 
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
 struct DownArgs {
   const void* big;
   const float* w;
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   constexpr int W_NV = BM * KSL / 4, W_KV = KSL / 4;  // weight vectors per chunk / per row
   constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * PLV + NT - 1) / NT;
   constexpr int NBUF = NSL > 1 ? 2 : 1;  // a single channel chunk (the 3-channel layers) needs one buffer
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * KSL * LDW + NBUF * CK * PLMAX];
+  constexpr int EP = 36;  // epilogue strip pitch (below)
+  __shared__ __attribute__((aligned(16))) float lds[cmax(NBUF * KSL * LDW + NBUF * CK * PLMAX, (NT / 64) * 32 * EP)];
   float* Wl = lds;
   float* Pl = lds + NBUF * KSL * LDW;
 
@@ -255,29 +258,73 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
     }
   }
 
-  // ---- epilogue: lane = pixel column, 16 channel rows per accumulator tile
+  // ---- epilogue.  An accumulator tile has its pixel on the lane and 16 channel rows in registers: stored as it
+  // stands, that is 16 dword stores (+ 16 dword loads of the ReLU operand) of 128 contiguous bytes per half-wave,
+  // and the store ISSUE, not the bytes, set the pace (ablation on one box, round 3: the epilogue was 11 % of decoder
+  // conv3's data gradient, 40 % of the 3-channel layers').  Each wave therefore turns its tile through a private
+  // LDS strip (the K loop's buffers are free by now) so that a lane owns ONE channel and FOUR consecutive pixels:
+  // one 16-byte load of the ReLU operand, one 16-byte store (raw-buffer accesses need dword alignment only); a quad
+  // that runs over the end of an image or of the tensor falls back to dwords.
+  // (strip pitch EP = 36: 16-byte aligned rows, the quads of 8 consecutive channels on distinct banks)
+  __syncthreads();  // every wave is done with the last chunk's operands
+  float* strip = lds + wid * 32 * EP;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 4u * (unsigned)Ntot * G::CS);
+  const __amdgpu_buffer_rsrc_t raux =
+      make_rsrc(p.aux ? p.aux : p.out, (p.epi == REPO_EPI_MUL_MASK4 ? 1u : 4u) * (unsigned)Ntot * G::CS);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + li;
-      const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
-      if (n < Ntot && mb < G::CS) {
-        const int img = n / G::PS, pix = n % G::PS;
-        const int o0 = (img * G::CS + mb) * G::PS + pix;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = (r & 3) + 8 * (r >> 2);
-          if (mb + dm < G::CS) {
-            const int o = o0 + dm * G::PS;
-            float v = acc[i][j][r];
-            if (p.bias) v += p.bias[mb + dm];
-            if (p.epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
-            else if (p.epi == REPO_EPI_MUL_DRELU) v = p.aux[o] > 0.f ? v : 0.f;
-            p.out[o] = v;
+      for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + li] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();
+      const int nb = n0 + (wn * TN + j) * 32, mt = m0 + (wm * TM + i) * 32;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int ml = pass * 8 + (lane >> 3), q = lane & 7;
+        const int m = mt + ml, n = nb + 4 * q;
+        f32x4 v = *reinterpret_cast<const f32x4*>(strip + ml * EP + 4 * q);
+        if (m < G::CS && n < Ntot) {
+          const float bv = p.bias ? p.bias[m] : 0.f;
+          const int img = n / G::PS, pix = n % G::PS;
+          const unsigned o = (unsigned)((img * G::CS + m) * G::PS + pix);
+          if (pix + 3 < G::PS && n + 3 < Ntot) {
+            f32x4 a4 = {1.f, 1.f, 1.f, 1.f};
+            if (p.epi == REPO_EPI_MUL_DRELU) {
+              a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, 4u * o, 0, 0));
+            } else if (p.epi == REPO_EPI_MUL_MASK4) {
+              // bits o .. o+3 of the quad mask: one byte when the quad is aligned (always, for PS % 4 == 0), else two
+              unsigned bits = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(raux, o >> 2, 0, 0) >> (o & 3);
+              if (o & 3) bits |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(raux, (o >> 2) + 1, 0, 0) << (4 - (o & 3));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) a4[e] = (bits >> e) & 1u ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = v[e] + bv;
+              if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
+              else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_MASK4) x = a4[e] > 0.f ? x : 0.f;
+              v[e] = x;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rout, 4u * o, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ne = n + e;
+              if (ne < Ntot) {
+                const int oe = ((ne / G::PS) * G::CS + m) * G::PS + ne % G::PS;
+                float x = v[e] + bv;
+                if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
+                else if (p.epi == REPO_EPI_MUL_DRELU) x = p.aux[oe] > 0.f ? x : 0.f;
+                else if (p.epi == REPO_EPI_MUL_MASK4)
+                  x = (reinterpret_cast<const unsigned char*>(p.aux)[oe >> 2] >> (oe & 3)) & 1 ? x : 0.f;
+                p.out[oe] = x;
+              }
+            }
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
   REPO_STAMP_FLUSH(NSL);
 }
@@ -598,6 +645,7 @@ struct NllArgs {
   const void* target;
   float* recon;     // nullable
   float* dpre;      // nullable
+  unsigned char* mask4;  // nullable: quad mask of h3 (REPO_EPI_MUL_MASK4)
   float* partials;  // one per workgroup
   float grad_scale;
   int nimg;
@@ -671,9 +719,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   auto lstore = [&](int tile) __attribute__((always_inline)) {
     const int rg = tile & 3;
     const unsigned long long bad = (rg == 0 ? mtop : 0ull) | (rg == 3 ? mbot : 0ull);
+    // quad mask of h3: this tile OWNS strip rows 2..9 (its 8 class rows; 6 in an image's last quarter) = the
+    // 16-byte vectors 15..74 (..59) of a channel's strip, each exactly one aligned quad of the flat tensor
+    const int e4_end = rg == 3 ? 60 : 75;
+    const long mbase = (long)(tile >> 2) * CS * PS + ((tile & 3) * 8 - 2) * HS;  // flat index of the strip's element 0
 #pragma unroll
     for (int j = 0; j < P_PER; ++j)
       if (pgo[j] >= 0) {
+        if (p.mask4) {
+          const int v = tid + j * 256, e4 = v % 75;
+          if (e4 >= 15 && e4 < e4_end) {
+            const unsigned nib = (rpv[j][0] > 0.f ? 1u : 0u) | (rpv[j][1] > 0.f ? 2u : 0u) | (rpv[j][2] > 0.f ? 4u : 0u) |
+                                 (rpv[j][3] > 0.f ? 8u : 0u);
+            p.mask4[(mbase + pgo[j]) >> 2] = (unsigned char)nib;
+          }
+        }
         const int base = ppk[j] & 0xffff, col0 = ppk[j] >> 16;
 #pragma unroll
         for (int e = 0; e < 4; ++e)

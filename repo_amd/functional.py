@@ -91,8 +91,8 @@ def decoder_fwd_nll(p, feat, target, grad_scale):
     """Decoder forward fused with the unit-variance pixel NLL (repo.py:46-53).
     Returns (sum 0.5*(recon-target)^2 (1,), saved incl. d loss/d recon * grad_scale)."""
     h0, h1, h2, h3 = decoder_trunk_fwd(p, feat)
-    loss_sum, dpre4, _ = ops.decoder_out_nll(h3, p[8], p[9], target, grad_scale)
-    return loss_sum, (h0, h1, h2, h3, dpre4)
+    loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(h3, p[8], p[9], target, grad_scale, want_mask=True)
+    return loss_sum, (h0, h1, h2, h3, dpre4, mask3)
 
 
 def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None, deferred=None):
@@ -101,7 +101,8 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
     deferred: a list that receives the weight-gradient launches as closures instead of running them, so
     the caller can issue them beside a later latency-bound kernel (they depend only on tensors kept
     alive by the closures)."""
-    h0, h1, h2, h3, d4 = saved
+    h0, h1, h2, h3, d4 = saved[:5]
+    mask3 = saved[5] if len(saved) > 5 else None  # quad mask of h3 from the fused output layer (8.8 MB for 282)
     rows = feat.shape[0]
     fk = _Fork(side, deferred)
 
@@ -110,7 +111,10 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
         ops.channel_sum(d4, out=g[9], accumulate=accumulate)
 
     fk.run(w4)
-    d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
+    if mask3 is not None:
+        d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_MASK4, aux=mask3)
+    else:
+        d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
 
     def w3():
         ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)

@@ -9,7 +9,7 @@ import torch
 
 from ._lib import check, lib
 
-EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU = 0, 1, 2, 3, 4
+EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU, EPI_MUL_MASK4 = 0, 1, 2, 3, 4, 5
 
 # layer ids of repo_conv_* (include/repo_hip.h)
 ENC1, ENC2, ENC3, ENC4, DEC2, DEC3, DEC4 = range(7)
@@ -174,9 +174,10 @@ def conv_wgrad(layer, small, big, dw=None, db=None, accumulate=False, want_bias=
     return dw, db
 
 
-def decoder_out_nll(h3, w, bias, target, grad_scale, want_recon=False, want_dpre=True):
+def decoder_out_nll(h3, w, bias, target, grad_scale, want_recon=False, want_dpre=True, want_mask=False):
     """Final transposed conv fused with 0.5*(recon-target)^2 summed over everything.
-    Returns (loss_sum (1,), dpre or None, recon or None)."""
+    Returns (loss_sum (1,), dpre or None, recon or None) and, with want_mask, the quad mask of h3
+    (uint8, numel/4: EPI_MUL_MASK4 of the layer's data gradient) as a fourth element."""
     nimg = h3.shape[0]
     is_u8 = target.dtype == torch.uint8
     assert target.is_contiguous() and target.numel() == nimg * 3 * 64 * 64
@@ -184,15 +185,16 @@ def decoder_out_nll(h3, w, bias, target, grad_scale, want_recon=False, want_dpre
     recon = torch.empty(nimg, 3, 64, 64, dtype=torch.float32, device=dev) if want_recon else None
     dpre = torch.empty(nimg, 3, 64, 64, dtype=torch.float32, device=dev) if want_dpre else None
     loss = torch.empty(1, dtype=torch.float32, device=dev)
+    mask = torch.empty(h3.numel() // 4, dtype=torch.uint8, device=dev) if want_mask else None
     nb = lib().repo_decoder_out_nll_workspace_bytes(nimg)
     ws = workspace(nb, dev)
     check(
         lib().repo_decoder_out_nll(nimg, _ptr(_f32c(h3)), _ptr(_f32c(w)), _ptr(bias), _ptr(target), int(is_u8),
-                                   float(grad_scale), _ptr(recon), _ptr(dpre), _ptr(loss), _ptr(ws), ws.numel(),
-                                   _stream()),
+                                   float(grad_scale), _ptr(recon), _ptr(dpre), _ptr(mask), _ptr(loss), _ptr(ws),
+                                   ws.numel(), _stream()),
         "repo_decoder_out_nll",
     )
-    return loss, dpre, recon
+    return (loss, dpre, recon, mask) if want_mask else (loss, dpre, recon)
 
 
 def channel_sum(x, out=None, accumulate=False):

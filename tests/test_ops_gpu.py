@@ -200,6 +200,43 @@ def test_decoder_out_nll(ops, u8, nimg):
     e0, e1, e2 = relerr(rec, recon), relerr(dpre, d * 0.25), abs(loss.item() - (0.5 * d * d).sum().item()) / (0.5 * d * d).sum().item()
     log(f"decoder_out_nll u8={u8}: recon {e0:.2e} dpre {e1:.2e} loss {e2:.2e}")
     assert e0 < TOL and e1 < TOL and e2 < 1e-5
+    # the quad mask of h3 (REPO_EPI_MUL_MASK4): bit (o & 3) of byte (o >> 2) is h3.flat[o] > 0, every byte written
+    sentinel = torch.full((h3.numel() // 4,), 0xAA, dtype=torch.uint8)
+    import repo_amd.ops as rops
+    loss2, dpre2, _, mask = ops.decoder_out_nll(dev(h3), dev(w), dev(b), dev(obs if u8 else tgt), 0.25, want_mask=True)
+    assert mask.dtype == torch.uint8 and mask.numel() == h3.numel() // 4
+    bits = (h3.reshape(-1, 4) > 0).to(torch.uint8)
+    want = bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)
+    assert torch.equal(mask.cpu(), want)
+    assert torch.equal(dpre2, dpre) and loss2.item() == loss.item()
+    # ... and the data gradient that reads it equals the one that reads h3 itself, bit for bit
+    d4 = dev(rnd(rs, nimg, 3, 64, 64))
+    a = ops.conv_down(rops.DEC4, d4, dev(w), None, epi=rops.EPI_MUL_DRELU, aux=dev(h3))
+    m = ops.conv_down(rops.DEC4, d4, dev(w), None, epi=rops.EPI_MUL_MASK4, aux=mask)
+    assert torch.equal(a, m)
+    assert float((a == 0).float().mean()) > 0.3  # the mask really masks
+    del sentinel
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3, 4, 5, 6])
+def test_conv_down_quad_mask_any_geometry(ops, layer):
+    """REPO_EPI_MUL_MASK4 on every geometry (pixel planes of 196, 36, 4, 25, 169 and 900 elements: quads that are
+    unaligned in the mask's bytes and quads that run over an image's end) equals REPO_EPI_MUL_DRELU bit for bit."""
+    import repo_amd.ops as rops
+    rs = np.random.RandomState(40 + layer)
+    (cb, hb, _), (cs, hs, _) = rops.conv_shapes(layer)
+    ks = rops.CONV_GEO[layer][3]
+    for nimg in (1, 7):
+        big = dev(rnd(rs, nimg, cb, hb, hb))
+        w = dev(rnd(rs, cs, cb, ks, ks, scale=0.1))
+        h = F.relu(rnd(rs, nimg, cs, hs, hs))
+        flat = h.reshape(-1)
+        pad = (-flat.numel()) % 4
+        bits = (torch.cat([flat, torch.zeros(pad)]).reshape(-1, 4) > 0).to(torch.uint8)
+        mask = (bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)).cuda()
+        a = ops.conv_down(layer, big, w, None, epi=rops.EPI_MUL_DRELU, aux=dev(h))
+        m = ops.conv_down(layer, big, w, None, epi=rops.EPI_MUL_MASK4, aux=mask)
+        assert torch.equal(a, m), (layer, nimg)
 
 
 def test_channel_sum_relu_mask(ops):

@@ -78,6 +78,9 @@ for li, nm in enumerate(LAYERS):
         if LAYERS[li].startswith("enc"):
             return lambda: ops.conv_down(li, big, w, bs, epi=ops.EPI_RELU, out=out)
         aux = small.clone()
+        if LAYERS[li] == "dec4" and os.environ.get("ISO_MASK", "1") == "1":   # as the update calls it: the ReLU operand is the quad mask of the fused output layer
+            mask = torch.randint(0, 16, (small.numel() // 4,), device=dev, dtype=torch.uint8)
+            return lambda: ops.conv_down(li, big.float(), w, None, epi=ops.EPI_MUL_MASK4, aux=mask, out=out)
         return lambda: ops.conv_down(li, big.float(), w, None, epi=ops.EPI_MUL_DRELU, aux=aux, out=out)
 
     def up(li=li, mk=mk):
@@ -108,7 +111,7 @@ def _nll():
     h3 = r(N, 32, 30, 30).relu_()
     w, b = r(32, 3, 6, 6, scale=0.05), r(3)
     tgt = torch.randint(0, 256, (N, 3, 64, 64), device=dev, dtype=torch.uint8)
-    return lambda: ops.decoder_out_nll(h3, w, b, tgt, 1e-3)
+    return lambda: ops.decoder_out_nll(h3, w, b, tgt, 1e-3, want_mask=os.environ.get("ISO_MASK", "1") == "1")
 
 
 def gemm(M, Nn, K, tb=True, epi=ops.EPI_NONE):
