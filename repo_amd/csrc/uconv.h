@@ -236,13 +236,99 @@ __device__ __forceinline__ void uconv_chunk(const UScatArgs& p, char* pl, int cl
   __builtin_amdgcn_wave_barrier();
 }
 
-// Drain the finished tile: bias / activation / mask, stores.  Wave q owns channel quad q (channels 4q..4q+3 of the tile's 16): a work item is one output pixel --
+// Drain the finished tile: bias / activation / mask, stores.  Wave q owns channel quad q (channels 4q..4q+3 of the
+// tile's 16).  A work item is FOUR consecutive pixels f0..f0+3 (f0 % 4 == 0) of an image's FLAT output plane (rows
+// are contiguous, so a quad may run over a row end; only a plane's last quad can be ragged): four 16-byte LDS reads
+// (one per pixel, each from the pixel's own class plane), a 4 x 4 register transpose, then ONE 16-byte store (and
+// one 16-byte load of the ReLU operand) per channel.  With one pixel per item the drain issued four dword stores +
+// four dword loads per pixel and was 26-27 % of the encoder's data gradients (ablation, round 3): the store issue,
+// not the bytes, set its pace.  Items are issued in batches (all LDS reads and mask loads before the first store).
+template <class G, class C>
+__device__ __forceinline__ void uconv_drain(const UScatArgs& p, float* planes, int grp, int img0, int q, int lane) {
+  constexpr int GI = C::GI, NXM = C::NXM, PLANE = C::PLANE;
+  constexpr int PB = G::PB, WB = G::WB;
+  constexpr int NQ = (PB + 3) / 4;       // pixel quads per image plane (the last may be ragged)
+  constexpr int NI = GI * NQ;            // items of this wave
+  constexpr int UB = 4;
+  const int cb = grp * 16 + 4 * q;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = p.bias[cb + i];
+  }
+  const size_t out_elems = (size_t)p.nimg * G::CB * PB;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, (unsigned)(out_elems * 4));
+  const __amdgpu_buffer_rsrc_t raux = make_rsrc(p.aux ? p.aux : p.out, (unsigned)(out_elems * 4));
+  for (int v0 = lane; v0 < NI; v0 += 64 * UB) {
+    f32x4acc w[UB][4], msk[UB][4];
+    unsigned gofs[UB];
+    int nv[UB];  // valid pixels of the quad (0: no item)
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int v = v0 + u * 64;
+      const int il = v / NQ, f0 = 4 * (v % NQ);
+      const bool act = v < NI && img0 + il < p.nimg;
+      nv[u] = act ? min(4, PB - f0) : 0;
+      gofs[u] = (unsigned)(((img0 + il) * G::CB + cb) * PB + f0);
+      const f32x4acc* ibase = reinterpret_cast<const f32x4acc*>(planes) + (il * 16 + q) * PLANE;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = f0 + e, y = f / WB, x = f % WB;
+        w[u][e] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+        if (e < nv[u]) w[u][e] = ibase[(((y & 1) << 1) | (x & 1)) * 4 * PLANE + (y >> 1) * NXM + (x >> 1)];
+      }
+      if (p.epi == REPO_EPI_MUL_DRELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          msk[u][i] = f32x4acc{1.f, 1.f, 1.f, 1.f};
+          if (nv[u] == 4) {
+            msk[u][i] = __builtin_bit_cast(f32x4acc, __builtin_amdgcn_raw_buffer_load_b128(raux, 4u * (gofs[u] + (unsigned)i * PB), 0, 0));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (e < nv[u]) msk[u][i][e] = p.aux[(size_t)gofs[u] + (size_t)i * PB + e];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (nv[u] == 0) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4acc t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = w[u][e][i] + bv[i];
+          if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
+          else if (p.epi == REPO_EPI_MUL_DRELU) x = msk[u][i][e] > 0.f ? x : 0.f;
+          t[e] = x;
+        }
+        const unsigned o = gofs[u] + (unsigned)i * PB;
+        if (nv[u] == 4) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, t), rout, 4u * o, 0, 0);
+        } else {
+          // a plane's ragged last quad (copies pinned in registers of their own before the branches, cf. rowtile.h)
+          float e0 = t[0], e1 = t[1], e2 = t[2];
+          asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2));
+          if (nv[u] > 0) p.out[o] = e0;
+          if (nv[u] > 1) p.out[o + 1] = e1;
+          if (nv[u] > 2) p.out[o + 2] = e2;
+        }
+      }
+    }
+  }
+}
+
+// The same drain one pixel per item (four dword stores): for planes with PB % 4 != 0, where three of the four channel
+// planes of a quad start off a 16-byte boundary and the misaligned 16-byte accesses cost more than they save (enc2's
+// 961-pixel planes: 421 -> 429 us; aligned planes: enc3 273 -> 241, dec3 560 -> 530).  Wave q owns channel quad q (channels 4q..4q+3 of the tile's 16): a work item is one output pixel --
 // ONE 16-byte LDS read (+ the zero written back) and four dword stores, one per channel plane; the 64 lanes hold
 // 64 consecutive pixels, so every store instruction writes 256 contiguous bytes and the wave's four biases are
 // uniform.  Items are issued in batches (all LDS reads and mask loads of a batch before its first store): one at a
 // time this phase is a chain of dependent latencies.
 template <class G, class C>
-__device__ __forceinline__ void uconv_drain(const UScatArgs& p, float* planes, int grp, int img0, int q, int lane) {
+__device__ __forceinline__ void uconv_drain1(const UScatArgs& p, float* planes, int grp, int img0, int q, int lane) {
   constexpr int GI = C::GI, NXM = C::NXM, PLANE = C::PLANE;
   constexpr int PB = G::PB, WB = G::WB;
   constexpr int NI = GI * PB;  // items of this wave: (image, output pixel)
@@ -346,7 +432,8 @@ __global__ __launch_bounds__(256, 2) void uconv_scatter_kernel(UScatArgs p) {
     if (NTAIL > 0) uconv_chunk<G, C, (NTAIL > 0 ? NTAIL : 1), 1>(p, buf, cls, lane, chunk_of(NFULL * NC, true), none, dmy, bfr, afr);
   }
   __syncthreads();
-  uconv_drain<G, C>(p, planes, grp, img0, cls, lane);
+  if (G::PB % 4 == 0) uconv_drain<G, C>(p, planes, grp, img0, cls, lane);
+  else uconv_drain1<G, C>(p, planes, grp, img0, cls, lane);
 }
 
 template <class G, class C>
