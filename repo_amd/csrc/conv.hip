@@ -309,7 +309,9 @@ __global__ void relu_mask_kernel(int64_t n, const float* __restrict__ dy, const 
 // direct-conv tiles per layer: <BM, BN, CK, WM, WN>
 template <class G>
 struct DTileFor;
-// wgrad tiles: <BM, BN, WM, WN, images per chunk, small rows per chunk>
+// wgrad tiles: <BM, BN, WM, WN, images per chunk, small rows per chunk>; WGT = workgroups the split-K over image
+// groups aims at (sweep of 768 / 1024 / 1536 / 2048 / 3072 on one box, round 3: enc2 371 -> 335 us at 768, enc3
+// 239 -> 226 at 1024, dec3 542 -> 531 at 2048; fewer splits also mean smaller slabs to reduce)
 // the 3-channel layers are one channel chunk per workgroup (no pipelining inside it): 8 waves per tile and short
 // weight-gradient bands measured best (tile sweep, round 2: enc1 fwd 148 -> 140 us, enc1 wgrad 224 -> 171,
 // dec4 dgrad 311-338 -> 247, dec4 wgrad 210 -> 201)
@@ -319,21 +321,21 @@ struct DTileFor;
 #ifndef REPO_DT_ENC1
 #define REPO_DT_ENC1 DTile<32, 512, 3, 1, 8>
 #endif
-template <> struct DTileFor<GEnc1> { using Down = REPO_DT_ENC1; using Wgrad = REPO_WT_ENC1; };
+template <> struct DTileFor<GEnc1> { using Down = REPO_DT_ENC1; using Wgrad = REPO_WT_ENC1; static constexpr int WGT = 3072; };
 #ifndef REPO_WT_ENC2
 #define REPO_WT_ENC2 WTile<64, 128, 2, 2, 1, 7, 2>
 #endif
 #ifndef REPO_DT_ENC2
 #define REPO_DT_ENC2 DTile<64, 128, 2, 2, 2>
 #endif
-template <> struct DTileFor<GEnc2> { using Down = REPO_DT_ENC2; using Wgrad = REPO_WT_ENC2; };
+template <> struct DTileFor<GEnc2> { using Down = REPO_DT_ENC2; using Wgrad = REPO_WT_ENC2; static constexpr int WGT = 768; };
 #ifndef REPO_WT_ENC3
 #define REPO_WT_ENC3 WTile<64, 128, 2, 2, 2, 6>
 #endif
 #ifndef REPO_DT_ENC3
 #define REPO_DT_ENC3 DTile<128, 128, 2, 2, 2>
 #endif
-template <> struct DTileFor<GEnc3> { using Down = REPO_DT_ENC3; using Wgrad = REPO_WT_ENC3; };
+template <> struct DTileFor<GEnc3> { using Down = REPO_DT_ENC3; using Wgrad = REPO_WT_ENC3; static constexpr int WGT = 1024; };
 // enc4 forward has only 9800 output pixels: 128 x 128 tiles are 154 workgroups on 256 CUs (171 us); 32 x 64: 125 us
 #ifndef REPO_WT_ENC4
 #define REPO_WT_ENC4 WTile<64, 128, 2, 2, 8, 2>
@@ -341,28 +343,28 @@ template <> struct DTileFor<GEnc3> { using Down = REPO_DT_ENC3; using Wgrad = RE
 #ifndef REPO_DT_ENC4
 #define REPO_DT_ENC4 DTile<32, 64, 2, 1, 2>
 #endif
-template <> struct DTileFor<GEnc4> { using Down = REPO_DT_ENC4; using Wgrad = REPO_WT_ENC4; };
+template <> struct DTileFor<GEnc4> { using Down = REPO_DT_ENC4; using Wgrad = REPO_WT_ENC4; static constexpr int WGT = 768; };
 #ifndef REPO_WT_DEC2
 #define REPO_WT_DEC2 WTile<64, 128, 2, 2, 4, 5>
 #endif
 #ifndef REPO_DT_DEC2
 #define REPO_DT_DEC2 DTile<128, 128, 4, 2, 2, 1>
 #endif
-template <> struct DTileFor<GDec2> { using Down = REPO_DT_DEC2; using Wgrad = REPO_WT_DEC2; };
+template <> struct DTileFor<GDec2> { using Down = REPO_DT_DEC2; using Wgrad = REPO_WT_DEC2; static constexpr int WGT = 1536; };
 #ifndef REPO_WT_DEC3
 #define REPO_WT_DEC3 WTile<64, 128, 2, 2, 1, 7>
 #endif
 #ifndef REPO_DT_DEC3
 #define REPO_DT_DEC3 DTile<64, 128, 2, 2, 2>
 #endif
-template <> struct DTileFor<GDec3> { using Down = REPO_DT_DEC3; using Wgrad = REPO_WT_DEC3; };
+template <> struct DTileFor<GDec3> { using Down = REPO_DT_DEC3; using Wgrad = REPO_WT_DEC3; static constexpr int WGT = 2048; };
 #ifndef REPO_WT_DEC4
 #define REPO_WT_DEC4 WTile<32, 128, 1, 4, 1, 2>
 #endif
 #ifndef REPO_DT_DEC4
 #define REPO_DT_DEC4 DTile<32, 256, 3, 1, 8>
 #endif
-template <> struct DTileFor<GDec4> { using Down = REPO_DT_DEC4; using Wgrad = REPO_WT_DEC4; };
+template <> struct DTileFor<GDec4> { using Down = REPO_DT_DEC4; using Wgrad = REPO_WT_DEC4; static constexpr int WGT = 1536; };
 
 // A handful of frames (the acting path encodes ONE per environment step): the throughput tiles leave 1-2
 // workgroups walking 16-64 dependent channel chunks (enc4: 147 us for one frame).  Latency tiles use 32
@@ -424,7 +426,7 @@ template <class G>
 static int dwgrad_ips(int64_t nimg) {
   using T = typename DTileFor<G>::Wgrad;
   const long tiles = ((G::CS + T::BM - 1) / T::BM) * ((G::CB * G::KK + T::BN - 1) / T::BN);
-  long want = (1536 + tiles - 1) / tiles;
+  long want = (DTileFor<G>::WGT + tiles - 1) / tiles;
   long ips = (nimg + want - 1) / want;
   const long min_ips = T::GI * ((G::PS >= 512) ? 1 : (G::PS >= 64 ? 2 : 4));
   if (ips < min_ips) ips = min_ips;
