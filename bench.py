@@ -467,6 +467,19 @@ def main():
     run_resident(2)
     dt_res = timed(run_resident, args.steps)
 
+    # north_star's literal input path ("sequence sampler ... pinned-memory hipMemcpyAsync'd to device"): the same loop
+    # with the HBM mirror off -- the batch is gathered on the host by repo_host_gather_rows (a few threads, into a
+    # page-locked slot) and copied on a side stream while the previous update computes
+    dt_pin = None
+    if world == 1 and not args.strong:
+        ring = agent.buffer
+        mirror, ring._mirror = ring._mirror, None
+        ring.__dict__.pop("_stage", None)
+        run_from_ring(3)
+        dt_pin = timed(run_from_ring, args.steps)
+        ring._mirror = mirror
+        ring.__dict__.pop("_stage", None)
+
     # N > 1: the same line also carries STRONG scaling -- one global batch of B sequences dealt 7,7,6,... over
     # the ranks, every rank sampling its shard from its own ring (a collective-free re-shard: reset_counts()
     # on all ranks, then the first global_count() of the next update gathers the new shard sizes)
@@ -522,6 +535,7 @@ def main():
                 "frac_of_fp32_mfma_peak_all_gpus": round(flop * value / 1e12 / FP32_MFMA_PEAK_TFLOPS / nranks, 4),
             },
             "resident_batch_ms": round(dt_res / args.steps * 1e3, 3),
+            "pinned_path_ms": round(dt_pin / args.steps * 1e3, 3) if dt_pin is not None else None,
             "last_scalars": {k: round(float(v), 6) for k, v in agent.last_scalars.items()},
         }
         line["roofline"] = roofline(timer, (L - 1) * Bl)

@@ -131,6 +131,14 @@ int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big
                     float* dw, float* dbias_small, int accumulate, void* ws, size_t ws_bytes,
                     hipStream_t stream);
 
+/* ------------------------------------------------------------------ replay batch gather (HOST memory, no GPU work)
+ * dst[i] = src[idx[i]] for n rows of row_bytes bytes, copied by `nthreads` host threads -- the reference's
+ * `ring[batch_inds]` (SequenceReplayBuffer._get_samples, common/buffers.py:186-191) written straight into the
+ * page-locked staging slot the asynchronous host-to-device copy reads from.  REPO_E_SHAPE if an index is outside
+ * [0, src_rows).  Needs no device; safe to call concurrently with kernel launches from another thread. */
+int repo_host_gather_rows(const void* src, int64_t src_rows, int64_t row_bytes, const int64_t* idx,
+                          int64_t n, void* dst, int nthreads);
+
 /* Final decoder layer fused with the pixel likelihood (models/decoder.py:47 +
  * -Normal(recon,1).log_prob(obs[1:]).sum((2,3,4)).mean((0,1)), repo.py:46-53):
  *   recon = up(layer 6)(h3) + bias;  d = recon - target

@@ -19,11 +19,37 @@ MI355X additions:
    The host arrays stay the source of truth (save/load, reference semantics unchanged).
 Frames stay uint8 on the device; normalisation is fused into the first convolution's loader.
 """
+import os
+
 import numpy as np
 import torch
 
 
 _FIELDS = ("observations", "actions", "rewards", "dones")
+# host threads of the pinned-path batch gather (repo_host_gather_rows); REPO_GATHER_THREADS overrides
+_GATHER_THREADS = int(os.environ.get("REPO_GATHER_THREADS", "0")) or max(1, min(8, (os.cpu_count() or 2) // 2))
+
+
+def _gather_rows(src, inds, out):
+    """out[i] = src[inds[i]] (the reference's `ring[batch_inds]`, common/buffers.py:186-191) by the C helper: a few
+    host threads copy the rows straight into `out` (a page-locked staging slot) with the GIL released.  Falls back
+    to np.take when the library is not built (host-only use of the buffer)."""
+    try:
+        from .._lib import RepoHipError, check, lib
+        L = lib()
+    except Exception:  # noqa: BLE001  (no librepo_hip.so: the buffer still works as a plain host ring)
+        np.take(src, inds, axis=0, out=out)
+        return
+    assert src.flags.c_contiguous and out.flags.c_contiguous and out.dtype == src.dtype and out.shape[1:] == src.shape[1:]
+    idx = np.ascontiguousarray(inds, dtype=np.int64)
+    row_bytes = src[0].nbytes if src.shape[0] else 0
+    if len(idx) == 0 or row_bytes == 0:
+        return
+    rc = L.repo_host_gather_rows(src.ctypes.data, src.shape[0], row_bytes, idx.ctypes.data, len(idx), out.ctypes.data,
+                                 _GATHER_THREADS)
+    if rc == -2:  # REPO_E_SHAPE: what NumPy reports for the same mistake
+        raise IndexError("replay gather: index out of range")
+    check(rc, "repo_host_gather_rows")
 
 
 def _time_major_indices(starts, seq_len):
@@ -214,7 +240,7 @@ class SequenceReplayBuffer:
             slot["event"].synchronize()  # previous copy out of this pinned slot has finished
         srcs = (self.observations, self.actions, self.rewards, self.dones)
         for h, src in zip(slot["host"], srcs):
-            np.take(src, inds, axis=0, out=h.numpy())
+            _gather_rows(src, inds, h.numpy())
         if st["stream"] is not None:
             consumed = slot.get("consumed")
             if consumed is not None:

@@ -78,6 +78,34 @@ def test_offline_adoption_matches_reference_golden():
             assert o.shape == (5, 3) + gh.OBS_SHAPE
 
 
+def test_host_gather_rows_equals_numpy_take():
+    """repo_host_gather_rows (the pinned path's batch gather) == ring[batch_inds]
+    (common/buffers.py:186-191) for frames and for the narrow fields, any thread count; a bad index is an
+    IndexError, nothing is copied out of range."""
+    import pytest
+
+    from repo_amd.common import buffers as B
+
+    rs = np.random.RandomState(5)
+    frames = rs.randint(0, 256, (300, 3, 64, 64)).astype(np.uint8)
+    acts = rs.uniform(-1, 1, (300, 6)).astype(np.float32)
+    inds = rs.randint(0, 300, 700)
+    old = B._GATHER_THREADS
+    try:
+        for th in (1, 3, 8):
+            B._GATHER_THREADS = th
+            for src in (frames, acts):
+                out = np.zeros((len(inds),) + src.shape[1:], dtype=src.dtype)
+                B._gather_rows(src, inds, out)
+                assert np.array_equal(out, src[inds]), (th, src.dtype)
+        with pytest.raises(IndexError):
+            B._gather_rows(frames, np.array([0, 300]), np.zeros((2, 3, 64, 64), np.uint8))
+        with pytest.raises(IndexError):
+            B._gather_rows(frames, np.array([-1]), np.zeros((1, 3, 64, 64), np.uint8))
+    finally:
+        B._GATHER_THREADS = old
+
+
 def test_c_abi_exports_every_declared_symbol():
     """librepo_hip.so loads without a GPU and exports every prototype of include/repo_hip.h
     (no compute call is made here)."""
