@@ -235,6 +235,10 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, i
   }
 }
 
+}  // namespace repo
+#include "wgrad_direct.h"
+namespace repo {
+
 static int wgrad_splits(long rows, long N, long K) {
   const long tiles = ((N + 63) / 64) * ((K + 1 + 63) / 64);
   long want = (768 + tiles - 1) / tiles;  // ~3 workgroups per CU
@@ -357,6 +361,12 @@ int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t
   }
   REPO_REQUIRE(ws && ws_bytes >= gemm_wgrad_group_ws_bytes(d, n), REPO_E_WS_TOO_SMALL);
   VWgradGroupOp op{};
+  WdJobs dj{};
+  int ndirect = 0;
+  for (int i = 0; i < n; ++i) ndirect += wgrad_direct_ok(d[i].M, d[i].N, d[i].K, d[i].lddy, d[i].ldx) ? 1 : 0;
+  if (ndirect > kWdMaxJobs) ndirect = kWdMaxJobs;
+  int dsplits = ndirect ? 256 / ndirect : 0;  // one workgroup per CU over all direct jobs of the launch
+  if (dsplits > kWdMaxSplits) dsplits = kWdMaxSplits;
   char* w = (char*)ws;
   long nblocks = 0;
   int z = 0, rmax = 0;
@@ -366,7 +376,16 @@ int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t
     REPO_REQUIRE(q.M < kMaxIdx && q.N < kMaxIdx && q.K < kMaxIdx - 1 && q.M * q.lddy < kMaxBufElems &&
                      q.M * q.ldx < kMaxBufElems,
                  REPO_E_SHAPE);
-    const int splits = wgrad_splits(q.M, q.N, q.K);
+    // the wide hidden layers of a head at tens of thousands of rows go straight from global memory to the matrix
+    // cores (wgrad_direct.h); everything else (1- and 12-row output layers, short row counts) through the tile engine
+    const bool direct = dj.njobs < kWdMaxJobs && wgrad_direct_ok(q.M, q.N, q.K, q.lddy, q.ldx);
+    const int splits = direct ? dsplits : wgrad_splits(q.M, q.N, q.K);
+    if (direct) {
+      WdJob& x = dj.job[dj.njobs++];
+      x.dY = q.dY, x.X = q.X, x.slab = (float*)w;
+      x.rows = (int)q.M, x.N = (int)q.N, x.K = (int)q.K, x.lddy = (int)q.lddy, x.ldx = (int)q.ldx;
+      x.rps = (int)(((q.M + splits - 1) / splits + 1) & ~1L);  // even: row pairs never straddle two ranges
+    }
     WgradJobDev& j = op.g.job[i];
     j.A = Dense2D{q.dY, 4u * (unsigned)((q.M - 1) * q.lddy + q.N), (int)q.lddy};
     j.B = Dense2D{q.X, 4u * (unsigned)((q.M - 1) * q.ldx + q.K), (int)q.ldx};
@@ -377,7 +396,7 @@ int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t
     j.zstart = z;
     j.gx = (int)cdiv(q.K + 1, T64x64::BN), j.gy = (int)cdiv(q.N, T64x64::BM);
     j.bstart = (int)nblocks;
-    nblocks += (long)j.gx * j.gy * splits;
+    if (!direct) nblocks += (long)j.gx * j.gy * splits;  // a direct job owns no tiles of the flat grid
     z += splits;
     w += (repo_gemm_wgrad_workspace_bytes(q.M, q.N, q.K) + 255) & ~(size_t)255;
     const int total = (int)(q.N * (q.K + 1));
@@ -386,8 +405,14 @@ int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t
   op.g.job[n].zstart = z;  // end marker
   op.g.job[n].bstart = (int)nblocks;
   op.g.njobs = n;
-  const int rc = launch_vgemm_flat<T64x64>(op, nblocks, stream);
-  if (rc) return rc;
+  if (dj.njobs > 0) {
+    hipLaunchKernelGGL(wgrad_direct_kernel, dim3(dsplits, dj.njobs), dim3(512), 0, stream, dj);
+    REPO_CHECK_LAUNCH();
+  }
+  if (nblocks > 0) {
+    const int rc = launch_vgemm_flat<T64x64>(op, nblocks, stream);
+    if (rc) return rc;
+  }
   const int blocks = cdiv(rmax, 256) < 1024 ? cdiv(rmax, 256) : 1024;
   hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(blocks, n), dim3(256), 0, stream, op.g, accumulate);
   REPO_CHECK_LAUNCH();
@@ -471,7 +496,9 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
 
 extern "C" size_t repo_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (size_t)wgrad_splits(M, N, K) * (size_t)N * (size_t)(K + 1) * sizeof(float);
+  int splits = wgrad_splits(M, N, K);
+  if (splits < kWdMaxSplits) splits = kWdMaxSplits;  // room for the direct kernel's row ranges (wgrad_direct.h)
+  return (size_t)splits * (size_t)N * (size_t)(K + 1) * sizeof(float);
 }
 
 extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t lddy,

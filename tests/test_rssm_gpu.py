@@ -85,9 +85,12 @@ def test_observe_fwd_bwd(ops, T, B, A):
     assert e < GTOL
 
 
-# rows >= 16384 run 32-row tiles (csrc/mlp16.hip); 16400 and 17001 leave a ragged last tile
+# rows >= 16384 run 32-row tiles (csrc/mlp16.hip); 16400 and 17001 leave a ragged last tile.  rows >= 4096: the weight
+# gradients of the 200-wide layers take the direct kernel (csrc/wgrad_direct.h): 4097 and 17001 end on a single row
+# (a half k-step), 4100 / 64 row ranges leaves the last ranges empty
 @pytest.mark.parametrize("mod,L,rows", [("reward_model", 4, 333), ("actor_model", 5, 1000), ("value_model", 4, 64),
-                                        ("value_model", 4, 16400), ("actor_model", 5, 17001), ("reward_model", 4, 1)])
+                                        ("value_model", 4, 16400), ("actor_model", 5, 17001), ("reward_model", 4, 1),
+                                        ("value_model", 4, 4097), ("actor_model", 5, 4100)])
 def test_mlp_fwd_bwd(ops, mod, L, rows):
     A = 6
     rs = np.random.RandomState(rows)

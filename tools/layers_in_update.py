@@ -5,7 +5,7 @@ duration, and -- for the conv kernels, whose FLOPs follow from the geometry in t
 the fraction of the fp32-MFMA peak at that in-update duration.  Next to profiles/rNN_layers_isolated.txt this
 shows what concurrency costs each kernel.
 
-    python tools/layers_in_update.py <kernel_stats.csv> <updates in the trace> [--json profiles/dominant_kernel_rocprof.json]
+    python tools/layers_in_update.py <kernel_stats.csv> [updates in the trace] [--json profiles/dominant_kernel_rocprof.json]
 """
 import csv
 import json
@@ -26,8 +26,12 @@ def conv_flop(name):
 
 
 def main():
-    path, nupd = sys.argv[1], float(sys.argv[2])
+    path = sys.argv[1]
     rows = list(csv.DictReader(open(path)))
+    # updates in the trace: one dual step (RePo) / three clip+Adam steps per update
+    by = {re.sub(r"\(.*", "", re.sub(r"repo::|void ", "", r["Name"])): int(r["Calls"]) for r in rows}
+    nupd = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].replace(".", "").isdigit() else float(
+        by.get("dual_step_kernel", 0) or by.get("clip_adam_kernel", 0) / 3)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"# kernels of the update as it runs (rocprofv3 --kernel-trace --stats of bench.py, {nupd:.0f} updates in the trace)")
     print(f"# sum of kernel time per update: {tot_ns / nupd / 1e6:.2f} ms")
