@@ -114,9 +114,16 @@ int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t ld
  *   wgrad: dw = corr(small, big)    both
  * epi: REPO_EPI_NONE (+bias if given), REPO_EPI_RELU (+bias), REPO_EPI_MUL_DRELU (aux: fp32, the
  * output's shape), REPO_EPI_MUL_MASK4 (aux: the output's quad mask, numel/4 bytes).
- * `big_is_u8` != 0: big is uint8 pixels (encoder conv1 only). */
+ * `big_is_u8` != 0: big is uint8 pixels (encoder conv1 only).
+ * dbias_small (nullable, [small_ch]): (+)= the sum over images and pixels of the values written to `small` -- when
+ * `small` is the pre-activation gradient of the transposed-conv layer below (decoder backward), that is that layer's
+ * bias gradient, taken while the values are in registers instead of by a second pass over the tensor
+ * (repo_channel_sum).  Needs ws >= repo_conv_down_workspace_bytes(layer, nimg) then (per-workgroup partial sums,
+ * reduced in a fixed order: bit-reproducible). */
+size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg);
 int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
-                   const float* bias, float* small, int epi, const void* aux, hipStream_t stream);
+                   const float* bias, float* small, int epi, const void* aux, float* dbias_small,
+                   int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t stream);
 /* `up` works from a fragment-ready copy of the layer's weights in `ws` (layers 1..5; 0 bytes for the 3-channel
  * layers 0 and 6): at least repo_conv_up_workspace_bytes(layer).  repo_conv_up_pack writes that copy; repo_conv_up
  * writes it itself first unless ws_is_packed != 0 (the weights change once per optimiser step, not per call). */

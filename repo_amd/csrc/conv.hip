@@ -374,14 +374,29 @@ template <> struct DLatTile<GEnc2> { using type = DTile<32, 128, 4, 1, 4>; };
 template <> struct DLatTile<GEnc3> { using type = DTile<32, 128, 8, 1, 4>; };
 template <> struct DLatTile<GEnc4> { using type = DTile<32, 128, 8, 1, 4>; };
 
+// pixel tiles of the direct conv's grid = rows of the channel-sum partials (repo_conv_down's dbias)
+template <class G>
+static long conv_down_tiles(int64_t nimg) {
+  const long px = nimg * (long)G::PS;
+  const long bn = px <= 512 ? DLatTile<G>::type::BN : DTileFor<G>::Down::BN;
+  return (px + bn - 1) / bn;
+}
+
 template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
-                       const float* aux, hipStream_t s) {
+                       const float* aux, float* dbias, int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
+  const long tiles = conv_down_tiles<G>(nimg);
+  if (dbias && (!ws || ws_bytes < (size_t)tiles * G::CS * sizeof(float))) return REPO_E_WS_TOO_SMALL;
   DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
-             (unsigned)(G::CS * G::CB * G::KK * sizeof(float))};
-  if (nimg * (int64_t)G::PS <= 512) return launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s);
-  return launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
+             (unsigned)(G::CS * G::CB * G::KK * sizeof(float)), dbias ? (float*)ws : nullptr};
+  const int rc = (nimg * (int64_t)G::PS <= 512) ? launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s)
+                                                : launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
+  if (rc || !dbias) return rc;
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(G::CS, 4)), dim3(256), 0, s, (const float*)ws, (int)tiles,
+                     (int)G::CS, dbias, accumulate_dbias);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
 }
 
 // Scatter-form configuration per geometry: images per workgroup, resident N tiles, weight prefetch.
@@ -487,7 +502,8 @@ using namespace repo;
   }
 
 extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
-                              const float* bias, float* small, int epi, const void* aux_, hipStream_t stream) {
+                              const float* bias, float* small, int epi, const void* aux_, float* dbias_small,
+                              int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
@@ -497,9 +513,16 @@ extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_
   const float* aux = (const float*)aux_;  // fp32 activations, or the quad mask's bytes (REPO_EPI_MUL_MASK4)
   if (big_is_u8) {
     REPO_REQUIRE(layer == 0, REPO_E_BADARG);
-    return conv_down_t<GEnc1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, stream);
+    return conv_down_t<GEnc1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, dbias_small,
+                                       accumulate_dbias, ws, ws_bytes, stream);
   }
-  REPO_LAYER_SWITCH(layer, return (conv_down_t<G, float>(nimg, (const float*)big, w, bias, small, epi, aux, stream)))
+  REPO_LAYER_SWITCH(layer, return (conv_down_t<G, float>(nimg, (const float*)big, w, bias, small, epi, aux, dbias_small,
+                                                         accumulate_dbias, ws, ws_bytes, stream)))
+}
+
+extern "C" size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg) {
+  if (nimg <= 0) return 0;
+  REPO_LAYER_SWITCH(layer, return ((size_t)conv_down_tiles<G>(nimg) * G::CS * sizeof(float)))
 }
 
 extern "C" size_t repo_conv_up_workspace_bytes(int layer) {

@@ -94,6 +94,7 @@ struct DownArgs {
   float* out;
   int nimg, epi;
   unsigned big_bytes, w_bytes;
+  float* chan_part;  // nullable: [pixel tiles][CS] sums of the written values per output channel (bias gradients)
 };
 
 template <class G, class BigT, class T>
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * PLV + NT - 1) / NT;
   constexpr int NBUF = NSL > 1 ? 2 : 1;  // a single channel chunk (the 3-channel layers) needs one buffer
   constexpr int EP = 36;  // epilogue strip pitch (below)
-  __shared__ __attribute__((aligned(16))) float lds[cmax(NBUF * KSL * LDW + NBUF * CK * PLMAX, (NT / 64) * 32 * EP)];
+  // (+ one row of per-wave channel sums behind the strips: DownArgs::chan_part)
+  __shared__ __attribute__((aligned(16))) float lds[cmax(NBUF * KSL * LDW + NBUF * CK * PLMAX, (NT / 64) * 32 * EP + (NT / 64) * TM * 32)];
   float* Wl = lds;
   float* Pl = lds + NBUF * KSL * LDW;
 
@@ -269,6 +271,14 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   __syncthreads();  // every wave is done with the last chunk's operands
   float* strip = lds + wid * 32 * EP;
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 4u * (unsigned)Ntot * G::CS);
+  // channel sums of what this workgroup writes (the bias gradient of the layer whose pre-activation gradient this
+  // is): a lane's quad, then the 8 lanes of a channel by shuffles, summed over the wave's pixel tiles in registers;
+  // the waves' rows meet in LDS and ONE thread per channel adds them in a fixed order -- no atomics, reproducible
+  float csum[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) csum[i][q4] = 0.f;
   const __amdgpu_buffer_rsrc_t raux =
       make_rsrc(p.aux ? p.aux : p.out, (p.epi == REPO_EPI_MUL_MASK4 ? 1u : 4u) * (unsigned)Ntot * G::CS);
 #pragma unroll
@@ -284,6 +294,7 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
         const int ml = pass * 8 + (lane >> 3), q = lane & 7;
         const int m = mt + ml, n = nb + 4 * q;
         f32x4 v = *reinterpret_cast<const f32x4*>(strip + ml * EP + 4 * q);
+        float qs = 0.f;  // this lane's contribution to its channel's sum
         if (m < G::CS && n < Ntot) {
           const float bv = p.bias ? p.bias[m] : 0.f;
           const int img = n / G::PS, pix = n % G::PS;
@@ -306,6 +317,7 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
               else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_MASK4) x = a4[e] > 0.f ? x : 0.f;
               v[e] = x;
             }
+            qs = (v[0] + v[1]) + (v[2] + v[3]);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rout, 4u * o, 0, 0);
           } else {
 #pragma unroll
@@ -319,13 +331,37 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
                 else if (p.epi == REPO_EPI_MUL_MASK4)
                   x = (reinterpret_cast<const unsigned char*>(p.aux)[oe >> 2] >> (oe & 3)) & 1 ? x : 0.f;
                 p.out[oe] = x;
+                qs += x;
               }
             }
           }
         }
+        if (p.chan_part) {  // wave-uniform
+          qs += __shfl_xor(qs, 1, 64);
+          qs += __shfl_xor(qs, 2, 64);
+          qs += __shfl_xor(qs, 4, 64);
+          csum[i][pass] += qs;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
+  if (p.chan_part) {
+    float* red = lds + (NT / 64) * 32 * EP;  // [wave][TM * 32]
+    if ((lane & 7) == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) red[wid * (TM * 32) + i * 32 + pass * 8 + (lane >> 3)] = csum[i][pass];
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < G::CS) {
+      const int wmc = tid / (TM * 32), c = tid % (TM * 32);
+      float t = 0.f;
+#pragma unroll
+      for (int x = 0; x < T::WN; ++x) t += red[(wmc * T::WN + x) * (TM * 32) + c];
+      p.chan_part[(size_t)blockIdx.x * G::CS + m0 + tid] = t;
+    }
+  }
   REPO_STAMP_FLUSH(NSL);
 }
 

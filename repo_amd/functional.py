@@ -111,6 +111,11 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
         ops.channel_sum(d4, out=g[9], accumulate=accumulate)
 
     fk.run(w4)
+    # The bias gradients of conv3 / conv2 / conv1 (g[7], g[5], g[3]) are the channel sums of d3 / d2 / d1.  They stay
+    # separate passes on the weight-gradient stream: taking them in the data-gradient kernels' epilogues
+    # (ops.conv_down(dbias=), tested) saves 240 us of kernel time per update but puts the shuffles, one more
+    # barrier per workgroup and a dependent reduction launch per layer ON the critical chain: 8.65 vs 8.55 ms per
+    # update (A/B on one box, round 3).
     if mask3 is not None:
         d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_MASK4, aux=mask3)
     else:
@@ -142,3 +147,4 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
     if dfeat is not None:
         ops.gemm(dh0, p[0], out=dfeat, accumulate=accumulate_dfeat)
     fk.join()
+

@@ -112,7 +112,9 @@ def gemm_wgrad(dY, X, dW=None, db=None, accumulate=False, want_bias=True):
     return dW, db
 
 
-def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None):
+def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None, dbias=None, accumulate_dbias=False):
+    """dbias: optional [small_ch] tensor that receives (accumulate_dbias: is added) the per-channel sum of the output
+    -- the bias gradient of the transposed-conv layer whose pre-activation gradient this call produces."""
     nimg = big.shape[0]
     (cb, hb, _), (cs, hs, _) = conv_shapes(layer)
     assert tuple(big.shape[1:]) == (cb, hb, hb) and big.is_contiguous(), big.shape
@@ -120,9 +122,13 @@ def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None):
     assert is_u8 or big.dtype == torch.float32
     if out is None:
         out = torch.empty(nimg, cs, hs, hs, dtype=torch.float32, device=big.device)
+    ws, nb = None, 0
+    if dbias is not None:
+        nb = lib().repo_conv_down_workspace_bytes(layer, nimg)
+        ws = workspace(nb, big.device)
     check(
         lib().repo_conv_down(layer, nimg, _ptr(big), int(is_u8), _ptr(_f32c(w)), _ptr(bias), _ptr(out), epi,
-                             _ptr(aux), _stream()),
+                             _ptr(aux), _ptr(dbias), int(accumulate_dbias), _ptr(ws), nb, _stream()),
         "repo_conv_down",
     )
     return out

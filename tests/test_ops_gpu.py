@@ -218,6 +218,31 @@ def test_decoder_out_nll(ops, u8, nimg):
     del sentinel
 
 
+@pytest.mark.parametrize("layer", [0, 1, 2, 3, 4, 5, 6])
+def test_conv_down_channel_sums(ops, layer):
+    """repo_conv_down's dbias: the per-channel sum of the values it writes (the bias gradient of the transposed-conv
+    layer below, taken in the epilogue) == a second pass over the output; throughput and latency tiles (<= 512
+    output pixels), ragged last tiles, accumulation, run-to-run bit-identical."""
+    import repo_amd.ops as rops
+    rs = np.random.RandomState(70 + layer)
+    (cb, hb, _), (cs, hs, _) = rops.conv_shapes(layer)
+    ks = rops.CONV_GEO[layer][3]
+    for nimg in (1, 9):
+        big = dev(rnd(rs, nimg, cb, hb, hb))
+        w = dev(rnd(rs, cs, cb, ks, ks, scale=0.1))
+        h = dev(F.relu(rnd(rs, nimg, cs, hs, hs)))
+        db = torch.full((cs,), 3.0, device="cuda")
+        out = ops.conv_down(layer, big, w, None, epi=rops.EPI_MUL_DRELU, aux=h, dbias=db, accumulate_dbias=True)
+        want = out.double().sum((0, 2, 3)) + 3.0
+        assert relerr(db, want) < TOL, (layer, nimg, relerr(db, want))
+        db2 = torch.empty(cs, device="cuda")
+        out2 = ops.conv_down(layer, big, w, None, epi=rops.EPI_MUL_DRELU, aux=h, dbias=db2)
+        db3 = torch.empty(cs, device="cuda")
+        ops.conv_down(layer, big, w, None, epi=rops.EPI_MUL_DRELU, aux=h, dbias=db3)
+        assert torch.equal(out2, out) and torch.equal(db2, db3)
+        assert relerr(db2, out.double().sum((0, 2, 3))) < TOL
+
+
 @pytest.mark.parametrize("layer", [1, 2, 3, 4, 5, 6])
 def test_conv_down_quad_mask_any_geometry(ops, layer):
     """REPO_EPI_MUL_MASK4 on every geometry (pixel planes of 196, 36, 4, 25, 169 and 900 elements: quads that are

@@ -76,7 +76,7 @@ int main() {
     void* ws;
     (void)hipMalloc(&ws, wsb ? wsb : 4);
     char nm[64];
-    float ms = run([&] { return repo_conv_down(l.id, n, big, 0, w, nullptr, small, 0, nullptr, 0); });
+    float ms = run([&] { return repo_conv_down(l.id, n, big, 0, w, nullptr, small, 0, nullptr, nullptr, 0, nullptr, 0, 0); });
     snprintf(nm, sizeof nm, "%s down", l.nm);
     report(nm, flop, ms);
     ms = run([&] { return repo_conv_wgrad(l.id, n, small, big, 0, dw, nullptr, 0, ws, wsb, 0); });
