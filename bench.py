@@ -366,6 +366,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE global batch of B sequences sharded over the ranks (7,7,6,...) "
                          "instead of B per GPU; resident batch only; not the contract's default")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="override the config's batch size (e.g. 7 = one rank's shard of the strong-scaling job at 8 "
+                         "GPUs, to time its compute alone); not the contract's default, the line says so")
     ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -386,6 +389,8 @@ def main():
 
     algo, B, A, label = CONFIGS[args.config]
     algo = args.algo or algo
+    if args.batch:
+        B, label = args.batch, label + f" with the batch overridden to {args.batch} (--batch)"
     set_gpu_mode(True, local_rank)
     dev = torch.device("cuda", local_rank)
     dp = None
@@ -484,7 +489,8 @@ def main():
     # the ranks, every rank sampling its shard from its own ring (a collective-free re-shard: reset_counts()
     # on all ranks, then the first global_count() of the next update gathers the new shard sizes)
     strong = None
-    if dp is not None and world > 1 and not args.strong:
+    # REPO_BENCH_FORCE_STRONG=1 (with REPO_FORCE_DP=1): walk the re-shard path with one rank (the whole batch is its shard)
+    if dp is not None and (world > 1 or os.environ.get("REPO_BENCH_FORCE_STRONG") == "1") and not args.strong:
         from repo_amd.parallel import shard_rows
 
         lo, hi = shard_rows(B, world, rank)
