@@ -108,11 +108,12 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t blk, floa
   for (int h = 0; h < 2; ++h) {
     const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.f / 16777216.f);      // (0, 1)
     const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.f / 16777216.f);
-    const float rad = sqrtf(-2.f * __logf(u1));
-    float sn, cs;
-    __sincosf(6.283185307179586f * u2, &sn, &cs);
-    z[2 * h] = rad * cs;
-    z[2 * h + 1] = rad * sn;
+    // hardware transcendentals (v_log_f32 = log2, v_sqrt_f32, v_sin/v_cos_f32 take REVOLUTIONS: sin(2 pi x)), ~1 ulp
+    // each: the noise only has to be N(0,1), and every consumer (the kernels that draw it, their backward passes,
+    // repo_philox_normal) evaluates this one function
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln 2 * log2 u1
+    z[2 * h] = rad * __builtin_amdgcn_cosf(u2);
+    z[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
   }
 }
 __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t i) {

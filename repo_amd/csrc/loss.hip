@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void tanh_normal_entropy_kernel(int n, int NS,
       const float dlt = x - mu;
       slog += -0.5f * dlt * dlt * isd2 - lsd - 0.5f * kLog2Pi - 2.f * (kLog2 - x - softplus(-2.f * x));
       // dlogp/dx (through the recomputed inverse) times dx/du (1 inside the clamp, else 0)
-      const float via_x = pass ? (-dlt * isd2 + 2.f * tanhf(x)) : 0.f;
+      // d/dx of the log-det term is 2 tanh(x), and tanh(x) = tanh(atanh(yc)) = yc
+      const float via_x = pass ? (-dlt * isd2 + 2.f * yc) : 0.f;
       gmu += dlt * isd2 + via_x;
       gsd += dlt * dlt * isd2 * isd - isd + via_x * ep;
     }
