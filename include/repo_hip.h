@@ -188,7 +188,8 @@ int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStre
  *          prior_state/mean/std, post_mean/std (T,B,S).
  * Saved for backward: xsa (T,B,S+A), e (T,B,D), gates (T,B,4D) = r|z|n|W_hn h+b_hn,
  *          hp, hq (T,B,Hd); eemb (T,B,Hd) is scratch for the hoisted embedding GEMM.
- * prior_only != 0: the reference's `observations=None` branch (rssm.py:118): step t+1 is fed the PRIOR sample of
+ * prior_only == 2: the scan leaves the prior head out (repo_rssm_prior_head below computes it for all steps).
+ * prior_only == 1: the reference's `observations=None` branch (rssm.py:118): step t+1 is fed the PRIOR sample of
  *          step t, featx[t+1][D:] = prior sample; the posterior outputs are then computed from whatever
  *          `embeds` holds and mean nothing (forward only: repo_rssm_observe_bwd assumes prior_only == 0). */
 size_t repo_rssm_observe_fwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
@@ -202,6 +203,18 @@ int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd
                           float* prior_std, float* post_mean, float* post_std, float* xsa, float* e,
                           float* gates, float* hp, float* hq, float* eemb, int prior_only, void* ws,
                           size_t ws_bytes, hipStream_t stream);
+
+/* The prior head (fc_embed_belief_prior, fc_state_prior, softplus + sample: rssm.py:42-50) of ALL T steps at once.
+ * It depends on belief_t only, i.e. it is off the recurrence: repo_rssm_observe_fwd(prior_only = 2) leaves it out of
+ * the scan (7-10 % of the weights a step streams), and this call -- two (T*B)-row GEMMs and an elementwise kernel --
+ * can run on another stream beside whatever consumes the posterior first (the decoder).  featx as written by the
+ * scan; hp (T,B,Hd) and the three prior tensors (T,B,S) as repo_rssm_observe_fwd would have written them (the same
+ * noise: eps_prior, or the Philox stream (seed, offset) of the scan's call). */
+size_t repo_rssm_prior_head_workspace_bytes(int64_t T, int64_t B, int64_t S);
+int repo_rssm_prior_head(int64_t T, int64_t B, int64_t D, int64_t Hd, int64_t S, const float* const* params,
+                         const float* featx, const float* eps_prior, uint64_t noise_seed, uint64_t noise_offset,
+                         float min_std, float* hp, float* prior_state, float* prior_mean, float* prior_std, void* ws,
+                         size_t ws_bytes, hipStream_t stream);
 
 /* Reverse scan (BPTT) + deferred weight gradients.  Upstream gradients (each nullable):
  * dfeat (T,B,D+S) w.r.t. featx[1:], dprior_state, dpm, dps, dqm, dqs (T,B,S) w.r.t. the

@@ -238,6 +238,8 @@ class Dreamer:
             pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
             self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev,
             noise=self._draw(2 * T * B * S),
+            # the prior head is off the recurrence: evaluated for all steps on the side stream, beside the decoder
+            prior_stream=self._side_stream if os.environ.get("REPO_PRIOR_HOIST", "1") == "1" else None,
         )
         st["sv"] = sv
         feat = sv.featx[1:].reshape(rows, D + S)
@@ -339,6 +341,8 @@ class Dreamer:
         obs, actions, rewards, nonterms = self._prep_batch(obs, actions, rewards, nonterms)
         st = self._world_model_forward(obs, actions, rewards, nonterms)
         sv, grow = st["sv"], st["grow"]
+        if sv.prior_ready is not None:
+            torch.cuda.current_stream(self.device).wait_stream(sv.prior_ready)
         kl_sum, kl_grads = ops.kl_balance(sv.prior_mean, sv.prior_std, sv.post_mean, sv.post_std, 1, 0.0, None,
                                           float(c.free_nats), 1.0 / grow)
         self._world_model_backward(st, kl_grads, decoder_attached=True)

@@ -55,6 +55,8 @@ class RePo(Dreamer):
         st = self._world_model_forward(obs, actions, rewards, nonterms)
         sv, grow = st["sv"], st["grow"]
         alpha = c.prior_train_steps / (1 + c.prior_train_steps)
+        if sv.prior_ready is not None:  # the prior head ran on the side stream, beside the decoder
+            torch.cuda.current_stream(self.device).wait_stream(sv.prior_ready)
         # gradients use beta BEFORE the dual update (kl_loss = exp(log_beta).detach() * viol, repo.py:83)
         kl_sum, kl_grads = ops.kl_balance(sv.prior_mean, sv.prior_std, sv.post_mean, sv.post_std, 0, alpha,
                                           self.log_beta, 0.0, 1.0 / grow)

@@ -114,6 +114,7 @@ struct ObsFwdArgs {
   float *xsa, *e, *gates, *hp, *hq;       // saved for backward: (T,B,S+A) (T,B,D) (T,B,4D) (T,B,Hd) (T,B,Hd)
   float min_std;
   int prior_only;  // the NEXT step is fed the prior sample (observe without observations, rssm.py:118)
+  int skip_prior;  // the prior head is not evaluated here (repo_rssm_prior_head does it for all steps at once)
 };
 
 // R rows per workgroup, KQ-way split of every reduction (k) range over thread groups of 256:
@@ -327,15 +328,24 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       krange(D, k0, k1);
       const float4* Wp4 = reinterpret_cast<const float4*>(p.WbpT);
       const float4* Wq4 = reinterpret_cast<const float4*>(p.WbqT);
+      if (p.skip_prior) {  // the prior head depends on belief_t only: off the recurrence, done for all steps afterwards
 #pragma unroll 2
-      for (int g = k0; g < k1; ++g) {
-        const float4 wp = Wp4[(size_t)g * Hd + j];
-        const float4 wq = Wq4[(size_t)g * Hd + j];
+        for (int g = k0; g < k1; ++g) {
+          const float4 wq = Wq4[(size_t)g * Hd + j];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const float* hv = hc + r * kMaxW + 4 * g;
-          ap[r] = fma4(wp, hv, ap[r]);
-          aq[r] = fma4(wq, hv, aq[r]);
+          for (int r = 0; r < R; ++r) aq[r] = fma4(wq, hc + r * kMaxW + 4 * g, aq[r]);
+        }
+      } else {
+#pragma unroll 2
+        for (int g = k0; g < k1; ++g) {
+          const float4 wp = Wp4[(size_t)g * Hd + j];
+          const float4 wq = Wq4[(size_t)g * Hd + j];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float* hv = hc + r * kMaxW + 4 * g;
+            ap[r] = fma4(wp, hv, ap[r]);
+            aq[r] = fma4(wq, hv, aq[r]);
+          }
         }
       }
 #pragma unroll
@@ -358,14 +368,14 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
         hps[r][tid] = vp;
         hqs[r][tid] = vq;
         if (r < nr) {
-          p.hp[(row0 + r) * Hd + tid] = vp;
+          if (!p.skip_prior) p.hp[(row0 + r) * Hd + tid] = vp;
           p.hq[(row0 + r) * Hd + tid] = vq;
         }
       }
     }
     __syncthreads();
     // ---- output layers: columns [0,2S) prior, [2S,4S) posterior; k split as above
-    if (j < 4 * S) {
+    if (j < 4 * S && (j >= 2 * S || !p.skip_prior)) {
       const bool post = j >= 2 * S;
       const int o = post ? j - 2 * S : j;
       const float* Wt = post ? p.WsqT : p.WspT;
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(256 * KQ) void observe_fwd_kernel(ObsFwdArgs p) {
       const int base = post ? 2 * S : 0;
       const float mean = outs[r][base + s];
       const float sd = softplus(outs[r][base + S + s]) + p.min_std;
-      if (r < nr) {
+      if (r < nr && (post || !p.skip_prior)) {
         const size_t o = (row0 + r) * S + s;
         const float eps = post ? p.eps_post.at(o) : p.eps_prior.at(o);
         const float smp = fmaf(sd, eps, mean);
@@ -861,7 +871,8 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   a.WbpT = WbpT; a.bbp = P[7]; a.WspT = WspT; a.bsp = P[9]; a.WbqT = WbqT; a.bbq = P[11]; a.WsqT = WsqT; a.bsq = P[13];
   a.prev_belief = prev_belief; a.prev_state = prev_state; a.actions = actions; a.nonterms = nonterms;
   a.eemb = eemb;
-  a.prior_only = prior_only;
+  a.prior_only = prior_only == 1;
+  a.skip_prior = prior_only == 2;
   a.eps_prior = NoiseSrc{eps_prior, noise_seed, noise_offset};
   a.eps_post = NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)};
   a.featx = featx; a.prior_state = prior_state; a.prior_mean = prior_mean; a.prior_std = prior_std;
@@ -880,6 +891,51 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
   } else {
     hipLaunchKernelGGL((observe_fwd_kernel<1, 4>), dim3((unsigned)B), dim3(1024), 0, stream, a);
   }
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+// ---- the prior head of all T steps at once (repo_rssm_observe_fwd with prior_only = 2 leaves it out of the scan)
+__global__ void prior_sample_kernel(int n, int S, const float* __restrict__ outp, NoiseSrc eps, float min_std,
+                                    float* __restrict__ mean_o, float* __restrict__ std_o, float* __restrict__ state_o) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int row = i / S, s = i % S;
+    const float mean = outp[(size_t)row * 2 * S + s];
+    const float sd = softplus(outp[(size_t)row * 2 * S + S + s]) + min_std;
+    mean_o[i] = mean;
+    std_o[i] = sd;
+    state_o[i] = fmaf(sd, eps.at(i), mean);
+  }
+}
+
+extern "C" size_t repo_rssm_prior_head_workspace_bytes(int64_t T, int64_t B, int64_t S) {
+  return (size_t)(T * B * 2 * S) * sizeof(float);
+}
+
+extern "C" int repo_rssm_prior_head(int64_t T, int64_t B, int64_t D, int64_t Hd, int64_t S, const float* const* params,
+                                    const float* featx, const float* eps_prior, uint64_t noise_seed,
+                                    uint64_t noise_offset, float min_std, float* hp, float* prior_state,
+                                    float* prior_mean, float* prior_std, void* ws, size_t ws_bytes,
+                                    hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(T >= 0 && B > 0 && D > 0 && Hd > 0 && S > 0 && T * B * (int64_t)(D + S) < kMaxBufElems, REPO_E_SHAPE);
+  REPO_REQUIRE(params && featx && hp && prior_state && prior_mean && prior_std, REPO_E_BADARG);
+  if (T == 0) return REPO_OK;
+  REPO_REQUIRE(ws && ws_bytes >= repo_rssm_prior_head_workspace_bytes(T, B, S), REPO_E_WS_TOO_SMALL);
+  const int64_t rows = T * B, F = D + S;
+  const float* bel = featx + (size_t)B * F;  // belief_t = featx[t + 1][:, :D]
+  float* outp = (float*)ws;
+  int rc;
+  // hp = elu(belief @ W_bp^T + b);  out = hp @ W_sp^T + b   (fc_embed_belief_prior, fc_state_prior: rssm.py:42-50)
+  if ((rc = repo_gemm(0, 1, rows, Hd, D, bel, F, params[6], D, params[7], 1, hp, Hd, REPO_EPI_ELU, nullptr, 0, 0, stream)))
+    return rc;
+  if ((rc = repo_gemm(0, 1, rows, 2 * S, Hd, hp, Hd, params[8], Hd, params[9], 1, outp, 2 * S, REPO_EPI_NONE, nullptr,
+                      0, 0, stream)))
+    return rc;
+  const int n = (int)(rows * S);
+  hipLaunchKernelGGL(prior_sample_kernel, dim3(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024), dim3(256), 0, stream, n, (int)S,
+                     (const float*)outp, NoiseSrc{eps_prior, noise_seed, noise_offset}, min_std, prior_mean, prior_std,
+                     prior_state);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }

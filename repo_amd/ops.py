@@ -244,13 +244,17 @@ def reduce_ws(device):
 # ----------------------------------------------------------------------------- RSSM observe
 class ObserveSaved:
     __slots__ = ("T", "B", "A", "D", "Hd", "S", "E", "featx", "prior_state", "prior_mean", "prior_std", "post_mean",
-                 "post_std", "xsa", "e", "gates", "hp", "hq", "nonterms", "embeds", "eps_prior", "eps_post", "noise")
+                 "post_std", "xsa", "e", "gates", "hp", "hq", "nonterms", "embeds", "eps_prior", "eps_post", "noise",
+                 "prior_ready")
 
 
 def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds, eps_prior, eps_post, min_std=0.1,
-                     noise=(0, 0), prior_only=False):
+                     noise=(0, 0), prior_only=False, prior_stream=None):
     """params: list of the 14 TransitionModel tensors in state_dict order.  Time-major inputs.
-    eps_prior = eps_post = None: the kernel draws its noise from Philox stream noise = (seed, offset)."""
+    eps_prior = eps_post = None: the kernel draws its noise from Philox stream noise = (seed, offset).
+    prior_stream: a side stream -- the scan then leaves the prior head out (it depends on belief_t only, not on the
+    recurrence) and repo_rssm_prior_head evaluates it for all steps on that stream, beside whatever the caller
+    enqueues next; `sv.prior_ready` (a stream to wait for) guards sv.prior_* and sv.hp."""
     T, B, A = actions.shape
     D, S = prev_belief.shape[1], prev_state.shape[1]
     Hd = params[6].shape[0]
@@ -278,10 +282,26 @@ def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds,
             _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior), _ptr(sv.eps_post), sv.noise[0], sv.noise[1],
             float(min_std), _ptr(sv.featx), _ptr(sv.prior_state), _ptr(sv.prior_mean), _ptr(sv.prior_std), _ptr(sv.post_mean),
             _ptr(sv.post_std), _ptr(sv.xsa), _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(eemb),
-            int(prior_only), _ptr(ws), ws.numel(), _stream(),
+            2 if (prior_stream is not None and not prior_only) else int(prior_only), _ptr(ws), ws.numel(), _stream(),
         ),
         "repo_rssm_observe_fwd",
     )
+    sv.prior_ready = None
+    if prior_stream is not None and not prior_only:
+        main = torch.cuda.current_stream(dev)
+        prior_stream.wait_stream(main)
+        nbp = lib().repo_rssm_prior_head_workspace_bytes(T, B, S)
+        with torch.cuda.stream(prior_stream):
+            wsp = torch.empty(nbp, dtype=torch.uint8, device=dev)  # its own scratch: the shared workspace is the main stream's
+            check(
+                lib().repo_rssm_prior_head(T, B, D, Hd, S, pa, _ptr(sv.featx), _ptr(sv.eps_prior), sv.noise[0], sv.noise[1],
+                                           float(min_std), _ptr(sv.hp), _ptr(sv.prior_state), _ptr(sv.prior_mean),
+                                           _ptr(sv.prior_std), _ptr(wsp), nbp, prior_stream.cuda_stream),
+                "repo_rssm_prior_head",
+            )
+        for t in (sv.hp, sv.prior_state, sv.prior_mean, sv.prior_std):
+            t.record_stream(prior_stream)
+        sv.prior_ready = prior_stream
     return sv
 
 

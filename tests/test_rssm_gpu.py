@@ -453,3 +453,33 @@ def test_observe_without_observations_prior_only_rollout():
     for g, w, name in zip(got, want, ("beliefs", "prior_states", "prior_means", "prior_std_devs")):
         assert tuple(g.shape) == tuple(w.shape)
         np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
+
+
+def test_prior_head_hoisted_out_of_the_scan_matches_in_scan_prior():
+    """repo_rssm_observe_fwd(prior_only = 2) + repo_rssm_prior_head (the prior head of all steps as two GEMMs on a side
+    stream) == the scan that evaluates the prior head step by step: same posterior path bit for bit, prior
+    mean / std / sample and the saved hidden activation within GEMM-order rounding; the reverse scan runs on either."""
+    from repo_amd import ops
+    from tests.test_update_gpu import make_agent
+
+    A, T, B = 6, 9, 5
+    agent, cfg = make_agent("repo", 8, 4, 5, A)
+    p = [t.detach() for t in agent.transition_model.plist()]
+    rs = np.random.RandomState(11)
+    dev = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()  # noqa: E731
+    b0, s0 = dev(rs.standard_normal((B, 200)) * 0.3), dev(rs.standard_normal((B, 30)))
+    act, non = dev(rs.uniform(-1, 1, (T, B, A))), torch.ones(T, B).cuda()
+    non[3, 1] = 0
+    emb = dev(rs.standard_normal((T, B, 1024)) * 0.5)
+    ep, eq = dev(rs.standard_normal((T, B, 30))), dev(rs.standard_normal((T, B, 30)))
+    side = torch.cuda.Stream()
+    for eps in ((ep, eq), (None, None)):  # explicit noise tensors / in-kernel Philox
+        a = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, eps[0], eps[1], 0.1, noise=(77, 1000))
+        h = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, eps[0], eps[1], 0.1, noise=(77, 1000), prior_stream=side)
+        assert h.prior_ready is side and a.prior_ready is None
+        torch.cuda.current_stream().wait_stream(side)
+        for name in ("featx", "post_mean", "post_std", "hq", "gates", "e", "xsa"):
+            assert torch.equal(getattr(a, name), getattr(h, name)), name
+        for name in ("prior_mean", "prior_std", "prior_state", "hp"):
+            np.testing.assert_allclose(getattr(h, name).cpu().numpy(), getattr(a, name).cpu().numpy(), rtol=2e-5, atol=2e-6,
+                                       err_msg=name)
