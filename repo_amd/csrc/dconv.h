@@ -803,33 +803,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         }
       }
 
-    // ---- epilogue
+    // ---- epilogue.  A lane holds, for each of its 4 pixel tiles, two (row parity, channel) pairs q = 2 lg + pr of the
+    // pixel pair (2cx, 2cx+1).  Neighbouring lanes (cx, cx + 1) swap one pair each, so that the even lane owns FOUR
+    // consecutive pixels of pair q0 and the odd lane four of pair q1: one 16-byte store of d recon and one dword of
+    // uint8 targets per lane and tile instead of two 8-byte stores and two 2-byte loads (the epilogue was 22 % of
+    // the kernel: ablation, round 3).
     const int img = tile >> 2, cy0 = (tile & 3) * 8;
     if (lg < 3) {
+      const int odd = lj & 1;
+      const int q = 2 * lg + odd, py = q / 3, cb = q % 3;  // the pair this lane ends up with
+      const float bv = p.bias ? p.bias[cb] : 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        // keep pair `odd`, send pair `1 - odd`; the partner (lane ^ 1) does the opposite
+        const float k0 = odd ? acc[t][2] : acc[t][0], k1 = odd ? acc[t][3] : acc[t][1];
+        const float s0 = odd ? acc[t][0] : acc[t][2], s1 = odd ? acc[t][1] : acc[t][3];
+        const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+        // four consecutive pixels starting at x0 = 4 * (cx >> 1): the even lane's own pair comes first
+        const float v0 = (odd ? r0 : k0) + bv, v1 = (odd ? r1 : k1) + bv, v2 = (odd ? k0 : r0) + bv, v3 = (odd ? k1 : r1) + bv;
         const int cy = cy0 + 2 * wv + (t >> 1), cx = 16 * (t & 1) + lj;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const int q = 2 * lg + pr, py = q / 3, cb = q % 3;
-          const int o = ((img * 3 + cb) * HB + 2 * cy + py) * HB + 2 * cx;
-          const float bv = p.bias ? p.bias[cb] : 0.f;
-          const float v0 = acc[t][2 * pr] + bv, v1 = acc[t][2 * pr + 1] + bv;
-          float t0, t1;
-          if (sizeof(TgtT) == 1) {
-            const unsigned short tw = *reinterpret_cast<const unsigned short*>((const uint8_t*)p.target + o);
-            t0 = pix_norm((uint8_t)(tw & 0xff));
-            t1 = pix_norm((uint8_t)(tw >> 8));
-          } else {
-            const float2 tw = *reinterpret_cast<const float2*>((const float*)p.target + o);
-            t0 = tw.x;
-            t1 = tw.y;
-          }
-          const float d0 = v0 - t0, d1 = v1 - t1;
-          lsum += 0.5f * (d0 * d0 + d1 * d1);
-          if (p.dpre) *reinterpret_cast<float2*>(p.dpre + o) = make_float2(d0 * p.grad_scale, d1 * p.grad_scale);
-          if (p.recon) *reinterpret_cast<float2*>(p.recon + o) = make_float2(v0, v1);
+        const int o = ((img * 3 + cb) * HB + 2 * cy + py) * HB + 4 * (cx >> 1);
+        float t0, t1, t2, t3;
+        if (sizeof(TgtT) == 1) {
+          const unsigned tw = *reinterpret_cast<const unsigned*>((const uint8_t*)p.target + o);
+          t0 = pix_norm((uint8_t)(tw & 0xff));
+          t1 = pix_norm((uint8_t)((tw >> 8) & 0xff));
+          t2 = pix_norm((uint8_t)((tw >> 16) & 0xff));
+          t3 = pix_norm((uint8_t)(tw >> 24));
+        } else {
+          const float4 tw = *reinterpret_cast<const float4*>((const float*)p.target + o);
+          t0 = tw.x, t1 = tw.y, t2 = tw.z, t3 = tw.w;
         }
+        const float d0 = v0 - t0, d1 = v1 - t1, d2 = v2 - t2, d3 = v3 - t3;
+        lsum += 0.5f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        if (p.dpre)
+          *reinterpret_cast<float4*>(p.dpre + o) = make_float4(d0 * p.grad_scale, d1 * p.grad_scale, d2 * p.grad_scale, d3 * p.grad_scale);
+        if (p.recon) *reinterpret_cast<float4*>(p.recon + o) = make_float4(v0, v1, v2, v3);
       }
     }
     __syncthreads();  // patch reads done before the next tile overwrites it
