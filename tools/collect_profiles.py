@@ -1,18 +1,24 @@
-"""Copy the summaries tools/refresh_profiles.sh left in gpurun_out/ to their tracked names under profiles/."""
+"""Copy the summaries tools/refresh_profiles.sh left in gpurun_out/ to their tracked names under profiles/ (round 3)."""
 import json, os, re, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 pairs = [
-    ("layers_isolated.txt", "r02_layers_isolated.txt"),
-    ("r02_bench_pipelined_kernel_stats.csv", "r02_bench_kernel_stats_pipelined.csv"),
-    ("r02_bench_join_kernel_stats.csv", "r02_bench_kernel_stats_join.csv"),
-    ("pmc_dec3/summary.txt", "r02_pmc_dec3_kernels.txt"),
-    ("pmc_scan_rollout/summary.txt", "r02_pmc_scan_rollout.txt"),
-    ("pmc_c3/summary.txt", "r02_pmc_3channel_layers.txt"),
-    ("pmc_mlp/summary.txt", "r02_pmc_mlp_heads.txt"),
-    ("r02_bench_final.json", "r02_bench_final.json"),
-    ("r02_bench_c4_c5.json", "r02_bench_c4_c5.json"),
-    ("lane_time.txt", "r02_lane_time.txt"),
+    ("r03_layers_isolated.txt", "r03_layers_isolated.txt"),
+    ("r03_layers_in_update.txt", "r03_layers_in_update.txt"),
+    ("r03_bench_pipelined_kernel_stats.csv", "r03_bench_kernel_stats_pipelined.csv"),
+    ("r03_bench_join_kernel_stats.csv", "r03_bench_kernel_stats_join.csv"),
+    ("r03_launch_count.txt", "r03_launch_count.txt"),
+    ("pmc_dec3/summary.txt", "r03_pmc_dec3_kernels.txt"),
+    ("pmc_convs/summary.txt", "r03_pmc_conv_layers.txt"),
+    ("pmc_scan_rollout/summary.txt", "r03_pmc_scan_rollout.txt"),
+    ("pmc_c3/summary.txt", "r03_pmc_3channel_layers.txt"),
+    ("pmc_mlp/summary.txt", "r03_pmc_mlp_heads.txt"),
+    ("r03_bench_final.json", "r03_bench_final.json"),
+    ("r03_bench_c4_c5.json", "r03_bench_c4_c5.json"),
+    ("r03_bench_shards.json", "r03_bench_shards.json"),
+    ("r03_lane_time.txt", "r03_lane_time.txt"),
+    ("r03_phase_time.txt", "r03_phase_time.txt"),
+    ("dominant_kernel_rocprof.json", "dominant_kernel_rocprof.json"),
 ]
 for src, dst in pairs:
     s = os.path.join(G, src)
@@ -24,7 +30,7 @@ for src, dst in pairs:
     open(os.path.join(P, dst), "w").write(text)
     print("wrote", dst, len(text))
 # the dominant kernel's counters, as bench.py quotes them
-txt = open(os.path.join(P, "r02_pmc_dec3_kernels.txt")).read()
+txt = open(os.path.join(P, "r03_pmc_dec3_kernels.txt")).read()
 blk = re.search(r"uconv_scatter_kernel.*?(?=\nvoid |\Z)", txt, re.S)
 if blk:
     b = blk.group(0)
@@ -35,7 +41,7 @@ if blk:
     j = {"kernel": "uconv_scatter_kernel<GDec3>", "traffic_bytes_per_launch": int(traffic.group(1)) * 1_000_000,
          "mfma_pipe_busy": float(busy.group(1)), "effective_clock_ghz": float(clock.group(1)),
          "duration_us_under_counters": float(dur.group(1)),
-         "source": "profiles/r02_pmc_dec3_kernels.txt (tools/pmc.sh dec3 ... tools/run_micro_case.py 'conv dec3': rocprofv3 --pmc passes, FETCH_SIZE x2 per MI355X_MICROARCH.md, median of 5 dispatches)"}
+         "source": "profiles/r03_pmc_dec3_kernels.txt (tools/pmc.sh dec3 ... tools/run_micro_case.py 'conv dec3': rocprofv3 --pmc passes, FETCH_SIZE x2 per MI355X_MICROARCH.md, median of 5 dispatches)"}
     old = json.load(open(os.path.join(P, "dominant_kernel_pmc.json")))
     print("dominant kernel pmc: old", {k: old.get(k) for k in j if k != "source"})
     print("dominant kernel pmc: new", {k: j[k] for k in j if k != "source"})

@@ -53,7 +53,9 @@ def main():
                    "frac_at_rocprof_duration": round(tf / PEAK, 4)}
     if "--json" in sys.argv and dom:
         out = sys.argv[sys.argv.index("--json") + 1]
-        dom["source"] = f"rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps {nupd:.0f} (tools/prof_bench.sh; isolated re-runs skipped under the profiler)"
+        dom["source"] = ("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 "
+                         f"(tools/prof_bench.sh; {nupd:.0f} updates in the trace: warm-up, timed, resident-batch and pinned-path "
+                         "loops; the isolated re-runs of the kernel are skipped under the profiler)")
         json.dump(dom, open(out, "w"), indent=1)
         print("# wrote", out, dom)
 

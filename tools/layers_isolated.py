@@ -193,11 +193,24 @@ def _ma():
 SCAN_MAC = 351e3 + 205e3  # per row-step
 
 
-@case("observe scan fwd (T=49,B=50; packs + hoisted embed GEMM + persistent scan)", flop=2.0 * N * SCAN_MAC)
+@case("observe scan fwd (T=49,B=50; packs + hoisted embed GEMM + persistent scan, prior head in the scan)", flop=2.0 * N * SCAN_MAC)
 def _of():
     act, non, emb = r(T, B, A), torch.ones(T, B, device=dev), r(T, B, E).relu_()
     e1, e2, b0, s0 = r(T, B, S), r(T, B, S), r(B, D, scale=0.3), r(B, S)
     return lambda: ops.rssm_observe_fwd(rp, b0, s0, act, non, emb, e1, e2)
+
+
+@case("observe scan fwd as the update calls it (prior head hoisted: 2 GEMMs + sample on a side stream, joined)",
+      flop=2.0 * N * SCAN_MAC)
+def _ofh():
+    act, non, emb = r(T, B, A), torch.ones(T, B, device=dev), r(T, B, E).relu_()
+    e1, e2, b0, s0 = r(T, B, S), r(T, B, S), r(B, D, scale=0.3), r(B, S)
+    side = torch.cuda.Stream()
+
+    def run():
+        ops.rssm_observe_fwd(rp, b0, s0, act, non, emb, e1, e2, prior_stream=side)
+        torch.cuda.current_stream().wait_stream(side)
+    return run
 
 
 @case("observe scan bwd (reverse scan + 8 deferred weight-gradient GEMMs + d-embed GEMM)", flop=4.0 * N * SCAN_MAC)
