@@ -2,7 +2,10 @@
 """Bank conflicts of the weight-gradient kernel's B-fragment reads (csrc/dconv.h, dconv_wgrad_kernel) per layer and
 candidate LDS pitches (BRP floats per row of `big`, BP per channel): lane li of a 32-column N tile reads
 (cb - cbf) * BP + ky * BRP + kx with n = (cb, ky, kx) = n_tile + li; ds_read_b32 has 32 banks.  Prints the current
-pitches' average / worst multiplicity over all N tiles and the smallest conflict-free candidates (the WPitch table)."""
+pitches' average / worst multiplicity over all N tiles and the smallest conflict-free candidates.  Round 3 tried them
+(and an odd pitch for `small`): with the element-wise staging stores they need, dec3 552 -> 592 us; with NO staging
+stores at all (ablation build) enc2 302 -> 291, dec3 505 -> 497, the rest unchanged -- the loop is not LDS-bound.
+Not adopted."""
 geos = {'enc1': (3, 32, 64, 4), 'enc2': (32, 64, 31, 4), 'enc3': (64, 128, 14, 4), 'enc4': (128, 256, 6, 4),
         'dec2': (64, 128, 13, 5), 'dec3': (32, 64, 30, 6), 'dec4': (3, 32, 64, 6)}
 tiles = {'enc1': (64, 4), 'enc2': (128, 7), 'enc3': (128, 6), 'enc4': (128, 2), 'dec2': (128, 5), 'dec3': (128, 7), 'dec4': (128, 2)}  # BN, RB
