@@ -105,6 +105,10 @@ int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t ld
  *                                                     -> 128x6x6 -> 256x2x2, k=4
  *   4..6  decoder conv2..4  (models/decoder.py:37-39): 128x5x5 -> 64x13x13 (k5)
  *                                                     -> 32x30x30 (k6) -> 3x64x64 (k6)
+ * or of the BUILD-DEFINED 128 x 128 stack (BASELINE config 4's frame size; the reference's encoder
+ * hard-codes the 64 x 64 flatten, encoder.py:39, so there is no reference model at this size):
+ *   7..10 encoder conv1..4 at 128: 3x128x128 -> 32x63x63 -> 64x30x30 -> 128x14x14 -> 256x6x6, k=4
+ *   11,12 decoder conv4, conv5 at 128 (after layers 4, 5): 32x30x30 -> 16x64x64 (k6) -> 3x128x128 (k2)
  * Every geometry is a pair (big, small) with big = 2*small + k - 2 and one weight tensor
  * indexed w[small_ch][big_ch][ky][kx] -- which is both nn.Conv2d's (out,in,kh,kw) for the
  * encoder and nn.ConvTranspose2d's (in,out,kh,kw) for the decoder.  Three kernels act on a
@@ -160,6 +164,14 @@ int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* w, const fl
                          const void* target, int target_is_u8, float grad_scale, float* recon,
                          float* dpre, unsigned char* relu_mask4, float* loss_sum, void* ws, size_t ws_bytes,
                          hipStream_t stream);
+
+/* A 3-channel transposed conv fused with the pixel likelihood on the gather engine, any output size: layer 12 (the
+ * 128 x 128 stack's output layer) or 6 (the reference's: repo_decoder_out_nll is the specialised kernel for it).
+ * Same outputs as repo_decoder_out_nll without the mask. */
+size_t repo_conv_up_nll_workspace_bytes(int layer, int64_t nimg);
+int repo_conv_up_nll(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
+                     const void* target, int target_is_u8, float grad_scale, float* recon, float* dpre,
+                     float* loss_sum, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* out[c] (+)= sum over n and p of x[n][c][p]   (bias gradient of an NCHW activation) */
 size_t repo_channel_sum_workspace_bytes(int64_t nimg, int64_t C, int64_t P);

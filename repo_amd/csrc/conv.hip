@@ -40,6 +40,18 @@ using GDec3 = Geo<32, 64, 30, 6>;
 using GDec4 = Geo<3, 32, 64, 6>;
 static_assert(GEnc1::HS == 31 && GEnc2::HS == 14 && GEnc3::HS == 6 && GEnc4::HS == 2, "encoder geometry");
 static_assert(GDec2::HS == 5 && GDec3::HS == 13 && GDec4::HS == 30, "decoder geometry");
+// The 128 x 128 stack (BASELINE config 4's frame size; build-defined: the reference's encoder hard-codes the 64 x 64
+// flatten, encoder.py:39).  Same kernel sizes and strides, one more decoder layer (layers 7..12 of the ABI):
+//   encoder  3x128x128 -> 32x63x63 -> 64x30x30 -> 128x14x14 -> 256x6x6 (k4), then a build-defined fc 9216 -> 1024
+//   decoder  ... -> 32x30x30 (layers 4, 5 as at 64 x 64) -> 16x64x64 (k6) -> 3x128x128 (k2)
+using GX1 = Geo<3, 32, 128, 4>;
+using GX2 = Geo<32, 64, 63, 4>;
+using GX3 = Geo<64, 128, 30, 4>;
+using GX4 = Geo<128, 256, 14, 4>;
+using GY4 = Geo<16, 32, 64, 6>;
+using GY5 = Geo<3, 16, 128, 2>;
+static_assert(GX1::HS == 63 && GX2::HS == 30 && GX3::HS == 14 && GX4::HS == 6 && GY4::HS == 30 && GY5::HS == 64,
+              "128 x 128 geometry");
 
 __device__ __forceinline__ float epi_apply(float v, int epi, const float* bias, int ch, const float* aux, int o) {
   if (bias) v += bias[ch];
@@ -365,6 +377,13 @@ template <> struct DTileFor<GDec3> { using Down = REPO_DT_DEC3; using Wgrad = RE
 #define REPO_DT_DEC4 DTile<32, 256, 3, 1, 8>
 #endif
 template <> struct DTileFor<GDec4> { using Down = REPO_DT_DEC4; using Wgrad = REPO_WT_DEC4; static constexpr int WGT = 1536; };
+// 128 x 128 stack: tiles by analogy with the 64 x 64 layer of the same role (not swept)
+template <> struct DTileFor<GX1> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = WTile<32, 64, 1, 2, 1, 4, 2>;  static constexpr int WGT = 3072; };
+template <> struct DTileFor<GX2> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 1, 3, 2>; static constexpr int WGT = 1536; };
+template <> struct DTileFor<GX3> { using Down = DTile<128, 128, 2, 2, 2>; using Wgrad = WTile<64, 128, 2, 2, 1, 7>;    static constexpr int WGT = 1024; };
+template <> struct DTileFor<GX4> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 2, 6>;    static constexpr int WGT = 1024; };
+template <> struct DTileFor<GY4> { using Down = DTile<32, 256, 2, 1, 4>;  using Wgrad = WTile<32, 128, 1, 4, 1, 2>;    static constexpr int WGT = 1536; };
+template <> struct DTileFor<GY5> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = WTile<32, 64, 1, 2, 1, 2>;     static constexpr int WGT = 1536; };
 
 // A handful of frames (the acting path encodes ONE per environment step): the throughput tiles leave 1-2
 // workgroups walking 16-64 dependent channel chunks (enc4: 147 us for one frame).  Latency tiles use 32
@@ -406,6 +425,10 @@ template <> struct UConf<GEnc2> { using type = SConf<GEnc2, 1, 8>; };
 template <> struct UConf<GDec2> { using type = SConf<GDec2, 5, 2>; };
 template <> struct UConf<GEnc3> { using type = SConf<GEnc3, 4, 2>; };
 template <> struct UConf<GEnc4> { using type = SConf<GEnc4, 8, 1>; };
+// 128 x 128 stack: the parity-class planes of a 16-channel group must fit LDS (<= 80 KB: two workgroups per CU), which
+// 30 x 30 and 14 x 14 outputs do; 63 x 63 / 64 x 64 / 128 x 128 outputs (262 KB) take the gather engine below
+template <> struct UConf<GX3> { using type = SConf<GX3, 1, 2>; };
+template <> struct UConf<GX4> { using type = SConf<GX4, 4, 1>; };
 
 template <class G>
 static size_t conv_up_ws_bytes() {
@@ -429,11 +452,13 @@ static int conv_up_t(int64_t nimg, const float* small, const float* w, const flo
   if constexpr (!std::is_void<UC>::value) {
     return launch_uconv_scatter<G, UC>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   } else {
-    // 3-channel outputs (encoder conv1 data-gradient, plain decoder conv4): the four output parity classes read
-    // the same (J x J) input taps, so they are merged on M (4 * 3 rows) in the gather engine of igemm.h
-    static_assert(G::CB < 8 && G::KS % 2 == 0, "only the 3-channel layers use the gather engine");
+    // 3-channel outputs (encoder conv1 data-gradient, plain decoder conv4) and, in the 128 x 128 stack, the outputs
+    // whose class planes do not fit LDS: the four output parity classes read the same (J x J) input taps, so they
+    // are merged on M (4 * CB rows) in the gather engine of igemm.h
+    static_assert(G::KS % 2 == 0, "the gather engine pairs horizontally adjacent output pixels");
     ConvUpMergedOp<G, float, 0> op{small, w, bias, aux, big, (int)nimg, epi, nullptr, nullptr, nullptr, 0.f, 0.f};
-    return launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
+    if constexpr (G::CB < 8) return launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
+    else return launch_igemm<T64x128>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, s);
   }
 }
 
@@ -498,6 +523,12 @@ using namespace repo;
     case 4: { using G = GDec2; CALL; }                 \
     case 5: { using G = GDec3; CALL; }                 \
     case 6: { using G = GDec4; CALL; }                 \
+    case 7: { using G = GX1; CALL; }                   \
+    case 8: { using G = GX2; CALL; }                   \
+    case 9: { using G = GX3; CALL; }                   \
+    case 10: { using G = GX4; CALL; }                  \
+    case 11: { using G = GY4; CALL; }                  \
+    case 12: { using G = GY5; CALL; }                  \
     default: return REPO_E_BADARG;                     \
   }
 
@@ -512,7 +543,10 @@ extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_
                    ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_MASK4) && aux_), REPO_E_BADARG);
   const float* aux = (const float*)aux_;  // fp32 activations, or the quad mask's bytes (REPO_EPI_MUL_MASK4)
   if (big_is_u8) {
-    REPO_REQUIRE(layer == 0, REPO_E_BADARG);
+    REPO_REQUIRE(layer == 0 || layer == 7, REPO_E_BADARG);
+    if (layer == 7)
+      return conv_down_t<GX1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, dbias_small,
+                                       accumulate_dbias, ws, ws_bytes, stream);
     return conv_down_t<GEnc1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, dbias_small,
                                        accumulate_dbias, ws, ws_bytes, stream);
   }
@@ -558,7 +592,10 @@ extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, cons
   REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
   REPO_REQUIRE(small && big && dw, REPO_E_BADARG);
   if (big_is_u8) {
-    REPO_REQUIRE(layer == 0, REPO_E_BADARG);
+    REPO_REQUIRE(layer == 0 || layer == 7, REPO_E_BADARG);
+    if (layer == 7)
+      return conv_wgrad_t<GX1, uint8_t>(nimg, small, (const uint8_t*)big, dw, dbias_small, accumulate, ws, ws_bytes,
+                                        stream);
     return conv_wgrad_t<GEnc1, uint8_t>(nimg, small, (const uint8_t*)big, dw, dbias_small, accumulate, ws, ws_bytes,
                                         stream);
   }
@@ -602,6 +639,57 @@ extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* 
                                       loss_sum, ws, stream);
   return decoder_out_nll_t<float>(nimg, h3, w, bias, (const float*)target, grad_scale, recon, dpre, relu_mask4, loss_sum,
                                   ws, stream);
+}
+
+// ---- a 3-channel transposed conv fused with the pixel likelihood on the gather engine (any output size): what the
+//      128 x 128 stack's output layer (layer 12) runs on; layer 6 goes through it too in the tests, as a second
+//      implementation of repo_decoder_out_nll.
+template <class G>
+static long up_nll_parts(int64_t nimg) {
+  constexpr int NY = (G::HB + 1) / 2, NX = (G::WB + 1) / 2;
+  return (nimg * (long)NY * NX + T32x256::BN - 1) / T32x256::BN;  // one workgroup row (M = 12 <= 32)
+}
+template <class G, class TgtT>
+static int conv_up_nll_t(int64_t nimg, const float* small, const float* w, const float* bias, const TgtT* target,
+                         float grad_scale, float* recon, float* dpre, float* loss_sum, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+  static_assert(G::CB < 8 && G::KS % 2 == 0, "output layers only");
+  if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
+  const long nparts = up_nll_parts<G>(nimg);
+  if (!ws || ws_bytes < (size_t)nparts * sizeof(float)) return REPO_E_WS_TOO_SMALL;
+  ConvUpMergedOp<G, TgtT, 1> op{small, w, bias, nullptr, recon, (int)nimg, REPO_EPI_NONE, target, dpre, (float*)ws,
+                                grad_scale, 0.f};
+  const int rc = launch_igemm<T32x256>(op, 4 * G::CB, nimg * (int64_t)op.NY * op.NX, 1, stream);
+  if (rc) return rc;
+  if (loss_sum) {
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)ws, (int)nparts, loss_sum, 0);
+    REPO_CHECK_LAUNCH();
+  }
+  return REPO_OK;
+}
+
+extern "C" size_t repo_conv_up_nll_workspace_bytes(int layer, int64_t nimg) {
+  if (nimg <= 0) return 0;
+  if (layer == 6) return (size_t)up_nll_parts<GDec4>(nimg) * sizeof(float);
+  if (layer == 12) return (size_t)up_nll_parts<GY5>(nimg) * sizeof(float);
+  return 0;
+}
+
+extern "C" int repo_conv_up_nll(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
+                                const void* target, int target_is_u8, float grad_scale, float* recon, float* dpre,
+                                float* loss_sum, void* ws, size_t ws_bytes, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
+  REPO_REQUIRE(small && w && target, REPO_E_BADARG);
+  REPO_REQUIRE(layer == 6 || layer == 12, REPO_E_BADARG);
+#define REPO_UPNLL(G)                                                                                                  \
+  return target_is_u8 ? conv_up_nll_t<G, uint8_t>(nimg, small, w, bias, (const uint8_t*)target, grad_scale, recon, dpre, \
+                                                  loss_sum, ws, ws_bytes, stream)                                         \
+                      : conv_up_nll_t<G, float>(nimg, small, w, bias, (const float*)target, grad_scale, recon, dpre,      \
+                                                loss_sum, ws, ws_bytes, stream)
+  if (layer == 6) { REPO_UPNLL(GDec4); }
+  REPO_UPNLL(GY5);
+#undef REPO_UPNLL
 }
 
 static inline int chansum_splits(int64_t nimg, int64_t C, int64_t P) {

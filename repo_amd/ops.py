@@ -11,8 +11,9 @@ from ._lib import check, lib
 
 EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU, EPI_MUL_MASK4 = 0, 1, 2, 3, 4, 5
 
-# layer ids of repo_conv_* (include/repo_hip.h)
+# layer ids of repo_conv_* (include/repo_hip.h): 0..6 the reference's 64 x 64 stack, 7..12 the build-defined 128 x 128 one
 ENC1, ENC2, ENC3, ENC4, DEC2, DEC3, DEC4 = range(7)
+X_ENC1, X_ENC2, X_ENC3, X_ENC4, X_DEC4, X_DEC5 = range(7, 13)
 # (CB, CS, HB, KS) per layer; HS = (HB-KS)//2+1
 CONV_GEO = {
     ENC1: (3, 32, 64, 4),
@@ -22,6 +23,12 @@ CONV_GEO = {
     DEC2: (64, 128, 13, 5),
     DEC3: (32, 64, 30, 6),
     DEC4: (3, 32, 64, 6),
+    X_ENC1: (3, 32, 128, 4),
+    X_ENC2: (32, 64, 63, 4),
+    X_ENC3: (64, 128, 30, 4),
+    X_ENC4: (128, 256, 14, 4),
+    X_DEC4: (16, 32, 64, 6),
+    X_DEC5: (3, 16, 128, 2),
 }
 
 
@@ -201,6 +208,28 @@ def decoder_out_nll(h3, w, bias, target, grad_scale, want_recon=False, want_dpre
         "repo_decoder_out_nll",
     )
     return (loss, dpre, recon, mask) if want_mask else (loss, dpre, recon)
+
+
+def conv_up_nll(layer, small, w, bias, target, grad_scale, want_recon=False, want_dpre=True):
+    """A 3-channel transposed conv (layer 6 or 12) fused with 0.5*(recon-target)^2 summed over everything, on the
+    gather engine (any output size).  Returns (loss_sum (1,), dpre or None, recon or None)."""
+    nimg = small.shape[0]
+    (cb, hb, _), (cs, hs, _) = conv_shapes(layer)
+    assert tuple(small.shape[1:]) == (cs, hs, hs) and small.is_contiguous(), small.shape
+    is_u8 = target.dtype == torch.uint8
+    assert target.is_contiguous() and target.numel() == nimg * cb * hb * hb
+    dev = small.device
+    recon = torch.empty(nimg, cb, hb, hb, dtype=torch.float32, device=dev) if want_recon else None
+    dpre = torch.empty(nimg, cb, hb, hb, dtype=torch.float32, device=dev) if want_dpre else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    nb = lib().repo_conv_up_nll_workspace_bytes(layer, nimg)
+    ws = workspace(nb, dev)
+    check(
+        lib().repo_conv_up_nll(layer, nimg, _ptr(_f32c(small)), _ptr(_f32c(w)), _ptr(bias), _ptr(target), int(is_u8),
+                               float(grad_scale), _ptr(recon), _ptr(dpre), _ptr(loss), _ptr(ws), ws.numel(), _stream()),
+        "repo_conv_up_nll",
+    )
+    return loss, dpre, recon
 
 
 def channel_sum(x, out=None, accumulate=False):

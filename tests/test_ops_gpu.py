@@ -104,9 +104,14 @@ def _layer_tensors(ops, layer, nimg, seed):
     return big, small, w, rs
 
 
-@pytest.mark.parametrize("layer", range(7))
+ALL_LAYERS = list(range(13))  # 0..6: the reference's 64 x 64 stack; 7..12: the build-defined 128 x 128 stack
+
+
+@pytest.mark.parametrize("layer", ALL_LAYERS)
 @pytest.mark.parametrize("nimg", [1, 5, 37])  # 37: pixel tiles that straddle several images / ragged last tile
 def test_conv_down(ops, layer, nimg):
+    if layer >= 7 and nimg == 37:
+        nimg = 11
     big, small, w, rs = _layer_tensors(ops, layer, nimg, 100 + layer)
     cs = small.shape[1]
     bias = rnd(rs, cs)
@@ -131,9 +136,11 @@ def test_conv_down_u8(ops):
     assert relerr(got, want) < TOL
 
 
-@pytest.mark.parametrize("layer", range(7))
+@pytest.mark.parametrize("layer", ALL_LAYERS)
 @pytest.mark.parametrize("nimg", [1, 5, 37])
 def test_conv_up(ops, layer, nimg):
+    if layer >= 7 and nimg == 37:
+        nimg = 11
     big, small, w, rs = _layer_tensors(ops, layer, nimg, 200 + layer)
     cb = big.shape[1]
     bias = rnd(rs, cb)
@@ -158,9 +165,11 @@ def test_conv_up(ops, layer, nimg):
     assert relerr(got, want) < TOL
 
 
-@pytest.mark.parametrize("layer", range(7))
+@pytest.mark.parametrize("layer", ALL_LAYERS)
 @pytest.mark.parametrize("nimg", [1, 9, 75])  # 75: several image groups per split, ragged last group and split
 def test_conv_wgrad(ops, layer, nimg):
+    if layer >= 7 and nimg == 75:
+        nimg = 21
     big, small, w, rs = _layer_tensors(ops, layer, nimg, 300 + layer)
     bigd = big.double().requires_grad_(False)
     wd = w.double().requires_grad_(True)
@@ -218,7 +227,7 @@ def test_decoder_out_nll(ops, u8, nimg):
     del sentinel
 
 
-@pytest.mark.parametrize("layer", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("layer", ALL_LAYERS)
 def test_conv_down_channel_sums(ops, layer):
     """repo_conv_down's dbias: the per-channel sum of the values it writes (the bias gradient of the transposed-conv
     layer below, taken in the epilogue) == a second pass over the output; throughput and latency tiles (<= 512
@@ -243,7 +252,7 @@ def test_conv_down_channel_sums(ops, layer):
         assert relerr(db2, out.double().sum((0, 2, 3))) < TOL
 
 
-@pytest.mark.parametrize("layer", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("layer", [1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12])
 def test_conv_down_quad_mask_any_geometry(ops, layer):
     """REPO_EPI_MUL_MASK4 on every geometry (pixel planes of 196, 36, 4, 25, 169 and 900 elements: quads that are
     unaligned in the mask's bytes and quads that run over an image's end) equals REPO_EPI_MUL_DRELU bit for bit."""
@@ -262,6 +271,29 @@ def test_conv_down_quad_mask_any_geometry(ops, layer):
         a = ops.conv_down(layer, big, w, None, epi=rops.EPI_MUL_DRELU, aux=dev(h))
         m = ops.conv_down(layer, big, w, None, epi=rops.EPI_MUL_MASK4, aux=mask)
         assert torch.equal(a, m), (layer, nimg)
+
+
+@pytest.mark.parametrize("layer,u8", [(6, True), (6, False), (12, True), (12, False)])
+def test_conv_up_nll(ops, layer, u8):
+    """The gather engine's fused output layer + pixel NLL (layer 12: the 128 x 128 stack's; layer 6: a second
+    implementation of repo_decoder_out_nll) vs fp64 torch, and at layer 6 vs the specialised kernel."""
+    import repo_amd.ops as rops
+    rs = np.random.RandomState(60 + layer)
+    (cb, hb, _), (cs, hs, _) = rops.conv_shapes(layer)
+    ks = rops.CONV_GEO[layer][3]
+    nimg = 5
+    h = F.relu(rnd(rs, nimg, cs, hs, hs))
+    w, b = rnd(rs, cs, cb, ks, ks, scale=0.05), rnd(rs, cb)
+    obs = torch.from_numpy(rs.randint(0, 256, size=(nimg, cb, hb, hb)).astype(np.uint8))
+    tgt = torch.from_numpy(((obs.numpy().astype(np.float32) / 255) * 2) - 1.0)
+    recon = F.conv_transpose2d(h.double(), w.double(), b.double(), stride=2)
+    d = recon - tgt.double()
+    loss, dpre, rec = ops.conv_up_nll(layer, dev(h), dev(w), dev(b), dev(obs if u8 else tgt), 0.25, want_recon=True)
+    want_loss = (0.5 * d * d).sum().item()
+    assert relerr(rec, recon) < TOL and relerr(dpre, d * 0.25) < TOL and abs(loss.item() - want_loss) / want_loss < 1e-5
+    if layer == 6:
+        loss2, dpre2, rec2 = ops.decoder_out_nll(dev(h), dev(w), dev(b), dev(obs if u8 else tgt), 0.25, want_recon=True)
+        assert relerr(rec2, rec.double()) < TOL and relerr(dpre2, dpre.double()) < TOL
 
 
 def test_channel_sum_relu_mask(ops):
