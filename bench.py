@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: RePo world-model + imagination updates per second.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|c4x128]
 
 Workload (default `--config c2` = BASELINE.json configs[1]): algo=repo, B=50
 sequences per GPU, L=50, H=15, A=6, 64x64x3 uint8 frames, parameters at torch default init under
@@ -50,13 +50,26 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 L, H = 50, 15
-# per-config: (algo, B, A, label); FLOPs scale with rows (SURVEY.md 8d scaling law)
+# per-config: (algo, B, A, label, frame size); FLOPs scale with rows (SURVEY.md 8d scaling law)
 CONFIGS = {
-    "c2": ("repo", 50, 6, "dmc_distracted-walker-walk shapes (BASELINE configs[1])"),
-    "c4": ("repo", 32, 7, "maniskill-PushCubeMatterport shapes at the reference's 64x64 frames, A=7 (BASELINE configs[3] pin)"),
-    "c5": ("dreamer", 50, 6, "algo=dreamer on dmc_distracted-walker-walk shapes (BASELINE configs[4])"),
+    "c2": ("repo", 50, 6, "dmc_distracted-walker-walk shapes (BASELINE configs[1])", 64),
+    "c4": ("repo", 32, 7, "maniskill-PushCubeMatterport shapes at the reference's 64x64 frames, A=7 (BASELINE configs[3] pin)", 64),
+    "c5": ("dreamer", 50, 6, "algo=dreamer on dmc_distracted-walker-walk shapes (BASELINE configs[4])", 64),
+    # BASELINE configs[3] at its own 128x128 frames: the reference cannot run it (its encoder flatten and decoder are
+    # 64x64 only), the conv stack is build-defined and its parity is pinned by the oracle only
+    "c4x128": ("repo", 32, 7, "maniskill-PushCubeMatterport shapes at 128x128 frames through the BUILD-DEFINED 128x128 "
+               "conv stack (no reference model exists for it), A=7", 128),
 }
 FLOP_PER_UPDATE_B50 = 740.4e9  # SURVEY.md 8d, autograd-counted on the reference at B=50 L=50 H=15 A=6
+# 128x128 stack: extra conv/fc FLOPs per decoded/encoded frame over the 64x64 stack, forward + data gradient + weight
+# gradient (2*Cout*Hout^2*Cin*k^2 per layer; encoder 29.4 -> 179.2 MFLOP incl. the 9216x1024 fc, decoder 48.4 -> 77.0
+# MFLOP forward; the first encoder layer has no data gradient)
+EXTRA_FLOP_PER_FRAME_128 = 3 * (179.2e6 - 29.4e6 + 77.0e6 - 48.4e6) - (12.19e6 - 2.95e6)
+
+
+def flop_per_update(B, image=64):
+    """Algorithmic FLOPs of one update of B sequences (L=50, H=15)."""
+    return FLOP_PER_UPDATE_B50 * B / 50.0 + (EXTRA_FLOP_PER_FRAME_128 * (L - 1) * B if image == 128 else 0.0)
 RING_FRAMES = 6000             # synthetic replay ring per rank (72 MB of frames; 120 windows of 50)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")
 
@@ -67,8 +80,8 @@ class Space:
 
 
 class Env:
-    def __init__(self, A=6):
-        self.observation_space = Space((3, 64, 64))
+    def __init__(self, A=6, image=64):
+        self.observation_space = Space((3, image, image))
         self.action_space = Space((A,))
 
 
@@ -96,20 +109,20 @@ def config(algo="repo", B=50):
     )
 
 
-def synthetic_batch(seed=1234, B=50, A=6):
+def synthetic_batch(seed=1234, B=50, A=6, image=64):
     rs = np.random.RandomState(seed)
-    obs = rs.randint(0, 256, (L, B, 3, 64, 64)).astype(np.uint8)
+    obs = rs.randint(0, 256, (L, B, 3, image, image)).astype(np.uint8)
     actions = rs.uniform(-1, 1, (L, B, A)).astype(np.float32)
     rewards = rs.uniform(0, 1, (L, B, 1)).astype(np.float32)
     dones = (rs.uniform(size=(L, B, 1)) < 1 / 500).astype(np.float32)
     return obs, actions, rewards, dones
 
 
-def synthetic_ring(buffer_cls, seed, A, device):
+def synthetic_ring(buffer_cls, seed, A, device, image=64):
     """A full replay ring of RING_FRAMES synthetic transitions (same distributions as synthetic_batch:
     uniform u8 frames, uniform actions / rewards, episode ends with probability 1/500), mirrored in HBM."""
     rs = np.random.RandomState(seed)
-    ring = buffer_cls(RING_FRAMES, (3, 64, 64), (A,), obs_type=np.uint8)
+    ring = buffer_cls(RING_FRAMES, (3, image, image), (A,), obs_type=np.uint8)
     ring.observations[:] = rs.randint(0, 256, size=ring.observations.shape, dtype=np.uint8)
     ring.actions[:] = rs.uniform(-1, 1, ring.actions.shape)
     ring.rewards[:] = rs.uniform(0, 1, ring.rewards.shape)
@@ -269,7 +282,7 @@ def roofline(timer, nimg):
     return out
 
 
-def _cpu_baseline_worker(q, threads, warm, timed, B, A, algo):
+def _cpu_baseline_worker(q, threads, warm, timed, B, A, algo, image=64):
     """Child process: the CPU oracle on the full synthetic batch."""
     import time as _t
 
@@ -279,9 +292,9 @@ def _cpu_baseline_worker(q, threads, warm, timed, B, A, algo):
     from oracle import fixtures as fx
     from oracle.repo_oracle import OracleAgent
 
-    batch = synthetic_batch(1234, B, A)
+    batch = synthetic_batch(1234, B, A, image)
     cfg = fx.default_config(algo=algo, batch_size=B, chunk_size=L, horizon=H)
-    agent = OracleAgent(cfg, A, seed=7)
+    agent = OracleAgent(cfg, A, seed=7, image=image)
     noise = fx.make_noise(L, B, H, A, seed=1)
     for _ in range(warm):
         agent.update(*batch, noise)  # thread pools, oneDNN primitive caches
@@ -291,7 +304,7 @@ def _cpu_baseline_worker(q, threads, warm, timed, B, A, algo):
     q.put((_t.perf_counter() - t0) / timed)
 
 
-def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0, B=50, A=6, algo="repo"):
+def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0, B=50, A=6, algo="repo", image=64):
     """the CPU oracle (PyTorch fp32 restatement of the reference update, validated against the
     reference's goldens) on the SAME full workload -- B=50, L=50, H=15 -- 2 warm-up + 3 timed updates on
     this box's host cores, in a child process that is killed after `timeout_s` (any --config: its B, A, algo)."""
@@ -301,7 +314,7 @@ def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0, B=50, A=6, algo
     threads = threads or max(1, min(avail, 32))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_cpu_baseline_worker, args=(q, threads, warm, timed, B, A, algo))
+    p = ctx.Process(target=_cpu_baseline_worker, args=(q, threads, warm, timed, B, A, algo, image))
     p.start()
     p.join(timeout_s)
     base = {"value": None, "unit": "updates/s", "cores": threads, "kind": "port"}
@@ -315,7 +328,7 @@ def cpu_baseline(threads=None, warm=2, timed=3, timeout_s=240.0, B=50, A=6, algo
         return {**base, "sample": f"oracle child exited with code {p.exitcode} before reporting"}
     return {
         **base, "value": round(1.0 / dt, 5),
-        "sample": f"{timed} timed updates after {warm} warm-up on the full batch (algo={algo}, B={B}, L={L}, H={H}, A={A}), "
+        "sample": f"{timed} timed updates after {warm} warm-up on the full batch (algo={algo}, B={B}, L={L}, H={H}, A={A}, {image}x{image} frames), "
                   f"{dt:.2f} s per update; PyTorch {torch.__version__} CPU, {threads} threads of {avail} available cores",
     }
 
@@ -387,7 +400,7 @@ def main():
     from repo_amd.common.buffers import SequenceReplayBuffer
     from repo_amd.common.utils import set_gpu_mode
 
-    algo, B, A, label = CONFIGS[args.config]
+    algo, B, A, label, image = CONFIGS[args.config]
     algo = args.algo or algo
     if args.batch:
         B, label = args.batch, label + f" with the batch overridden to {args.batch} (--batch)"
@@ -409,17 +422,17 @@ def main():
 
     torch.manual_seed(0)
     cfg = config(algo, B)
-    agent = (RePo if algo == "repo" else Dreamer)(cfg, Env(A), Env(A), NullLogger())
+    agent = (RePo if algo == "repo" else Dreamer)(cfg, Env(A, image), Env(A, image), NullLogger())
     if dp is not None:
         dp.attach(agent)
     if args.strong:
         from repo_amd.parallel import shard_rows
 
         lo, hi = shard_rows(B, world, rank)
-        host = tuple(np.ascontiguousarray(x[:, lo:hi]) for x in synthetic_batch(1234, B, A))
+        host = tuple(np.ascontiguousarray(x[:, lo:hi]) for x in synthetic_batch(1234, B, A, image))
         cfg.batch_size = hi - lo
     else:
-        host = synthetic_batch(1234 + rank, B, A)  # each rank holds its own B-sequence shard of the global batch
+        host = synthetic_batch(1234 + rank, B, A, image)  # each rank holds its own B-sequence shard of the global batch
     resident = tuple(torch.from_numpy(x).to(dev) for x in host)
     Bl = cfg.batch_size
 
@@ -431,7 +444,7 @@ def main():
         agent.synchronize()
 
     np.random.seed(4321 + rank)  # the sampler's RNG (np.random.choice, like the reference)
-    agent.buffer = synthetic_ring(SequenceReplayBuffer, 1234 + rank, A, dev)
+    agent.buffer = synthetic_ring(SequenceReplayBuffer, 1234 + rank, A, dev, image)
 
     def run_from_ring(k):
         # train_agent()'s loop body K times: fresh indices on the host, device gather, pipelined update
@@ -503,7 +516,7 @@ def main():
             dt_s = timed(run_from_ring, args.steps)
             strong = {"value": round(args.steps / dt_s, 3), "unit": "updates/s", "ms_per_step": round(dt_s / args.steps * 1e3, 3),
                       "global_batch": B, "shards": [b - a for a, b in (shard_rows(B, world, r) for r in range(world))],
-                      "algorithmic_tflops": round(FLOP_PER_UPDATE_B50 * B / 50.0 * args.steps / dt_s / 1e12, 2)}
+                      "algorithmic_tflops": round(flop_per_update(B, image) * args.steps / dt_s / 1e12, 2)}
             Bl = cfg.batch_size = Bl_weak
             dp.reset_counts()
         else:
@@ -515,10 +528,10 @@ def main():
         value = (1 if args.strong else nranks) * args.steps / dt
         # FLOPs of one update of the GLOBAL batch this line's `value` counts: B sequences (--strong: one global
         # batch sharded over the ranks) or B per rank (weak)
-        flop = FLOP_PER_UPDATE_B50 * B / 50.0
+        flop = flop_per_update(B, image)
         line = {
-            "metric": "world-model+imagine updates/sec (B=50,L=50,64x64x3)" if args.config != "c4" else
-                      "world-model+imagine updates/sec (B=32,L=50,64x64x3,A=7)",
+            "metric": "world-model+imagine updates/sec (B=50,L=50,64x64x3)" if not args.config.startswith("c4") else
+                      f"world-model+imagine updates/sec (B=32,L=50,{image}x{image}x3,A=7)",
             "value": round(value, 3),
             "unit": "updates/s",
             "n_gpus": nranks,
@@ -531,7 +544,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: algo={algo} {label}: B={B}/GPU L={L} H={H} A={A} 64x64x3 uint8; one step = "
+                "workload": f"{args.config}: algo={algo} {label}: B={B}/GPU L={L} H={H} A={A} {image}x{image}x3 uint8; one step = "
                             "sample a fresh batch from the HBM-mirrored replay ring + train_dynamics + "
                             "train_actor_critic incl. 4 optimiser steps" + (" (resident batch: --strong)" if args.strong else ""),
                 "global_batch": B if args.strong else B * nranks, "per_gpu_batch": Bl,
@@ -550,7 +563,7 @@ def main():
         if ar is not None:
             line["allreduce_ms"] = ar.summary(args.steps)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B=B, A=A, algo=algo)
+            line["cpu_baseline"] = cpu_baseline(B=B, A=A, algo=algo, image=image)
         print(json.dumps(line), flush=True)
     if dp is not None:
         dp.barrier()

@@ -81,14 +81,21 @@ def default_config(**over):
     return SimpleNamespace(**c)
 
 
-def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024):
-    """Ordered {module: OrderedDict(name -> shape)} in state_dict order."""
+def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, image=64):
+    """Ordered {module: OrderedDict(name -> shape)} in state_dict order.
+    image=128: the BUILD-DEFINED 128 x 128 stack (no reference model exists at that size: the reference's encoder
+    hard-codes the 64 x 64 flatten, encoder.py:39): the same four encoder convs (-> 256x6x6) + fc 9216 -> embed; the
+    decoder's conv4 becomes 32 -> 16 (k6, 30 -> 64) and a conv5 16 -> 3 (k2, 64 -> 128) follows."""
     A = action_size
     feat = belief + state
+    assert image in (64, 128), image
     enc = OrderedDict()
     for i, (co, ci) in enumerate([(32, 3), (64, 32), (128, 64), (256, 128)], 1):
         enc[f"conv{i}.weight"] = (co, ci, 4, 4)
         enc[f"conv{i}.bias"] = (co,)
+    if image == 128:
+        enc["fc.weight"] = (embed, 256 * 6 * 6)
+        enc["fc.bias"] = (embed,)
     rssm = OrderedDict(
         [
             ("fc_embed_state_action.weight", (belief, state + A)),
@@ -121,6 +128,9 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024):
             ("conv4.bias", (3,)),
         ]
     )
+    if image == 128:
+        dec["conv4.weight"], dec["conv4.bias"] = (32, 16, 6, 6), (16,)
+        dec["conv5.weight"], dec["conv5.bias"] = (16, 3, 2, 2), (3,)
 
     def mlp(n_hidden_layers, out):
         d = OrderedDict()
@@ -145,7 +155,7 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024):
     )
 
 
-def make_params(action_size, seed=7):
+def make_params(action_size, seed=7, image=64):
     """{module: OrderedDict(name -> float32 ndarray)}; uniform(-k, k), k = fan_in**-0.5.
 
     One RandomState drawn sequentially in (module, state_dict) order; a bias uses
@@ -153,7 +163,7 @@ def make_params(action_size, seed=7):
     """
     rs = np.random.RandomState(seed)
     out = OrderedDict()
-    for mod, shapes in param_shapes(action_size).items():
+    for mod, shapes in param_shapes(action_size, image=image).items():
         d = OrderedDict()
         k = 1.0
         for name, shp in shapes.items():
@@ -164,11 +174,11 @@ def make_params(action_size, seed=7):
     return out
 
 
-def make_batch(L, B, action_size, seed=11, planted_dones=((3, 1), (5, 2)), p_done=0.0):
+def make_batch(L, B, action_size, seed=11, planted_dones=((3, 1), (5, 2)), p_done=0.0, image=64):
     """Synthetic replay batch, time-major like SequenceReplayBuffer.sample
     (/root/reference/common/buffers.py:156-166)."""
     rs = np.random.RandomState(seed)
-    obs = rs.randint(0, 256, size=(L, B, 3, 64, 64)).astype(np.uint8)
+    obs = rs.randint(0, 256, size=(L, B, 3, image, image)).astype(np.uint8)
     actions = rs.uniform(-1, 1, size=(L, B, action_size)).astype(np.float32)
     rewards = rs.uniform(0, 1, size=(L, B, 1)).astype(np.float32)
     dones = (rs.uniform(size=(L, B, 1)) < p_done).astype(np.float32)

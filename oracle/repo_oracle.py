@@ -43,11 +43,16 @@ ATANH_CLAMP = 0.99999997  # literal of models/utils.py:128 (rounds to 0.99999994
 
 # --------------------------------------------------------------------------- modules
 def encoder_fwd(p, obs):
-    """obs (rows,3,64,64) f32 -> (rows,1024).  encoder.py:34-41 (fc is Identity)."""
+    """obs (rows,3,64,64) f32 -> (rows,1024).  encoder.py:34-41 (fc is Identity at embedding_size 1024).
+    128 x 128 frames (build-defined stack, fixtures.param_shapes(image=128)): the flatten is 9216 wide and
+    `fc` = Linear(9216, 1024), applied without an activation like the reference's optional fc (encoder.py:40)."""
     h = obs
     for i in range(1, 5):
         h = F.relu(F.conv2d(h, p[f"conv{i}.weight"], p[f"conv{i}.bias"], stride=2))
-    return h.reshape(-1, 1024)
+    h = h.reshape(h.shape[0], -1)
+    if "fc.weight" in p:
+        h = F.linear(h, p["fc.weight"], p["fc.bias"])
+    return h
 
 
 def gru_cell(p, x, h):
@@ -101,6 +106,9 @@ def decoder_fwd(p, belief, state):
     h = F.relu(F.conv_transpose2d(h, p["conv1.weight"], p["conv1.bias"], stride=2))
     h = F.relu(F.conv_transpose2d(h, p["conv2.weight"], p["conv2.bias"], stride=2))
     h = F.relu(F.conv_transpose2d(h, p["conv3.weight"], p["conv3.bias"], stride=2))
+    if "conv5.weight" in p:  # build-defined 128 x 128 stack: one more ReLU layer, then the output layer
+        h = F.relu(F.conv_transpose2d(h, p["conv4.weight"], p["conv4.bias"], stride=2))
+        return F.conv_transpose2d(h, p["conv5.weight"], p["conv5.bias"], stride=2)
     return F.conv_transpose2d(h, p["conv4.weight"], p["conv4.bias"], stride=2)
 
 
@@ -222,10 +230,10 @@ def clip_grad_norm(params, max_norm):
 class OracleAgent:
     """Holds parameters + optimiser state and runs reference-faithful updates on CPU."""
 
-    def __init__(self, cfg, action_size, params=None, seed=7):
+    def __init__(self, cfg, action_size, params=None, seed=7, image=64):
         self.c = cfg
         self.A = action_size
-        np_params = params if params is not None else fx.make_params(action_size, seed)
+        np_params = params if params is not None else fx.make_params(action_size, seed, image=image)
         self.p = OrderedDict()
         for mod in fx.MODULES:
             self.p[mod] = OrderedDict(
@@ -248,7 +256,7 @@ class OracleAgent:
         c, p = self.c, self.p
         L, B = obs.shape[:2]
         T = L - 1
-        embeds = encoder_fwd(p["encoder"], obs.reshape(L * B, 3, 64, 64)).reshape(L, B, -1)
+        embeds = encoder_fwd(p["encoder"], obs.reshape(L * B, *obs.shape[2:])).reshape(L, B, -1)
         b0 = torch.zeros(B, c.belief_size)
         s0 = torch.zeros(B, c.state_size)
         beliefs, prior_s, pm, ps, post_s, qm, qs = observe(
@@ -259,7 +267,7 @@ class OracleAgent:
             recon = decoder_fwd(p["obs_model"], fb.detach(), fs.detach())
         else:
             recon = decoder_fwd(p["obs_model"], fb, fs)
-        recon = recon.reshape(T, B, 3, 64, 64)
+        recon = recon.reshape(T, B, *obs.shape[2:])
         obs_loss = (0.5 * (recon - obs[1:]) ** 2 + 0.5 * LOG_2PI).sum((2, 3, 4)).mean((0, 1))
 
         r_pred = scalar_head(p["reward_model"], fb, fs).reshape(T, B)

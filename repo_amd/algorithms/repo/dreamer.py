@@ -124,6 +124,7 @@ class Dreamer:
         obs_size = env.observation_space.shape
         action_size = int(np.prod(env.action_space.shape))
         self.action_size = action_size
+        self._npix = int(np.prod(obs_size))  # 3*64*64 (the reference's frames) or 3*128*128 (build-defined)
         dev = self.device
         # same construction order as the reference (dreamer.py:57-114) => same default init under a seed
         self.encoder = Encoder(False, obs_size, config.embedding_size, config.cnn_activation_function).to(dev)
@@ -473,7 +474,7 @@ class Dreamer:
         c = self.c
         h = self._log_host[:n].tolist()
         nll, rsq, rmask, kl, ret, ent, lat, vsq, _vn, gm, ga_, gv_ = h[:12]
-        npix = 3 * 64 * 64
+        npix = self._npix
         out = {}
         out["train/obs_loss"] = nll / grow + 0.5 * LOG_2PI * npix
         out["train/reward_loss"] = (rsq + 0.5 * LOG_2PI * rmask) / grow

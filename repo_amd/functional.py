@@ -10,14 +10,23 @@ from . import ops
 
 
 # ----------------------------------------------------------------------------- encoder
+# layer ids per frame size: the reference's 64 x 64 stack, and the build-defined 128 x 128 one (BASELINE config 4's
+# size; same kernel sizes, 256x6x6 flatten + a linear `fc` 9216 -> 1024: p then has ten tensors)
+_ENC = {64: (ops.ENC1, ops.ENC2, ops.ENC3, ops.ENC4), 128: (ops.X_ENC1, ops.X_ENC2, ops.X_ENC3, ops.X_ENC4)}
+
+
 def encoder_fwd(p, obs):
-    """VisualEncoder.forward (models/encoder.py:34-41).  obs (n,3,64,64) uint8 or float32.
-    p = [conv1.w, conv1.b, ..., conv4.w, conv4.b].  Returns (embeds (n,1024), saved)."""
-    h1 = ops.conv_down(ops.ENC1, obs, p[0], p[1], epi=ops.EPI_RELU)
-    h2 = ops.conv_down(ops.ENC2, h1, p[2], p[3], epi=ops.EPI_RELU)
-    h3 = ops.conv_down(ops.ENC3, h2, p[4], p[5], epi=ops.EPI_RELU)
-    h4 = ops.conv_down(ops.ENC4, h3, p[6], p[7], epi=ops.EPI_RELU)
-    return h4.view(-1, 1024), (h1, h2, h3, h4)
+    """VisualEncoder.forward (models/encoder.py:34-41).  obs (n,3,64,64) [or (n,3,128,128)] uint8 or float32.
+    p = [conv1.w, conv1.b, ..., conv4.w, conv4.b (, fc.w, fc.b)].  Returns (embeds (n,1024), saved)."""
+    L = _ENC[obs.shape[-1]]
+    h1 = ops.conv_down(L[0], obs, p[0], p[1], epi=ops.EPI_RELU)
+    h2 = ops.conv_down(L[1], h1, p[2], p[3], epi=ops.EPI_RELU)
+    h3 = ops.conv_down(L[2], h2, p[4], p[5], epi=ops.EPI_RELU)
+    h4 = ops.conv_down(L[3], h3, p[6], p[7], epi=ops.EPI_RELU)
+    flat = h4.view(h4.shape[0], -1)
+    if len(p) > 8:
+        return ops.gemm(flat, p[8], transb=True, bias=p[9]), (h1, h2, h3, h4)
+    return flat, (h1, h2, h3, h4)
 
 
 class _Fork:
@@ -52,17 +61,24 @@ def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False, side=None):
     """Gradients of all eight encoder tensors into g (same order as p)."""
     h1, h2, h3, h4 = saved
     n = h4.shape[0]
+    L = _ENC[obs.shape[-1]]
     fk = _Fork(side)
-    d4 = ops.relu_mask(dembeds.reshape(n, 256, 2, 2).contiguous(), h4)
-    fk.run(lambda: ops.conv_wgrad(ops.ENC4, d4, h3, dw=g[6], db=g[7], accumulate=accumulate))
+    if len(p) > 8:  # the 128 x 128 stack's fc: d flatten = d embeds @ W, dW = d embeds^T @ flatten
+        flat = h4.view(n, -1)
+        dflat = ops.gemm(dembeds, p[8])
+        fk.run(lambda: ops.gemm_wgrad(dembeds, flat, dW=g[8], db=g[9], accumulate=accumulate))
+        d4 = ops.relu_mask(dflat.view(h4.shape), h4)
+    else:
+        d4 = ops.relu_mask(dembeds.reshape(h4.shape).contiguous(), h4)
+    fk.run(lambda: ops.conv_wgrad(L[3], d4, h3, dw=g[6], db=g[7], accumulate=accumulate))
     # the three weight packs first (independent of the gradients): their launches do not sit between the convs
-    pk4, pk3, pk2 = ops.conv_up_pack(ops.ENC4, p[6]), ops.conv_up_pack(ops.ENC3, p[4]), ops.conv_up_pack(ops.ENC2, p[2])
-    d3 = ops.conv_up(ops.ENC4, d4, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h3, pack=pk4)
-    fk.run(lambda: ops.conv_wgrad(ops.ENC3, d3, h2, dw=g[4], db=g[5], accumulate=accumulate))
-    d2 = ops.conv_up(ops.ENC3, d3, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h2, pack=pk3)
-    fk.run(lambda: ops.conv_wgrad(ops.ENC2, d2, h1, dw=g[2], db=g[3], accumulate=accumulate))
-    d1 = ops.conv_up(ops.ENC2, d2, p[2], None, epi=ops.EPI_MUL_DRELU, aux=h1, pack=pk2)
-    ops.conv_wgrad(ops.ENC1, d1, obs, dw=g[0], db=g[1], accumulate=accumulate)
+    pk4, pk3, pk2 = ops.conv_up_pack(L[3], p[6]), ops.conv_up_pack(L[2], p[4]), ops.conv_up_pack(L[1], p[2])
+    d3 = ops.conv_up(L[3], d4, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h3, pack=pk4)
+    fk.run(lambda: ops.conv_wgrad(L[2], d3, h2, dw=g[4], db=g[5], accumulate=accumulate))
+    d2 = ops.conv_up(L[2], d3, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h2, pack=pk3)
+    fk.run(lambda: ops.conv_wgrad(L[1], d2, h1, dw=g[2], db=g[3], accumulate=accumulate))
+    d1 = ops.conv_up(L[1], d2, p[2], None, epi=ops.EPI_MUL_DRELU, aux=h1, pack=pk2)
+    ops.conv_wgrad(L[0], d1, obs, dw=g[0], db=g[1], accumulate=accumulate)
     fk.join()
 
 
@@ -81,8 +97,13 @@ def decoder_trunk_fwd(p, feat):
 
 
 def decoder_fwd(p, feat):
-    """VisualObservationModel.forward -> (recon (rows,3,64,64), saved)."""
+    """VisualObservationModel.forward -> (recon (rows,3,64,64), saved).  Twelve tensors in p = the 128 x 128 stack
+    (conv4 32 -> 16 with ReLU, conv5 16 -> 3): recon (rows,3,128,128), saved gains h4."""
     h0, h1, h2, h3 = decoder_trunk_fwd(p, feat)
+    if len(p) > 10:
+        h4 = ops.conv_up(ops.X_DEC4, h3, p[8], p[9], epi=ops.EPI_RELU)
+        recon = ops.conv_up(ops.X_DEC5, h4, p[10], p[11], epi=ops.EPI_NONE)
+        return recon, (h0, h1, h2, h3, h4)
     recon = ops.conv_up(ops.DEC4, h3, p[8], p[9], epi=ops.EPI_NONE)
     return recon, (h0, h1, h2, h3)
 
@@ -91,6 +112,10 @@ def decoder_fwd_nll(p, feat, target, grad_scale):
     """Decoder forward fused with the unit-variance pixel NLL (repo.py:46-53).
     Returns (sum 0.5*(recon-target)^2 (1,), saved incl. d loss/d recon * grad_scale)."""
     h0, h1, h2, h3 = decoder_trunk_fwd(p, feat)
+    if len(p) > 10:  # 128 x 128 stack: the output layer + NLL on the gather engine (ops.conv_up_nll)
+        h4 = ops.conv_up(ops.X_DEC4, h3, p[8], p[9], epi=ops.EPI_RELU)
+        loss_sum, dpre5, _ = ops.conv_up_nll(ops.X_DEC5, h4, p[10], p[11], target, grad_scale)
+        return loss_sum, (h0, h1, h2, h3, h4, dpre5)
     loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(h3, p[8], p[9], target, grad_scale, want_mask=True)
     return loss_sum, (h0, h1, h2, h3, dpre4, mask3)
 
@@ -101,10 +126,12 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
     deferred: a list that receives the weight-gradient launches as closures instead of running them, so
     the caller can issue them beside a later latency-bound kernel (they depend only on tensors kept
     alive by the closures)."""
-    h0, h1, h2, h3, d4 = saved[:5]
-    mask3 = saved[5] if len(saved) > 5 else None  # quad mask of h3 from the fused output layer (8.8 MB for 282)
     rows = feat.shape[0]
     fk = _Fork(side, deferred)
+    if len(p) > 10:
+        return _decoder_bwd_128(p, feat, saved, g, dfeat, accumulate_dfeat, accumulate, fk)
+    h0, h1, h2, h3, d4 = saved[:5]
+    mask3 = saved[5] if len(saved) > 5 else None  # quad mask of h3 from the fused output layer (8.8 MB for 282)
 
     def w4():
         ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
@@ -126,6 +153,38 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
         ops.channel_sum(d3, out=g[7], accumulate=accumulate)
 
     fk.run(w3)
+    _decoder_bwd_tail(p, feat, h0, h1, h2, d3, g, dfeat, accumulate_dfeat, accumulate, fk)
+
+
+def _decoder_bwd_128(p, feat, saved, g, dfeat, accumulate_dfeat, accumulate, fk):
+    """The 128 x 128 stack's two extra layers (conv5 16 -> 3, k2; conv4 32 -> 16, k6), then the shared tail."""
+    h0, h1, h2, h3, h4, d5 = saved
+
+    def w5():
+        ops.conv_wgrad(ops.X_DEC5, h4, d5, dw=g[10], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d5, out=g[11], accumulate=accumulate)
+
+    fk.run(w5)
+    d4 = ops.conv_down(ops.X_DEC5, d5, p[10], None, epi=ops.EPI_MUL_DRELU, aux=h4)
+
+    def w4():
+        ops.conv_wgrad(ops.X_DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+
+    fk.run(w4)
+    d3 = ops.conv_down(ops.X_DEC4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
+
+    def w3():
+        ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d3, out=g[7], accumulate=accumulate)
+
+    fk.run(w3)
+    _decoder_bwd_tail(p, feat, h0, h1, h2, d3, g, dfeat, accumulate_dfeat, accumulate, fk)
+
+
+def _decoder_bwd_tail(p, feat, h0, h1, h2, d3, g, dfeat, accumulate_dfeat, accumulate, fk):
+    """From d h3's pre-activation gradient down to fc1 (the same layers at both frame sizes)."""
+    rows = feat.shape[0]
     d2 = ops.conv_down(ops.DEC3, d3, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h2)
 
     def w2():

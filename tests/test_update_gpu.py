@@ -36,8 +36,8 @@ class Space:
 
 
 class Env:
-    def __init__(self, A):
-        self.observation_space = Space((3, 64, 64))
+    def __init__(self, A, image=64):
+        self.observation_space = Space((3, image, image))
         self.action_space = Space((A,))
 
 
@@ -54,22 +54,22 @@ class Logger:
         pass
 
 
-def make_agent(algo, L, B, H, A, seed=7):
+def make_agent(algo, L, B, H, A, seed=7, image=64):
     from repo_amd.algorithms.repo import Dreamer, RePo
     from repo_amd.common.utils import set_gpu_mode
 
     set_gpu_mode(True)
     cfg = fx.default_config(algo=algo, batch_size=B, chunk_size=L, horizon=H)
-    agent = (RePo if algo == "repo" else Dreamer)(cfg, Env(A), Env(A), Logger())
-    params = fx.make_params(A, seed)
+    agent = (RePo if algo == "repo" else Dreamer)(cfg, Env(A, image), Env(A, image), Logger())
+    params = fx.make_params(A, seed, image)
     for mod in fx.MODULES:
         sd = {k: torch.from_numpy(v) for k, v in params[mod].items()}
         agent._load_module(getattr(agent, mod), sd)
     return agent, cfg
 
 
-def dev_batch(L, B, A, seed, u8=True):
-    obs, act, rew, done = fx.make_batch(L, B, A, seed=seed)
+def dev_batch(L, B, A, seed, u8=True, image=64):
+    obs, act, rew, done = fx.make_batch(L, B, A, seed=seed, image=image)
     o = torch.from_numpy(obs if u8 else fx.preprocess_u8(obs)).cuda()
     return (o, torch.from_numpy(act).cuda(), torch.from_numpy(rew).cuda(), torch.from_numpy(done).cuda()), (obs, act, rew, done)
 
@@ -129,13 +129,16 @@ def test_update_matches_reference_goldens(golden_dir, fname, algo):
         assert abs(have[n][0] - s_) <= 1e-3 * abs(a_) + 1e-6, (n, have[n][0], s_)
 
 
-@pytest.mark.parametrize("algo", ["repo", "dreamer"])
-def test_update_matches_oracle_latents_and_grads(algo):
-    L, B, H, A = 10, 5, 6, 6
-    agent, cfg = make_agent(algo, L, B, H, A)
-    oracle = OracleAgent(cfg, A, seed=7)
+# image=128: the build-defined 128 x 128 conv stack (BASELINE config 4's frame size).  The reference has no such
+# model (its flatten hard-codes 64 x 64), so this variant's parity is pinned by the oracle only -- "parity unpinned
+# by the reference" (DESIGN.md section 6).
+@pytest.mark.parametrize("algo,image,A", [("repo", 64, 6), ("dreamer", 64, 6), ("repo", 128, 7), ("dreamer", 128, 7)])
+def test_update_matches_oracle_latents_and_grads(algo, image, A):
+    L, B, H = (10, 5, 6) if image == 64 else (7, 3, 5)
+    agent, cfg = make_agent(algo, L, B, H, A, image=image)
+    oracle = OracleAgent(cfg, A, seed=7, image=image)
     for u in range(2):
-        batch, host = dev_batch(L, B, A, 40 + u)
+        batch, host = dev_batch(L, B, A, 40 + u, u8=(u == 0), image=image)
         agent.noise_source, nz = dev_noise(L, B, H, A, 140 + u)
         # gradients of THIS update before the optimiser touches them: snapshot via a hook on step
         beliefs, post = agent.train_dynamics(batch[0], batch[1], batch[2], 1.0 - batch[3])
@@ -164,7 +167,7 @@ def test_update_matches_oracle_latents_and_grads(algo):
             ("value", g_value, flat(oracle.last["value_grads"], agent.value_optimizer)),
         ):
             e = ((got.cpu() - want).norm() / want.norm()).item()
-            log(f"[oracle {algo}] update {u} flat grad {name}: l2 rel {e:.2e}")
+            log(f"[oracle {algo} {image}x{image}] update {u} flat grad {name}: l2 rel {e:.2e}")
             # normwise (a ReLU unit within rounding of zero may flip between two fp32 runs); observed 2e-7 .. 3e-6
             assert e < 1e-3, (name, e)
 
@@ -197,14 +200,15 @@ def test_full_size_update_properties():
     assert outs[0] == outs[1], (outs[0], outs[1])
 
 
-def test_module_autograd_wrappers():
+@pytest.mark.parametrize("image", [64, 128])
+def test_module_autograd_wrappers(image):
     """encoder / obs_model / reward_model / transition_model.observe as autograd nodes."""
     from repo_amd.algorithms.repo.models.utils import bottle
     from oracle import repo_oracle as ro
 
     L, B, H, A = 6, 3, 4, 6
-    agent, cfg = make_agent("dreamer", L, B, H, A)
-    batch, host = dev_batch(L, B, A, 77, u8=False)
+    agent, cfg = make_agent("dreamer", L, B, H, A, image=image)
+    batch, host = dev_batch(L, B, A, 77, u8=False, image=image)
     obs, act, rew, done = batch
     nz, nzh = dev_noise(L, B, H, A, 177)
     T = L - 1
@@ -220,13 +224,13 @@ def test_module_autograd_wrappers():
         p.grad = None
     loss.backward()
     # oracle
-    o = OracleAgent(cfg, A, seed=7)
+    o = OracleAgent(cfg, A, seed=7, image=image)
     ho = torch.from_numpy(fx.preprocess_u8(host[0]))
-    oe = ro.encoder_fwd(o.p["encoder"], ho.reshape(L * B, 3, 64, 64)).reshape(L, B, -1)
+    oe = ro.encoder_fwd(o.p["encoder"], ho.reshape(L * B, 3, image, image)).reshape(L, B, -1)
     oo = ro.observe(o.p["transition_model"], torch.zeros(B, 200), torch.zeros(B, 30), torch.from_numpy(host[1])[:-1], oe[1:],
                     1 - torch.from_numpy(host[3])[:-1], torch.from_numpy(nzh["obs_prior"]), torch.from_numpy(nzh["obs_post"]))
     fb, fs = oo[0].reshape(T * B, -1), oo[4].reshape(T * B, -1)
-    orec = ro.decoder_fwd(o.p["obs_model"], fb, fs).reshape(T, B, 3, 64, 64)
+    orec = ro.decoder_fwd(o.p["obs_model"], fb, fs).reshape(T, B, 3, image, image)
     orp = ro.scalar_head(o.p["reward_model"], fb, fs).reshape(T, B)
     ol = (0.5 * (orec - ho[1:]) ** 2).sum((2, 3, 4)).mean() + (orp**2).mean() + oo[2].pow(2).mean()
     ol.backward()
