@@ -378,12 +378,41 @@ template <> struct DTileFor<GDec3> { using Down = REPO_DT_DEC3; using Wgrad = RE
 #endif
 template <> struct DTileFor<GDec4> { using Down = REPO_DT_DEC4; using Wgrad = REPO_WT_DEC4; static constexpr int WGT = 1536; };
 // 128 x 128 stack: tiles by analogy with the 64 x 64 layer of the same role (not swept)
-template <> struct DTileFor<GX1> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = WTile<32, 64, 1, 2, 1, 4, 2>;  static constexpr int WGT = 3072; };
-template <> struct DTileFor<GX2> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 1, 3, 2>; static constexpr int WGT = 1536; };
-template <> struct DTileFor<GX3> { using Down = DTile<128, 128, 2, 2, 2>; using Wgrad = WTile<64, 128, 2, 2, 1, 7>;    static constexpr int WGT = 1024; };
-template <> struct DTileFor<GX4> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 2, 6>;    static constexpr int WGT = 1024; };
-template <> struct DTileFor<GY4> { using Down = DTile<32, 256, 2, 1, 4>;  using Wgrad = WTile<32, 128, 1, 4, 1, 2>;    static constexpr int WGT = 1536; };
-template <> struct DTileFor<GY5> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = WTile<32, 64, 1, 2, 1, 2>;     static constexpr int WGT = 1536; };
+#ifndef REPO_WT_X1
+#define REPO_WT_X1 WTile<32, 64, 1, 2, 1, 2, 2>
+#endif
+#ifndef REPO_WT_X2
+#define REPO_WT_X2 WTile<64, 128, 2, 2, 1, 3, 2>
+#endif
+#ifndef REPO_WT_X3
+#define REPO_WT_X3 WTile<64, 128, 2, 2, 1, 7>
+#endif
+#ifndef REPO_WT_X4
+#define REPO_WT_X4 WTile<64, 128, 2, 2, 2, 6>
+#endif
+#ifndef REPO_WT_Y4
+#define REPO_WT_Y4 WTile<32, 128, 1, 4, 1, 2>
+#endif
+#ifndef REPO_WT_Y5
+#define REPO_WT_Y5 WTile<32, 64, 1, 2, 1, 2>
+#endif
+#ifndef REPO_WGT_X1
+#define REPO_WGT_X1 3072
+#endif
+#ifndef REPO_WGT_X2
+#define REPO_WGT_X2 1536
+#endif
+#ifndef REPO_WGT_Y5
+#define REPO_WGT_Y5 1536
+#endif
+// (GX1's weight gradient walks 2-row bands: with 4 rows of 63 pixels the 126 k-pairs of a band exceed what the
+// compiler unrolls, the chunk-ahead loads then index their registers at run time: 1935 us instead of ~400)
+template <> struct DTileFor<GX1> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = REPO_WT_X1; static constexpr int WGT = REPO_WGT_X1; };
+template <> struct DTileFor<GX2> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = REPO_WT_X2; static constexpr int WGT = REPO_WGT_X2; };
+template <> struct DTileFor<GX3> { using Down = DTile<128, 128, 2, 2, 2>; using Wgrad = REPO_WT_X3; static constexpr int WGT = 1024; };
+template <> struct DTileFor<GX4> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = REPO_WT_X4; static constexpr int WGT = 1024; };
+template <> struct DTileFor<GY4> { using Down = DTile<32, 256, 2, 1, 4>;  using Wgrad = REPO_WT_Y4; static constexpr int WGT = 1536; };
+template <> struct DTileFor<GY5> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = REPO_WT_Y5; static constexpr int WGT = REPO_WGT_Y5; };
 
 // A handful of frames (the acting path encodes ONE per environment step): the throughput tiles leave 1-2
 // workgroups walking 16-64 dependent channel chunks (enc4: 147 us for one frame).  Latency tiles use 32
