@@ -109,6 +109,7 @@ int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t ld
  * hard-codes the 64 x 64 flatten, encoder.py:39, so there is no reference model at this size):
  *   7..10 encoder conv1..4 at 128: 3x128x128 -> 32x63x63 -> 64x30x30 -> 128x14x14 -> 256x6x6, k=4
  *   11,12 decoder conv4, conv5 at 128 (after layers 4, 5): 32x30x30 -> 16x64x64 (k6) -> 3x128x128 (k2)
+ *   13    TIAObservationModel.conv4 (models/decoder.py:165): 32x30x30 -> 6x64x64 (k6), [recon(3) | mask(3)]
  * Every geometry is a pair (big, small) with big = 2*small + k - 2 and one weight tensor
  * indexed w[small_ch][big_ch][ky][kx] -- which is both nn.Conv2d's (out,in,kh,kw) for the
  * encoder and nn.ConvTranspose2d's (in,out,kh,kw) for the decoder.  Three kernels act on a
@@ -350,6 +351,19 @@ int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const flo
  * dpred = (pred-target)*mask*scale (nullable). */
 int repo_scalar_nll(int64_t n, const float* pred, const float* target, const float* mask, float scale,
                     float* dpred, float* sums2, void* ws, size_t ws_bytes, hipStream_t stream);
+/* TIA's masked blend of two decoders + unit-variance pixel NLL (tia.py:123-133; TIAObservationModel,
+ * models/decoder.py:154-175): t_out, d_out (nimg, 6, pixels) = [recon(3) | mask(3)] of the task / distractor
+ * decoder; mask_wb[7] = mask_head's Conv2d(6,1,1) weight (t_mask(3), d_mask(3)) and bias;
+ *   m = sigmoid(bias + w . [t_mask | d_mask]);  recon = t_recon*m + d_recon*(1-m)
+ * sums8 = {sum 0.5*(recon-target)^2, d/dw[0..5], d/dbias} of grad_scale * that sum (the loss itself unscaled);
+ * dt_out / dd_out (nullable together; may alias t_out / d_out) = grad_scale * d sum / d t_out, d_out;
+ * recon (nimg, 3, pixels) nullable.  target (nimg, 3, pixels) float32 in [-1,1] or uint8 (normalised in-kernel).
+ * pixels % 4 == 0. */
+size_t repo_tia_blend_nll_workspace_bytes(void);
+int repo_tia_blend_nll(int64_t nimg, int64_t pixels, const float* t_out, const float* d_out,
+                       const float* mask_wb, const void* target, int target_is_u8, float grad_scale,
+                       float* dt_out, float* dd_out, float* recon, float* sums8, void* ws, size_t ws_bytes,
+                       hipStream_t stream);
 /* SampleDist.entropy of the tanh-Normal policy (models/utils.py:126-134,160-163):
  * eps (samples, rows, A), or NULL => drawn in-kernel, sample s of element e = row*A + a being normal number
  * noise_offset + e*samples + s (sample-fastest; rows*A*samples consumed).  *ent_sum = sum_rows entropy_row;

@@ -32,6 +32,12 @@ MODULES = (
 )
 # modules whose parameters form ``model_params`` (dreamer.py:90-95)
 MODEL_MODULES = ("encoder", "transition_model", "obs_model", "reward_model")
+# TIA (tia.py:27-82): obs_model becomes the 6-channel TIAObservationModel and these modules are added;
+# model_params in the reference's order
+TIA_EXTRA_MODULES = ("distractor_transition_model", "distractor_obs_model", "distractor_only_obs_model",
+                     "distractor_reward_model", "mask_head")
+TIA_MODEL_MODULES = ("encoder", "transition_model", "reward_model", "obs_model", "distractor_transition_model",
+                     "distractor_reward_model", "distractor_obs_model", "distractor_only_obs_model", "mask_head")
 
 
 def default_config(**over):
@@ -65,6 +71,9 @@ def default_config(**over):
         disag_model=False,
         inv_dynamics=False,
         disag_coef=0.0,
+        tia_obs_coef=1.0,
+        tia_adv_coef=1.0,
+        tia_reward_train_steps=1,
         replay_size=1000,
         train_steps=1,
         prefill=0,
@@ -81,7 +90,7 @@ def default_config(**over):
     return SimpleNamespace(**c)
 
 
-def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, image=64):
+def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, image=64, tia=False):
     """Ordered {module: OrderedDict(name -> shape)} in state_dict order.
     image=128: the BUILD-DEFINED 128 x 128 stack (no reference model exists at that size: the reference's encoder
     hard-codes the 64 x 64 flatten, encoder.py:39): the same four encoder convs (-> 256x6x6) + fc 9216 -> embed; the
@@ -143,7 +152,7 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, imag
         d[f"fc{n_hidden_layers + 1}.bias"] = (out,)
         return d
 
-    return OrderedDict(
+    out = OrderedDict(
         [
             ("encoder", enc),
             ("transition_model", rssm),
@@ -153,9 +162,21 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, imag
             ("value_model", mlp(3, 1)),
         ]
     )
+    if tia:
+        # TIAObservationModel (models/decoder.py:154-165): conv4 emits 6 channels = [recon | mask]
+        assert image == 64
+        dec6 = OrderedDict(dec)
+        dec6["conv4.weight"], dec6["conv4.bias"] = (32, 6, 6, 6), (6,)
+        out["obs_model"] = dec6
+        out["distractor_transition_model"] = OrderedDict(rssm)
+        out["distractor_obs_model"] = OrderedDict(dec6)
+        out["distractor_only_obs_model"] = OrderedDict(dec)
+        out["distractor_reward_model"] = mlp(3, 1)
+        out["mask_head"] = OrderedDict([("0.weight", (1, 6, 1, 1)), ("0.bias", (1,))])
+    return out
 
 
-def make_params(action_size, seed=7, image=64):
+def make_params(action_size, seed=7, image=64, tia=False):
     """{module: OrderedDict(name -> float32 ndarray)}; uniform(-k, k), k = fan_in**-0.5.
 
     One RandomState drawn sequentially in (module, state_dict) order; a bias uses
@@ -163,7 +184,7 @@ def make_params(action_size, seed=7, image=64):
     """
     rs = np.random.RandomState(seed)
     out = OrderedDict()
-    for mod, shapes in param_shapes(action_size, image=image).items():
+    for mod, shapes in param_shapes(action_size, image=image, tia=tia).items():
         d = OrderedDict()
         k = 1.0
         for name, shp in shapes.items():
@@ -193,10 +214,11 @@ def preprocess_u8(obs_u8):
     return ((obs_u8.astype(np.float32) / 255) * 2) - 1.0
 
 
-def make_noise(L, B, H, action_size, state=30, samples=100, seed=101):
+def make_noise(L, B, H, action_size, state=30, samples=100, seed=101, tia=False):
     """Noise for ONE update in the reference's draw order:
     train_dynamics: for t: eps_prior (B,S), eps_post (B,S);
     train_actor_critic: for t<H-1: eps_act (N,A), eps_prior (N,S); then entropy (100,(H-1)N,A).
+    tia=True: the distractor filter's scan draws (d_obs_prior, d_obs_post) after the task scan's (tia.py:88-121).
     """
     rs = np.random.RandomState(seed)
     T = L - 1
@@ -209,15 +231,23 @@ def make_noise(L, B, H, action_size, state=30, samples=100, seed=101):
     for _ in range(T):
         obs_prior.append(n(B, state))
         obs_post.append(n(B, state))
+    d_prior, d_post = [], []
+    if tia:
+        for _ in range(T):
+            d_prior.append(n(B, state))
+            d_post.append(n(B, state))
     img_act, img_prior = [], []
     for _ in range(H - 1):
         img_act.append(n(N, action_size))
         img_prior.append(n(N, state))
     ent = n(samples, (H - 1) * N, action_size)
-    return dict(
+    out = dict(
         obs_prior=np.stack(obs_prior),
         obs_post=np.stack(obs_post),
         img_act=np.stack(img_act),
         img_prior=np.stack(img_prior),
         entropy=ent,
     )
+    if tia:
+        out["d_obs_prior"], out["d_obs_post"] = np.stack(d_prior), np.stack(d_post)
+    return out

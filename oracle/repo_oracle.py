@@ -399,3 +399,124 @@ class OracleAgent:
         out["actor_model"] = math.sqrt(sum(float((g.double() ** 2).sum()) for g in self.last["actor_grads"]))
         out["value_model"] = math.sqrt(sum(float((g.double() ** 2).sum()) for g in self.last["value_grads"]))
         return out
+
+
+# --------------------------------------------------------------------------- TIA
+class OracleTIA(OracleAgent):
+    """TIA(Dreamer), /root/reference/algorithms/repo/tia.py:17-209: a distractor RSSM on the same embeddings, a
+    mask-blended pair of 6-channel decoders (models/decoder.py:154-175) + mask_head (tia.py:69), a distractor-only
+    decoder, an adversarial (frozen) distractor reward head that is then fitted for tia_reward_train_steps steps.
+    ONE Adam over model_params in the reference's order (tia.py:71-82): parameters whose gradient is None are
+    skipped by a step (per-parameter step counts, as torch.optim.Adam keeps them).
+    Parity status: PINNED by tests/golden/tia_tiny.npz (the reference's TIA run by tests/golden/gen_golden.py)."""
+
+    def __init__(self, cfg, action_size, params=None, seed=7):
+        np_params = params if params is not None else fx.make_params(action_size, seed, tia=True)
+        super().__init__(cfg, action_size, params=np_params)
+        assert not self.is_repo
+        for mod in fx.TIA_EXTRA_MODULES:
+            self.p[mod] = OrderedDict(
+                (k, torch.tensor(np.asarray(v), dtype=torch.float32).requires_grad_(True)) for k, v in np_params[mod].items()
+            )
+        self.model_params = [t for mod in fx.TIA_MODEL_MODULES for t in self.p[mod].values()]
+        self.model_opt = PerParamAdam(self.model_params, cfg.model_lr)
+
+    def train_dynamics(self, obs, actions, rewards, nonterms, eps_prior, eps_post, d_eps_prior=None, d_eps_post=None,
+                       apply=True):
+        c, p = self.c, self.p
+        L, B = obs.shape[:2]
+        T = L - 1
+        embeds = encoder_fwd(p["encoder"], obs.reshape(L * B, *obs.shape[2:])).reshape(L, B, -1)
+        b0 = torch.zeros(B, c.belief_size)
+        s0 = torch.zeros(B, c.state_size)
+        tb, _, tpm, tps, tpost, tqm, tqs = observe(p["transition_model"], b0, s0, actions[:-1], embeds[1:], nonterms[:-1],
+                                                   eps_prior, eps_post)
+        db, _, dpm, dps, dpost, dqm, dqs = observe(p["distractor_transition_model"], b0, s0, actions[:-1], embeds[1:],
+                                                   nonterms[:-1], d_eps_prior, d_eps_post)
+        tfb, tfs = tb.reshape(T * B, -1), tpost.reshape(T * B, -1)
+        dfb, dfs = db.reshape(T * B, -1), dpost.reshape(T * B, -1)
+        # tia.py:123-133
+        t_recon, t_mask = decoder_fwd(p["obs_model"], tfb, tfs).chunk(2, 1)
+        d_recon, d_mask = decoder_fwd(p["distractor_obs_model"], dfb, dfs).chunk(2, 1)
+        m = torch.sigmoid(F.conv2d(torch.cat((t_mask, d_mask), 1), p["mask_head"]["0.weight"], p["mask_head"]["0.bias"]))
+        recon = (t_recon * m + d_recon * (1 - m)).reshape(T, B, *obs.shape[2:])
+        obs_loss = (0.5 * (recon - obs[1:]) ** 2 + 0.5 * LOG_2PI).sum((2, 3, 4)).mean((0, 1))
+        # tia.py:135-145
+        d_only = decoder_fwd(p["distractor_only_obs_model"], dfb, dfs).reshape(T, B, *obs.shape[2:])
+        d_obs_loss = (0.5 * (d_only - obs[1:]) ** 2 + 0.5 * LOG_2PI).sum((2, 3, 4)).mean((0, 1))
+        # tia.py:147-158
+        r_tgt = rewards[:-1].squeeze(-1)
+        mask = nonterms[:-1].squeeze(-1)
+        t_reward = scalar_head(p["reward_model"], tfb, tfs).reshape(T, B)
+        frozen = list(p["distractor_reward_model"].values())
+        for q in frozen:
+            q.requires_grad_(False)
+        try:
+            d_reward = scalar_head(p["distractor_reward_model"], dfb, dfs).reshape(T, B)
+        finally:
+            for q in frozen:
+                q.requires_grad_(True)
+        t_reward_loss = ((0.5 * (t_reward - r_tgt) ** 2 + 0.5 * LOG_2PI) * mask).mean((0, 1))
+        d_reward_loss = (-(0.5 * (d_reward - r_tgt) ** 2 + 0.5 * LOG_2PI) * mask).mean((0, 1))
+        reward_loss = t_reward_loss + c.tia_adv_coef * d_reward_loss
+        # tia.py:160-172
+        free = torch.full((1,), float(c.free_nats))
+        t_kl = normal_kl(tqm, tqs, tpm, tps).sum(2)
+        d_kl = normal_kl(dqm, dqs, dpm, dps).sum(2)
+        kl_loss = torch.max(t_kl, free).mean((0, 1)) + torch.max(d_kl, free).mean((0, 1))
+        model_loss = obs_loss + c.tia_obs_coef * d_obs_loss + reward_loss + kl_loss
+        self.model_opt.zero_grad()
+        model_loss.backward()
+        self.last["model_grads"] = [None if q.grad is None else q.grad.detach().clone() for q in self.model_params]
+        total = clip_grad_norm(self.model_params, c.grad_clip_norm)
+        self.last["model_total_norm"] = float(total)
+        if apply:
+            self.model_opt.step()
+        # tia.py:184-196
+        self.last["d_reward_total_norms"] = []
+        for _ in range(int(c.tia_reward_train_steps)):
+            d_reward = scalar_head(p["distractor_reward_model"], dfb.detach(), dfs.detach()).reshape(T, B)
+            d_reward_loss = ((0.5 * (d_reward - r_tgt) ** 2 + 0.5 * LOG_2PI) * mask).mean((0, 1))
+            self.model_opt.zero_grad()
+            d_reward_loss.backward()
+            self.last["d_reward_grads"] = [q.grad.detach().clone() for q in frozen]
+            self.last["d_reward_total_norms"].append(float(clip_grad_norm(self.model_params, c.grad_clip_norm)))
+            if apply:
+                self.model_opt.step()
+        out = {
+            "train/obs_loss": obs_loss, "train/d_obs_loss": d_obs_loss, "train/reward_loss": reward_loss,
+            "train/t_reward_loss": t_reward_loss, "train/d_reward_loss": d_reward_loss, "train/kl_loss": kl_loss,
+            "train/t_kl_div": t_kl.mean(), "train/d_kl_div": d_kl.mean(), "train/model_loss": model_loss,
+        }
+        return tb.detach(), tpost.detach(), {k: float(v.detach()) for k, v in out.items()}
+
+    def update(self, obs_u8, actions, rewards, dones, noise):
+        obs = torch.from_numpy(fx.preprocess_u8(np.asarray(obs_u8)))
+        t = {k: torch.as_tensor(v) for k, v in noise.items()}
+        beliefs, post, scal = self.train_dynamics(obs, torch.as_tensor(actions), torch.as_tensor(rewards),
+                                                  1 - torch.as_tensor(dones), t["obs_prior"], t["obs_post"],
+                                                  t["d_obs_prior"], t["d_obs_post"])
+        scal.update(self.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1), t["img_act"], t["img_prior"],
+                                            t["entropy"]))
+        return beliefs, post, scal
+
+
+class PerParamAdam(Adam):
+    """torch.optim.Adam's per-parameter step count: a parameter whose gradient is None is skipped entirely."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr, betas, eps)
+        self.steps = [0] * len(self.params)
+
+    @torch.no_grad()
+    def step(self):
+        for i, (p, m, v) in enumerate(zip(self.params, self.m, self.v)):
+            if p.grad is None:
+                continue
+            self.steps[i] += 1
+            t = self.steps[i]
+            g = p.grad
+            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            denom = (v.sqrt() / math.sqrt(1 - self.b2**t)).add_(self.eps)
+            p.addcdiv_(m, denom, value=-(self.lr / (1 - self.b1**t)))

@@ -1,4 +1,5 @@
 from .dreamer import Dreamer
 from .repo import RePo
+from .tia import TIA
 
-__all__ = ["Dreamer", "RePo"]
+__all__ = ["Dreamer", "RePo", "TIA"]

@@ -109,6 +109,7 @@ class Dreamer:
         self._ac_stream = torch.cuda.Stream(device=self.device)
         self._ev_ac_done = None      # AC(k) finished reading the world-model parameters
         self._log_pending = None     # (event, pinned host buffer, meta) of the last enqueued update
+        self._pending_extra = None   # (loss sums, gradient norms) a sibling algorithm adds to the update's log
         self._log_host = torch.empty(32, dtype=torch.float32).pin_memory()
         self._act_graphs = {}
         self._act_graph_enabled = os.environ.get("REPO_ACT_GRAPH", "1") == "1"
@@ -452,28 +453,37 @@ class Dreamer:
         msc.record_stream(cur)
         if dual is not None:
             dual.record_stream(cur)
-        parts = [msc[:4], ret_sum, ent_sum, lat_sum, v_sums, msc[4:5], self.actor_optimizer.sqnorm,
-                 self.value_optimizer.sqnorm]
+        # a sibling algorithm's own loss sums / gradient norms (TIA): behind the shared ones of each kind
+        xs, xn = self._pending_extra if self._pending_extra is not None else (msc[:0], msc[:0])
+        self._pending_extra = None
+        parts = [msc[:4], ret_sum, ent_sum, lat_sum, v_sums, xs, msc[4:5], self.actor_optimizer.sqnorm,
+                 self.value_optimizer.sqnorm, xn]
         if dual is not None:
             parts.append(dual)
         buf = torch.cat([p.reshape(-1) for p in parts])
         # the leading entries (losses) are per-rank partial sums; the gradient norms behind them are already global
-        self._allreduce_scalars(buf, n_sum=sum(p.numel() for p in parts[:5]))
+        self._allreduce_scalars(buf, n_sum=sum(p.numel() for p in parts[:6]))
         n = buf.numel()
         self._log_host[:n].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(cur)
-        self._log_pending = (ev, n, dual is not None, grow, Hm, gN)
+        self._log_pending = (ev, n, dual is not None, grow, Hm, gN, xs.numel(), xn.numel())
+
+    def _extra_scalars(self, out, sums, norms, grow):
+        """Hook of the sibling algorithms: rewrite / add logged scalars from their own sums (see _log_update)."""
 
     def _flush_log(self):
         if self._log_pending is None:
             return
-        ev, n, has_dual, grow, Hm, gN = self._log_pending
+        ev, n, has_dual, grow, Hm, gN, nxs, nxn = self._log_pending
         self._log_pending = None
         ev.synchronize()
         c = self.c
         h = self._log_host[:n].tolist()
-        nll, rsq, rmask, kl, ret, ent, lat, vsq, _vn, gm, ga_, gv_ = h[:12]
+        nll, rsq, rmask, kl, ret, ent, lat, vsq, _vn = h[:9]
+        xsums, h = h[9 : 9 + nxs], h[:9] + h[9 + nxs :]
+        gm, ga_, gv_ = h[9:12]
+        xnorms, h = h[12 : 12 + nxn], h[:12] + h[12 + nxn :]
         npix = self._npix
         out = {}
         out["train/obs_loss"] = nll / grow + 0.5 * LOG_2PI * npix
@@ -487,6 +497,7 @@ class Dreamer:
         else:
             out["train/kl_loss"] = kl / grow
         out["train/model_loss"] = out["train/obs_loss"] + out["train/reward_loss"] + out["train/kl_loss"]
+        self._extra_scalars(out, xsums, xnorms, grow)
         action_entropy = ent / (Hm * gN)
         latent_entropy = lat / (Hm * gN)
         out["train/actor_loss"] = (-ret / ((Hm - 1) * gN) - c.action_ent_coef * action_entropy
@@ -665,6 +676,9 @@ class Dreamer:
                     job()
             self.step += 1
 
+    def _reconstruct(self, belief, state):
+        return self.obs_model(belief, state)
+
     def eval_agent(self):
         """One deterministic-policy episode on eval_env; logs return, success and a side-by-side video of
         observed and reconstructed frames (reference dreamer.py:457-490)."""
@@ -677,7 +691,7 @@ class Dreamer:
             tr = driver.advance()
             if self.c.pixel_obs:
                 with torch.no_grad():
-                    recon = self.obs_model(driver.latent[0], driver.latent[1])
+                    recon = self._reconstruct(driver.latent[0], driver.latent[1])
                 pairs.append([tr.obs, postprocess(to_np(recon))[0]])
             finished = tr.done
         driver.report("test")

@@ -39,6 +39,32 @@ class VisualObservationModel(nn.Module):
         return decoder_apply(self, belief, state)
 
 
+class TIAObservationModel(nn.Module):
+    """TIA's decoder (reference models/decoder.py:154-175): the visual decoder with a 6-channel output layer,
+    returned as (recon, mask) = out.chunk(2, 1).  64 x 64 frames only (as the reference)."""
+
+    def __init__(self, belief_size, state_size, embedding_size, activation_function="relu"):
+        super().__init__()
+        if activation_function != "relu":
+            raise NotImplementedError("HIP decoder kernels fuse ReLU (cnn_activation_function='relu')")
+        if embedding_size != 1024:
+            raise NotImplementedError("embedding_size != 1024 is not on the hot path")
+        self.embedding_size = embedding_size
+        self.fc1 = nn.Linear(belief_size + state_size, embedding_size)
+        self.conv1 = nn.ConvTranspose2d(embedding_size, 128, 5, stride=2)
+        self.conv2 = nn.ConvTranspose2d(128, 64, 5, stride=2)
+        self.conv3 = nn.ConvTranspose2d(64, 32, 6, stride=2)
+        self.conv4 = nn.ConvTranspose2d(32, 6, 6, stride=2)
+
+    def plist(self):
+        return [t for m in (self.fc1, self.conv1, self.conv2, self.conv3, self.conv4) for t in (m.weight, m.bias)]
+
+    def forward(self, belief, state):
+        from ..autograd import decoder_apply
+
+        return decoder_apply(self, belief, state).chunk(2, 1)
+
+
 def ObservationModel(symbolic, observation_size, belief_size, state_size, embedding_size, activation_function="relu"):
     if symbolic:
         raise NotImplementedError("symbolic (non-pixel) observations are outside the MI355X hot path")

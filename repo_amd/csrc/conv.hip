@@ -50,6 +50,7 @@ using GX3 = Geo<64, 128, 30, 4>;
 using GX4 = Geo<128, 256, 14, 4>;
 using GY4 = Geo<16, 32, 64, 6>;
 using GY5 = Geo<3, 16, 128, 2>;
+using GT4 = Geo<6, 32, 64, 6>;  // TIAObservationModel.conv4 (models/decoder.py:165): 32 -> 6 = [recon | mask]
 static_assert(GX1::HS == 63 && GX2::HS == 30 && GX3::HS == 14 && GX4::HS == 6 && GY4::HS == 30 && GY5::HS == 64,
               "128 x 128 geometry");
 
@@ -412,6 +413,7 @@ template <> struct DTileFor<GX2> { using Down = DTile<64, 128, 2, 2, 2>;  using 
 template <> struct DTileFor<GX3> { using Down = DTile<128, 128, 2, 2, 2>; using Wgrad = REPO_WT_X3; static constexpr int WGT = 1024; };
 template <> struct DTileFor<GX4> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = REPO_WT_X4; static constexpr int WGT = 1024; };
 template <> struct DTileFor<GY4> { using Down = DTile<32, 256, 2, 1, 4>;  using Wgrad = REPO_WT_Y4; static constexpr int WGT = 1536; };
+template <> struct DTileFor<GT4> { using Down = DTile<32, 256, 3, 1, 8>;  using Wgrad = WTile<32, 128, 1, 4, 1, 2>; static constexpr int WGT = 1536; };
 template <> struct DTileFor<GY5> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = REPO_WT_Y5; static constexpr int WGT = REPO_WGT_Y5; };
 
 // A handful of frames (the acting path encodes ONE per environment step): the throughput tiles leave 1-2
@@ -558,6 +560,7 @@ using namespace repo;
     case 10: { using G = GX4; CALL; }                  \
     case 11: { using G = GY4; CALL; }                  \
     case 12: { using G = GY5; CALL; }                  \
+    case 13: { using G = GT4; CALL; }                  \
     default: return REPO_E_BADARG;                     \
   }
 

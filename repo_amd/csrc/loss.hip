@@ -286,6 +286,90 @@ __global__ __launch_bounds__(256) void tanh_normal_mode_kernel(int rows, int A, 
   }
 }
 
+// ------------------------------------------------------------------ TIA: mask head + blend + pixel NLL
+// tia.py:123-133 (reference): the task and distractor decoders each emit 6 channels (3 "recon" + 3 "mask");
+//   m = sigmoid(b + sum_c w[c] t_mask[c] + w[3+c] d_mask[c])          (mask_head = Conv2d(6, 1, 1) + Sigmoid)
+//   recon[c] = t_recon[c] m + d_recon[c] (1 - m);  loss = sum 0.5 (recon - target)^2
+// One streaming pass: reads both 6-channel outputs and the target, writes the gradients with respect to both outputs
+// (may alias the inputs: every thread reads its 4 pixels before it writes them) and 8 partials per workgroup:
+// the loss and d loss / d (w[0..5], b).  Thread = 4 consecutive pixels of one frame (16-byte accesses).
+template <class TgtT>
+__global__ __launch_bounds__(256) void tia_blend_nll_kernel(int n4, int pix4, const float* __restrict__ wb,
+                                                            const float* t_out, const float* d_out,
+                                                            const TgtT* __restrict__ target, float gscale, float* dt_out,
+                                                            float* dd_out, float* __restrict__ recon_out,
+                                                            float* __restrict__ parts) {
+  __shared__ float red[16];
+  float w[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) w[c] = wb[c];
+  const float b = wb[6];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const int img = i / pix4, q = i % pix4;
+    const size_t base6 = ((size_t)img * 6 * pix4 + q) * 4;  // channel c at + c * 4 * pix4
+    const size_t base3 = ((size_t)img * 3 * pix4 + q) * 4;
+    float4 t[6], d[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      t[c] = *reinterpret_cast<const float4*>(t_out + base6 + (size_t)c * 4 * pix4);
+      d[c] = *reinterpret_cast<const float4*>(d_out + base6 + (size_t)c * 4 * pix4);
+    }
+    float tg[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tg[c][e] = load_as_float(target, (unsigned)(base3 + (size_t)c * 4 * pix4 + e));
+    float4 gt[6], gd[6], rc[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      auto el = [e](float4& v) -> float& { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+      float z = b;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) z += w[c] * el(t[3 + c]) + w[3 + c] * el(d[3 + c]);
+      const float m = 1.f / (1.f + expf(-z));
+      float dm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float tr = el(t[c]), dr = el(d[c]);
+        const float r = tr * m + dr * (1.f - m);
+        const float df = r - tg[c][e];
+        acc[0] += 0.5f * df * df;
+        const float g = df * gscale;
+        el(gt[c]) = g * m;
+        el(gd[c]) = g * (1.f - m);
+        el(rc[c]) = r;
+        dm += g * (tr - dr);
+      }
+      const float dz = dm * m * (1.f - m);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        el(gt[3 + c]) = dz * w[c];
+        el(gd[3 + c]) = dz * w[3 + c];
+        acc[1 + c] += dz * el(t[3 + c]);
+        acc[4 + c] += dz * el(d[3 + c]);
+      }
+      acc[7] += dz;
+    }
+    if (dt_out) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        *reinterpret_cast<float4*>(dt_out + base6 + (size_t)c * 4 * pix4) = gt[c];
+        *reinterpret_cast<float4*>(dd_out + base6 + (size_t)c * 4 * pix4) = gd[c];
+      }
+    }
+    if (recon_out) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(recon_out + base3 + (size_t)c * 4 * pix4) = rc[c];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const float sv = block_sum(acc[v], red);
+    if (threadIdx.x == 0) parts[v * gridDim.x + blockIdx.x] = sv;
+  }
+}
+
 static inline int red_blocks(long n, int per_block) {
   long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -339,6 +423,29 @@ extern "C" int repo_scalar_nll(int64_t n, const float* pred, const float* target
                      (float*)ws);
   REPO_CHECK_LAUNCH();
   return final_sum((const float*)ws, blocks, 2, sums2, stream);
+}
+
+extern "C" size_t repo_tia_blend_nll_workspace_bytes(void) { return 8 * kRedBlocks * sizeof(float); }
+
+extern "C" int repo_tia_blend_nll(int64_t nimg, int64_t pixels, const float* t_out, const float* d_out,
+                                  const float* mask_wb, const void* target, int target_is_u8, float grad_scale,
+                                  float* dt_out, float* dd_out, float* recon, float* sums8, void* ws, size_t ws_bytes,
+                                  hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(nimg > 0 && pixels > 0 && pixels % 4 == 0 && nimg * pixels * 6 < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(t_out && d_out && mask_wb && target && sums8 && ((dt_out == nullptr) == (dd_out == nullptr)),
+               REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_tia_blend_nll_workspace_bytes(), REPO_E_WS_TOO_SMALL);
+  const long n4 = nimg * pixels / 4;
+  const int blocks = red_blocks(n4, 512);
+  if (target_is_u8)
+    hipLaunchKernelGGL(tia_blend_nll_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, (int)n4, (int)(pixels / 4),
+                       mask_wb, t_out, d_out, (const uint8_t*)target, grad_scale, dt_out, dd_out, recon, (float*)ws);
+  else
+    hipLaunchKernelGGL(tia_blend_nll_kernel<float>, dim3(blocks), dim3(256), 0, stream, (int)n4, (int)(pixels / 4),
+                       mask_wb, t_out, d_out, (const float*)target, grad_scale, dt_out, dd_out, recon, (float*)ws);
+  REPO_CHECK_LAUNCH();
+  return final_sum((const float*)ws, blocks, 8, sums8, stream);
 }
 
 extern "C" int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,

@@ -104,7 +104,8 @@ def decoder_fwd(p, feat):
         h4 = ops.conv_up(ops.X_DEC4, h3, p[8], p[9], epi=ops.EPI_RELU)
         recon = ops.conv_up(ops.X_DEC5, h4, p[10], p[11], epi=ops.EPI_NONE)
         return recon, (h0, h1, h2, h3, h4)
-    recon = ops.conv_up(ops.DEC4, h3, p[8], p[9], epi=ops.EPI_NONE)
+    # (TIAObservationModel, models/decoder.py:165-175: conv4 has 6 output channels = [recon | mask], layer T_DEC4)
+    recon = ops.conv_up(ops.T_DEC4 if p[8].shape[1] == 6 else ops.DEC4, h3, p[8], p[9], epi=ops.EPI_NONE)
     return recon, (h0, h1, h2, h3)
 
 
@@ -132,9 +133,10 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
         return _decoder_bwd_128(p, feat, saved, g, dfeat, accumulate_dfeat, accumulate, fk)
     h0, h1, h2, h3, d4 = saved[:5]
     mask3 = saved[5] if len(saved) > 5 else None  # quad mask of h3 from the fused output layer (8.8 MB for 282)
+    l4 = ops.T_DEC4 if p[8].shape[1] == 6 else ops.DEC4
 
     def w4():
-        ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
+        ops.conv_wgrad(l4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
         ops.channel_sum(d4, out=g[9], accumulate=accumulate)
 
     fk.run(w4)
@@ -144,9 +146,9 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
     # barrier per workgroup and a dependent reduction launch per layer ON the critical chain: 8.65 vs 8.55 ms per
     # update (A/B on one box, round 3).
     if mask3 is not None:
-        d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_MASK4, aux=mask3)
+        d3 = ops.conv_down(l4, d4, p[8], None, epi=ops.EPI_MUL_MASK4, aux=mask3)
     else:
-        d3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
+        d3 = ops.conv_down(l4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
 
     def w3():
         ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)

@@ -14,6 +14,7 @@ EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU, EPI_MUL_MASK4 = 0, 1, 
 # layer ids of repo_conv_* (include/repo_hip.h): 0..6 the reference's 64 x 64 stack, 7..12 the build-defined 128 x 128 one
 ENC1, ENC2, ENC3, ENC4, DEC2, DEC3, DEC4 = range(7)
 X_ENC1, X_ENC2, X_ENC3, X_ENC4, X_DEC4, X_DEC5 = range(7, 13)
+T_DEC4 = 13  # TIAObservationModel.conv4 (32 -> 6 = [recon | mask])
 # (CB, CS, HB, KS) per layer; HS = (HB-KS)//2+1
 CONV_GEO = {
     ENC1: (3, 32, 64, 4),
@@ -29,6 +30,7 @@ CONV_GEO = {
     X_ENC4: (128, 256, 14, 4),
     X_DEC4: (16, 32, 64, 6),
     X_DEC5: (3, 16, 128, 2),
+    T_DEC4: (6, 32, 64, 6),
 }
 
 
@@ -538,6 +540,29 @@ def scalar_nll(pred, target, mask, scale, want_grad=True, out=None):
         "repo_scalar_nll",
     )
     return out, dpred
+
+
+def tia_blend_nll(t_out, d_out, mask_wb, target, grad_scale, want_grads=True, want_recon=False, inplace=False):
+    """TIA's masked blend of the task / distractor decoder outputs + pixel NLL (tia.py:123-133).
+    t_out, d_out (n,6,H,W); mask_wb (7,) = mask_head weight(6) + bias; target (n,3,H,W) uint8 | float32.
+    Returns (sums8 = [loss_sum, d/dw(6), d/db], dt_out, dd_out, recon); inplace: the gradients overwrite t_out, d_out."""
+    n = t_out.shape[0]
+    pixels = t_out.shape[2] * t_out.shape[3]
+    assert t_out.shape == d_out.shape and t_out.shape[1] == 6 and t_out.is_contiguous() and d_out.is_contiguous()
+    assert target.is_contiguous() and target.numel() == n * 3 * pixels and mask_wb.numel() == 7
+    dev = t_out.device
+    dt = (t_out if inplace else torch.empty_like(t_out)) if want_grads else None
+    dd = (d_out if inplace else torch.empty_like(d_out)) if want_grads else None
+    recon = torch.empty(n, 3, *t_out.shape[2:], dtype=torch.float32, device=dev) if want_recon else None
+    sums = torch.empty(8, dtype=torch.float32, device=dev)
+    ws = workspace(lib().repo_tia_blend_nll_workspace_bytes(), dev)
+    check(
+        lib().repo_tia_blend_nll(n, pixels, _ptr(_f32c(t_out)), _ptr(_f32c(d_out)), _ptr(_f32c(mask_wb)), _ptr(target),
+                                 int(target.dtype == torch.uint8), float(grad_scale), _ptr(dt), _ptr(dd), _ptr(recon),
+                                 _ptr(sums), _ptr(ws), ws.numel(), _stream()),
+        "repo_tia_blend_nll",
+    )
+    return sums, dt, dd, recon
 
 
 def tanh_normal_entropy(mean, std, eps, gscale=0.0, want_grads=True, noise=(0, 0), samples=None):

@@ -43,9 +43,9 @@ def import_reference():
     import common.utils as cu
 
     cu.set_gpu_mode(False)
-    from algorithms.repo import Dreamer, RePo
+    from algorithms.repo import TIA, Dreamer, RePo
 
-    return Dreamer, RePo
+    return Dreamer, RePo, TIA
 
 
 class FakeSpace:
@@ -81,6 +81,10 @@ class NoiseFeeder:
         for t in range(T):
             q.append(noise["obs_prior"][t])
             q.append(noise["obs_post"][t])
+        if "d_obs_prior" in noise:  # TIA: the distractor filter's scan follows the task scan (tia.py:88-121)
+            for t in range(T):
+                q.append(noise["d_obs_prior"][t])
+                q.append(noise["d_obs_post"][t])
         for t in range(H - 1):
             q.append(noise["img_act"][t])
             q.append(noise["img_prior"][t])
@@ -207,14 +211,73 @@ def run_case(Algo, algo_name, L, B, H, A, n_updates, full_latents, feeder, recor
     print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
 
 
+def run_tia_case(TIA, L, B, H, A, n_updates, feeder, record, out_path, **cfg_over):
+    """The reference's TIA (tia.py) on seeded parameters / batches / noise: logged scalars, the pre-clip total
+    norms of its clip_grad_norm_ calls (model, distractor reward x tia_reward_train_steps, actor, value), the task
+    latents and per-tensor checksums of every module after the last update."""
+    cfg = fx.default_config(algo="tia", batch_size=B, chunk_size=L, horizon=H, **cfg_over)
+    logger = RecLogger()
+    algo = TIA(cfg, FakeEnv(A), FakeEnv(A), logger)
+    mods = fx.MODULES + fx.TIA_EXTRA_MODULES
+    params = fx.make_params(A, seed=7, tia=True)
+    for mod in mods:
+        m = getattr(algo, mod)
+        assert list(m.state_dict().keys()) == list(params[mod].keys()), (mod, list(m.state_dict().keys()))
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params[mod].items()})
+    assert [id(q) for mod in fx.TIA_MODEL_MODULES for q in getattr(algo, mod).parameters()] == [id(q) for q in algo.model_params]
+    T = L - 1
+    g = OrderedDict()
+    g["meta"] = np.array([L, B, H, A, n_updates, cfg.tia_reward_train_steps], dtype=np.int64)
+    g["coefs"] = np.array([cfg.tia_obs_coef, cfg.tia_adv_coef], dtype=np.float64)
+    scalar_keys = None
+    for u in range(n_updates):
+        obs_u8, actions, rewards, dones = fx.make_batch(L, B, A, seed=11 + u)
+        noise = fx.make_noise(L, B, H, A, seed=101 + u, tia=True)
+        feeder.load(noise, T, H)
+        record["clip_calls"].clear()
+        record["total_norms"].clear()
+        logger.kv.clear()
+        obs = torch.from_numpy(fx.preprocess_u8(obs_u8))
+        beliefs, post = algo.train_dynamics(obs, torch.from_numpy(actions), torch.from_numpy(rewards),
+                                            torch.from_numpy(1 - dones))
+        algo.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
+        assert not feeder.queue, "noise left over: draw order differs"
+        keys = sorted(logger.kv.keys())
+        scalar_keys = scalar_keys or keys
+        assert keys == scalar_keys
+        g[f"u{u}/scalars"] = np.array([logger.kv[k] for k in keys], dtype=np.float64)
+        g[f"u{u}/total_norms"] = np.array(record["total_norms"], dtype=np.float64)
+        g[f"u{u}/beliefs"] = beliefs.numpy().copy()
+        g[f"u{u}/posterior_states"] = post.numpy().copy()
+        print(f"  [{os.path.basename(out_path)}] update {u}: "
+              + " ".join(f"{k.split('/')[-1]}={logger.kv[k]:.6g}" for k in keys), flush=True)
+    g["scalar_keys"] = np.array(scalar_keys)
+    names, sums, abssums = [], [], []
+    for mod in mods:
+        for k, v in getattr(algo, mod).state_dict().items():
+            names.append(f"{mod}.{k}")
+            sums.append(float(v.double().sum()))
+            abssums.append(float(v.double().abs().sum()))
+    g["param_names"] = np.array(names)
+    g["param_sums"] = np.array(sums, dtype=np.float64)
+    g["param_abssums"] = np.array(abssums, dtype=np.float64)
+    np.savez_compressed(out_path, **g)
+    print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    Dreamer, RePo = import_reference()
+    Dreamer, RePo, TIA = import_reference()
     feeder = NoiseFeeder()
     record = {"clip_calls": [], "total_norms": []}
     install_patches(feeder, record)
 
+    if "--tia-only" in sys.argv:
+        run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(HERE, "tia_tiny.npz"))
+        run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(HERE, "tia_coefs.npz"), tia_obs_coef=0.5,
+                     tia_adv_coef=2.0, tia_reward_train_steps=2)
+        return
     # tiny unit-test size, full latents (SURVEY 8c)
     run_case(RePo, "repo", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(HERE, "repo_tiny.npz"))
     # config 5: Dreamer objective (free-nats KL, attached decoder)
@@ -223,6 +286,10 @@ def main():
     run_case(RePo, "repo", 6, 3, 3, 7, 2, True, feeder, record, os.path.join(HERE, "repo_odd.npz"))
     # config 1 shapes, scalar + sliced latents only
     run_case(RePo, "repo", 50, 16, 15, 6, 2, False, feeder, record, os.path.join(HERE, "repo_c1.npz"))
+    # TIA (f4): default coefficients, and non-default ones with two distractor-reward fitting steps
+    run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(HERE, "tia_tiny.npz"))
+    run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(HERE, "tia_coefs.npz"), tia_obs_coef=0.5,
+                 tia_adv_coef=2.0, tia_reward_train_steps=2)
 
 
 if __name__ == "__main__":

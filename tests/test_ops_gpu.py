@@ -104,7 +104,7 @@ def _layer_tensors(ops, layer, nimg, seed):
     return big, small, w, rs
 
 
-ALL_LAYERS = list(range(13))  # 0..6: the reference's 64 x 64 stack; 7..12: the build-defined 128 x 128 stack
+ALL_LAYERS = list(range(14))  # 0..6: the reference's 64 x 64 stack; 7..12: the build-defined 128 x 128 stack; 13: TIA conv4
 
 
 @pytest.mark.parametrize("layer", ALL_LAYERS)
