@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: RePo world-model + imagination updates per second.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|c4x128]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|c4x128|tia]
 
 Workload (default `--config c2` = BASELINE.json configs[1]): algo=repo, B=50
 sequences per GPU, L=50, H=15, A=6, 64x64x3 uint8 frames, parameters at torch default init under
@@ -57,6 +57,9 @@ CONFIGS = {
     "c5": ("dreamer", 50, 6, "algo=dreamer on dmc_distracted-walker-walk shapes (BASELINE configs[4])", 64),
     # BASELINE configs[3] at its own 128x128 frames: the reference cannot run it (its encoder flatten and decoder are
     # 64x64 only), the conv stack is build-defined and its parity is pinned by the oracle only
+    # f4 widening: the reference's TIA (algorithms/repo/tia.py) on configs[1]'s shapes: two filters, three decoders
+    "tia": ("tia", 50, 6, "algo=tia (tia.py: distractor filter, masked pair of decoders, distractor-only decoder) on "
+            "dmc_distracted-walker-walk shapes", 64),
     "c4x128": ("repo", 32, 7, "maniskill-PushCubeMatterport shapes at 128x128 frames through the BUILD-DEFINED 128x128 "
                "conv stack (no reference model exists for it), A=7", 128),
 }
@@ -67,9 +70,15 @@ FLOP_PER_UPDATE_B50 = 740.4e9  # SURVEY.md 8d, autograd-counted on the reference
 EXTRA_FLOP_PER_FRAME_128 = 3 * (179.2e6 - 29.4e6 + 77.0e6 - 48.4e6) - (12.19e6 - 2.95e6)
 
 
-def flop_per_update(B, image=64):
+# TIA: two more decoder passes (48.4 MFLOP forward per frame each, x3 with both gradients) and one more observe scan
+# (0.556 MMAC per row-step forward, x3) per frame over Dreamer's update
+EXTRA_FLOP_PER_FRAME_TIA = 2 * 3 * 48.4e6 + 3 * 2 * 0.556e6
+
+
+def flop_per_update(B, image=64, algo="repo"):
     """Algorithmic FLOPs of one update of B sequences (L=50, H=15)."""
-    return FLOP_PER_UPDATE_B50 * B / 50.0 + (EXTRA_FLOP_PER_FRAME_128 * (L - 1) * B if image == 128 else 0.0)
+    return (FLOP_PER_UPDATE_B50 * B / 50.0 + (EXTRA_FLOP_PER_FRAME_128 * (L - 1) * B if image == 128 else 0.0)
+            + (EXTRA_FLOP_PER_FRAME_TIA * (L - 1) * B if algo == "tia" else 0.0))
 RING_FRAMES = 6000             # synthetic replay ring per rank (72 MB of frames; 120 windows of 50)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")
 
@@ -105,6 +114,7 @@ def config(algo="repo", B=50):
         gamma=0.99, gae_lambda=0.95, action_noise=0.0, action_ent_coef=3e-4, latent_ent_coef=0.0, free_nats=3,
         model_lr=3e-4, actor_lr=8e-5, value_lr=8e-5, grad_clip_norm=100.0, target_kl=3.0, beta_lr=1e-4,
         init_beta=1e-5, prior_train_steps=5, disag_model=False, inv_dynamics=False, disag_coef=0.0,
+        tia_obs_coef=1.0, tia_adv_coef=1.0, tia_reward_train_steps=1,
         replay_size=8, train_steps=1, prefill=0, load_checkpoint=False, load_offline=False, save_buffer=False,
     )
 
@@ -294,8 +304,13 @@ def _cpu_baseline_worker(q, threads, warm, timed, B, A, algo, image=64):
 
     batch = synthetic_batch(1234, B, A, image)
     cfg = fx.default_config(algo=algo, batch_size=B, chunk_size=L, horizon=H)
-    agent = OracleAgent(cfg, A, seed=7, image=image)
-    noise = fx.make_noise(L, B, H, A, seed=1)
+    if algo == "tia":
+        from oracle.repo_oracle import OracleTIA
+
+        agent = OracleTIA(cfg, A, seed=7)
+    else:
+        agent = OracleAgent(cfg, A, seed=7, image=image)
+    noise = fx.make_noise(L, B, H, A, seed=1, tia=algo == "tia")
     for _ in range(warm):
         agent.update(*batch, noise)  # thread pools, oneDNN primitive caches
     t0 = _t.perf_counter()
@@ -373,7 +388,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--algo", default=None, help="override the config's algorithm (repo | dreamer)")
+    ap.add_argument("--algo", default=None, help="override the config's algorithm (repo | dreamer | tia)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--join", action="store_true", help="join the two update lanes after every update (no overlap)")
     ap.add_argument("--strong", action="store_true",
@@ -396,7 +411,7 @@ def main():
         return rendezvous_only(world, rank)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
 
-    from repo_amd.algorithms.repo import Dreamer, RePo
+    from repo_amd.algorithms.repo import TIA, Dreamer, RePo
     from repo_amd.common.buffers import SequenceReplayBuffer
     from repo_amd.common.utils import set_gpu_mode
 
@@ -422,7 +437,7 @@ def main():
 
     torch.manual_seed(0)
     cfg = config(algo, B)
-    agent = (RePo if algo == "repo" else Dreamer)(cfg, Env(A, image), Env(A, image), NullLogger())
+    agent = {"repo": RePo, "dreamer": Dreamer, "tia": TIA}[algo](cfg, Env(A, image), Env(A, image), NullLogger())
     if dp is not None:
         dp.attach(agent)
     if args.strong:
@@ -516,7 +531,7 @@ def main():
             dt_s = timed(run_from_ring, args.steps)
             strong = {"value": round(args.steps / dt_s, 3), "unit": "updates/s", "ms_per_step": round(dt_s / args.steps * 1e3, 3),
                       "global_batch": B, "shards": [b - a for a, b in (shard_rows(B, world, r) for r in range(world))],
-                      "algorithmic_tflops": round(flop_per_update(B, image) * args.steps / dt_s / 1e12, 2)}
+                      "algorithmic_tflops": round(flop_per_update(B, image, algo) * args.steps / dt_s / 1e12, 2)}
             Bl = cfg.batch_size = Bl_weak
             dp.reset_counts()
         else:
@@ -528,7 +543,7 @@ def main():
         value = (1 if args.strong else nranks) * args.steps / dt
         # FLOPs of one update of the GLOBAL batch this line's `value` counts: B sequences (--strong: one global
         # batch sharded over the ranks) or B per rank (weak)
-        flop = flop_per_update(B, image)
+        flop = flop_per_update(B, image, algo)
         line = {
             "metric": "world-model+imagine updates/sec (B=50,L=50,64x64x3)" if not args.config.startswith("c4") else
                       f"world-model+imagine updates/sec (B=32,L=50,{image}x{image}x3,A=7)",

@@ -75,15 +75,14 @@ class TIA(Dreamer):
         return conv.weight, conv.bias
 
     # ------------------------------------------------------------------ world model
-    def _observe(self, model, actions, nonterms, embeds, T, B, keys):
+    def _observe(self, model, actions, nonterms, embeds, T, B, noise):
         c, dev = self.c, self.device
         pr, _ = self._pg(model)
         b0 = torch.zeros(B, c.belief_size, device=dev)
         s0 = torch.zeros(B, c.state_size, device=dev)
         return ops.rssm_observe_fwd(
             pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
-            self._noise(keys[0], (T, B, c.state_size)), self._noise(keys[1], (T, B, c.state_size)), model.min_std_dev,
-            noise=self._draw(2 * T * B * c.state_size),
+            noise[0], noise[1], model.min_std_dev, noise=noise[2],
         )
 
     def train_dynamics(self, obs, actions, rewards, nonterms):
@@ -99,10 +98,26 @@ class TIA(Dreamer):
         frames = obs[1:].reshape(rows, *obs.shape[2:])
         pe, ge = self._pg(self.encoder)
         embeds, enc_saved = Fn.encoder_fwd(pe, frames)
-        # -- both filters over the same embeddings (noise order: task scan, then distractor scan: tia.py:88-121)
-        sv_t = self._observe(self.transition_model, actions, nonterms, embeds, T, B, ("obs_prior", "obs_post"))
-        sv_d = self._observe(self.distractor_transition_model, actions, nonterms, embeds, T, B,
-                             ("d_obs_prior", "d_obs_post"))
+        # -- both filters over the same embeddings (noise order: task scan, then distractor scan: tia.py:88-121).
+        #    A scan is a latency-bound kernel on ~25 CUs: the distractor's runs on the side stream beside the task's
+        main = torch.cuda.current_stream(dev)
+        side2 = self._side_stream
+        sv_t_noise = (self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self._draw(2 * T * B * S))
+        sv_d_noise = (self._noise("d_obs_prior", (T, B, S)), self._noise("d_obs_post", (T, B, S)),
+                      self._draw(2 * T * B * S))
+        if side2 is not None:
+            side2.wait_stream(main)
+            with torch.cuda.stream(side2):
+                sv_d = self._observe(self.distractor_transition_model, actions, nonterms, embeds, T, B, sv_d_noise)
+            for name in sv_d.__slots__:   # allocated on the side stream, consumed on this one
+                t = getattr(sv_d, name, None)
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
+        sv_t = self._observe(self.transition_model, actions, nonterms, embeds, T, B, sv_t_noise)
+        if side2 is not None:
+            main.wait_stream(side2)
+        else:
+            sv_d = self._observe(self.distractor_transition_model, actions, nonterms, embeds, T, B, sv_d_noise)
         feat_t = sv_t.featx[1:].reshape(rows, D + S)
         feat_d = sv_d.featx[1:].reshape(rows, D + S)
         # -- masked joint reconstruction (tia.py:123-133)
@@ -144,16 +159,22 @@ class TIA(Dreamer):
         ops.mlp_bwd(pw_t, feat_t, rt_hid, drew_t.view(rows, 1), dparams=gw_t, dx=dfeat_t)
         Fn.decoder_bwd(pd_t, feat_t, (*saved_t, dt_out), gd_t, dfeat=dfeat_t, accumulate_dfeat=True, side=side)
         dembeds = torch.empty(rows, c.embedding_size, device=dev)
-        ops.rssm_observe_bwd(pr_t, sv_t, gr_t, dfeat=dfeat_t, dpm=klg_t[0], dps=klg_t[1], dqm=klg_t[2], dqs=klg_t[3],
-                             dembeds=dembeds, min_std=self.transition_model.min_std_dev)
-        # -- distractor side: adversarial reward (input gradient only), both decoders, reverse scan
+        dembeds_d = torch.empty(rows, c.embedding_size, device=dev)
         dfeat_d = torch.empty(rows, D + S, device=dev)
+        # the task filter's reverse scan (latency-bound, ~25 CUs) runs on the side stream beside the distractor
+        # side's three compute-bound backward passes; the distractor's reverse scan follows on this stream
+        rs = side2 if side2 is not None else main
+        rs.wait_stream(main)
+        with torch.cuda.stream(rs):
+            ops.rssm_observe_bwd(pr_t, sv_t, gr_t, dfeat=dfeat_t, dpm=klg_t[0], dps=klg_t[1], dqm=klg_t[2],
+                                 dqs=klg_t[3], dembeds=dembeds, min_std=self.transition_model.min_std_dev)
+        # -- distractor side: adversarial reward (input gradient only), both decoders, reverse scan
         ops.mlp_bwd(pw_d, feat_d, rd_hid, drew_d.view(rows, 1), dparams=None, dx=dfeat_d)
         Fn.decoder_bwd(pd_d, feat_d, (*saved_d, dd_out), gd_d, dfeat=dfeat_d, accumulate_dfeat=True, side=side)
         Fn.decoder_bwd(pd_o, feat_d, saved_o, gd_o, dfeat=dfeat_d, accumulate_dfeat=True, side=side)
-        dembeds_d = torch.empty(rows, c.embedding_size, device=dev)
         ops.rssm_observe_bwd(pr_d, sv_d, gr_d, dfeat=dfeat_d, dpm=klg_d[0], dps=klg_d[1], dqm=klg_d[2], dqs=klg_d[3],
                              dembeds=dembeds_d, min_std=self.distractor_transition_model.min_std_dev)
+        main.wait_stream(rs)
         dembeds.add_(dembeds_d)
         Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=side)
         self._model_step()
