@@ -22,6 +22,7 @@
 #include "igemm.h"
 #include "dconv.h"
 #include "uconv.h"
+#include "dconv_up.h"
 
 namespace repo {
 
@@ -461,17 +462,71 @@ template <> struct UConf<GEnc4> { using type = SConf<GEnc4, 8, 1>; };
 template <> struct UConf<GX3> { using type = SConf<GX3, 1, 2>; };
 template <> struct UConf<GX4> { using type = SConf<GX4, 4, 1>; };
 
+// Direct (register-accumulating) transposed conv, dconv_up.h: tile per geometry, or NoTile = not used.  It takes
+// precedence over the scatter kernel / the gather engine where a tile is given.  A/B on one box (round 3, us):
+//   enc2@128 data gradient  gather engine 1634 -> direct 1243 (8 waves; 4 waves 1424)
+//   dec4@128 forward        gather engine  717 -> direct  535
+//   TIA conv4 forward       gather engine  775 -> direct  434
+//   enc2 data gradient      scatter        425 vs direct  606 (its K loop alone runs 424, staging +76, epilogue
+//                           +106; staggered starts, 16-byte-aligned stores and prefetching the ReLU operand under
+//                           the last chunk's MFMAs each changed nothing): the scatter kernel stays
+struct NoTile {};
+template <class G> struct UpDirect { using type = NoTile; };
+#ifndef REPO_UPD_ENC2
+#define REPO_UPD_ENC2 NoTile
+#endif
+#ifndef REPO_UPD_ENC3
+#define REPO_UPD_ENC3 NoTile
+#endif
+#ifndef REPO_UPD_ENC4
+#define REPO_UPD_ENC4 NoTile
+#endif
+#ifndef REPO_UPD_DEC2
+#define REPO_UPD_DEC2 NoTile
+#endif
+#ifndef REPO_UPD_DEC3
+#define REPO_UPD_DEC3 NoTile
+#endif
+#ifndef REPO_UPD_X2
+#define REPO_UPD_X2 DTile<128, 128, 8, 2, 4>
+#endif
+#ifndef REPO_UPD_X3
+#define REPO_UPD_X3 NoTile
+#endif
+#ifndef REPO_UPD_X4
+#define REPO_UPD_X4 NoTile
+#endif
+#ifndef REPO_UPD_Y4
+#define REPO_UPD_Y4 DTile<64, 256, 4, 2, 4>
+#endif
+#ifndef REPO_UPD_T4
+#define REPO_UPD_T4 DTile<32, 256, 4, 1, 8>
+#endif
+template <> struct UpDirect<GEnc2> { using type = REPO_UPD_ENC2; };
+template <> struct UpDirect<GEnc3> { using type = REPO_UPD_ENC3; };
+template <> struct UpDirect<GEnc4> { using type = REPO_UPD_ENC4; };
+template <> struct UpDirect<GDec2> { using type = REPO_UPD_DEC2; };
+template <> struct UpDirect<GDec3> { using type = REPO_UPD_DEC3; };
+template <> struct UpDirect<GX2> { using type = REPO_UPD_X2; };
+template <> struct UpDirect<GX3> { using type = REPO_UPD_X3; };
+template <> struct UpDirect<GX4> { using type = REPO_UPD_X4; };
+template <> struct UpDirect<GY4> { using type = REPO_UPD_Y4; };
+template <> struct UpDirect<GT4> { using type = REPO_UPD_T4; };
+template <class G> constexpr bool kUpDirect = !std::is_same<typename UpDirect<G>::type, NoTile>::value;
+
 template <class G>
 static size_t conv_up_ws_bytes() {
   using C = typename UConf<G>::type;
-  if constexpr (std::is_void<C>::value) return 0;
+  if constexpr (kUpDirect<G>) return UpGeo<G>::PACK_FLOATS * sizeof(float);
+  else if constexpr (std::is_void<C>::value) return 0;
   else return C::PACK_FLOATS * sizeof(float);
 }
 
 template <class G>
 static int conv_up_pack_t(const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
   using UC = typename UConf<G>::type;
-  if constexpr (!std::is_void<UC>::value) return launch_uconv_pack<G, UC>(w, ws, ws_bytes, s);
+  if constexpr (kUpDirect<G>) return launch_dconv_up_pack<G>(w, ws, ws_bytes, s);
+  else if constexpr (!std::is_void<UC>::value) return launch_uconv_pack<G, UC>(w, ws, ws_bytes, s);
   else return REPO_OK;  // the 3-channel layers read the native weights
 }
 
@@ -480,7 +535,9 @@ static int conv_up_t(int64_t nimg, const float* small, const float* w, const flo
                      const float* aux, int packed, void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   using UC = typename UConf<G>::type;
-  if constexpr (!std::is_void<UC>::value) {
+  if constexpr (kUpDirect<G>) {
+    return launch_dconv_up<G, typename UpDirect<G>::type>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
+  } else if constexpr (!std::is_void<UC>::value) {
     return launch_uconv_scatter<G, UC>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   } else {
     // 3-channel outputs (encoder conv1 data-gradient, plain decoder conv4) and, in the 128 x 128 stack, the outputs

@@ -54,9 +54,9 @@ def case(name, flop=None, bytes_=None):
 
 
 LAYERS = ["enc1", "enc2", "enc3", "enc4", "dec2", "dec3", "dec4", "enc1@128", "enc2@128", "enc3@128", "enc4@128", "dec4@128",
-          "dec5@128"]
+          "dec5@128", "dec4@tia"]
 for li, nm in enumerate(LAYERS):
-    if ("@128" in nm) != (IMAGE == 128) and nm != "dec3":
+    if ("@128" in nm) != (IMAGE == 128) and nm != "dec3" or ("@tia" in nm and IMAGE == 128):
         continue
     (cb, hb, _), (cs, hs, _) = ops.conv_shapes(li)
     ks = ops.CONV_GEO[li][3]
