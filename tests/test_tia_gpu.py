@@ -187,3 +187,70 @@ def test_tia_checkpoint_roundtrip_and_reconstruct(tmp_path):
     s = torch.zeros(1, cfg.state_size, device="cuda")
     with torch.no_grad():
         assert agent._reconstruct(b, s).shape == (1, 3, 64, 64)
+
+
+def test_tia_data_parallel_two_shards_equal_full_batch():
+    """Two row shards of a TIA update (threads on one GPU standing in for RCCL ranks, tests/test_host_gpu.ThreadDP)
+    with sum-all-reduced gradient buffers -- model group, distractor reward head, actor + critic -- reproduce the
+    full-batch update, and the replicas stay bit-identical."""
+    import threading
+    from fractions import Fraction
+
+    from repo_amd.parallel import shard_rows
+    from tests.test_host_gpu import ThreadDP
+
+    L, B, H, A, world = 7, 6, 5, 6, 2
+    over = dict(tia_reward_train_steps=2, free_nats=0.1)
+    T, N = L - 1, (L - 1) * B
+    batch, _ = dev_batch(L, B, A, 31)
+    nz, _ = tia_noise(L, B, H, A, 32)
+    full, _ = make_tia(L, B, H, A, **over)
+    full.noise_source = nz
+    full.update(batch)
+    s_full = dict(full.last_scalars)
+    bounds = [shard_rows(B, world, r) for r in range(world)]
+
+    def shard_noise(lo, hi):
+        nb = hi - lo
+        rows = torch.arange(T * B).view(T, B)[:, lo:hi].reshape(-1).cuda()
+        out = {k: nz[k][:, lo:hi].contiguous() for k in ("obs_prior", "obs_post", "d_obs_prior", "d_obs_post")}
+        out["img_act"] = nz["img_act"][:, rows].contiguous()
+        out["img_prior"] = nz["img_prior"][:, rows].contiguous()
+        out["entropy"] = nz["entropy"].view(100, H - 1, N, A)[:, :, rows].reshape(100, (H - 1) * T * nb, A).contiguous()
+        return out
+
+    shared = {"slot": [None] * world, "barrier": threading.Barrier(world)}
+    agents, scal, errs = [], [None] * world, []
+    for r, (lo, hi) in enumerate(bounds):
+        ag, _ = make_tia(L, hi - lo, H, A, **over)
+        ag.dp = ThreadDP(r, world, shared, Fraction(B, hi - lo))
+        ag.noise_source = shard_noise(lo, hi)
+        agents.append(ag)
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = bounds[r]
+            agents[r].update(tuple(x[:, lo:hi].contiguous() for x in batch))
+            scal[r] = dict(agents[r].last_scalars)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            shared["barrier"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for k, w in s_full.items():
+        assert abs(scal[0][k] - w) <= 2e-4 * abs(w) + 1e-6, (k, scal[0][k], w)
+    assert scal[0] == scal[1]
+    for r in range(world):
+        for name in ("model_optimizer", "d_reward_optimizer", "actor_optimizer", "value_optimizer"):
+            e = (getattr(agents[r], name).flat - getattr(full, name).flat).abs().max().item()
+            log(f"[tia dp 2 shards] rank {r} {name}: max |param diff| vs full batch {e:.2e}")
+            assert e < 2e-5, (name, e)
+    assert torch.equal(agents[0].model_optimizer.flat, agents[1].model_optimizer.flat)
+    assert torch.equal(agents[0].d_reward_optimizer.flat, agents[1].d_reward_optimizer.flat)

@@ -13,7 +13,7 @@ import re
 import sys
 
 PEAK = 157.3
-NIMG = 2450
+NIMG = 2450   # --nimg N: frames per update of the traced config (c4 / c4x128: 1568)
 
 
 def conv_flop(name):
@@ -26,12 +26,16 @@ def conv_flop(name):
 
 
 def main():
+    global NIMG
+    if "--nimg" in sys.argv:
+        NIMG = int(sys.argv[sys.argv.index("--nimg") + 1])
     path = sys.argv[1]
     rows = list(csv.DictReader(open(path)))
     # updates in the trace: one dual step (RePo) / three clip+Adam steps per update
     by = {re.sub(r"\(.*", "", re.sub(r"repo::|void ", "", r["Name"])): int(r["Calls"]) for r in rows}
+    # one lambda-return launch per update in every algorithm
     nupd = float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].replace(".", "").isdigit() else float(
-        by.get("dual_step_kernel", 0) or by.get("clip_adam_kernel", 0) / 3)
+        by.get("lambda_return_kernel", 0) or by.get("dual_step_kernel", 0) or by.get("clip_adam_kernel", 0) / 3)
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"# kernels of the update as it runs (rocprofv3 --kernel-trace --stats of bench.py, {nupd:.0f} updates in the trace)")
     print(f"# sum of kernel time per update: {tot_ns / nupd / 1e6:.2f} ms")
