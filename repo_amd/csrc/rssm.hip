@@ -15,6 +15,7 @@
 //    formed inside the scan: the reverse scan emits per-step pre-activation deltas and the
 //    weight/bias gradients become seven (T*B)-row MFMA GEMMs afterwards.
 #include "common.h"
+#include "scan_cs.h"
 
 namespace repo {
 
@@ -818,8 +819,10 @@ using namespace repo;
 
 extern "C" size_t repo_rssm_observe_fwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S, int64_t E) {
-  (void)T; (void)B; (void)E;
-  return fwd_ws_floats(A, D, Hd, S) * sizeof(float);
+  (void)E;
+  size_t f = fwd_ws_floats(A, D, Hd, S);
+  if (scan_cs_ok(T, B, A, D, Hd, S)) f = std::max(f, scan_cs_fwd_ws_floats(B, A, D, Hd, S));  // prior_only = 3
+  return f * sizeof(float);
 }
 
 extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
@@ -839,6 +842,18 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= fwd_ws_floats(A, D, Hd, S) * sizeof(float), REPO_E_WS_TOO_SMALL);
   const float* const* P = params;
+  if (prior_only == 3) {
+    // the column-split, weight-stationary engine (scan_cs.hip): prior head left out as with prior_only = 2
+    REPO_REQUIRE(scan_cs_ok(T, B, A, D, Hd, S), REPO_E_SHAPE);
+    if (T == 0) return REPO_OK;
+    int rc3 = repo_gemm(0, 1, T * B, Hd, E, embeds, E, P[10] + D, D + E, nullptr, 1, eemb, Hd, REPO_EPI_NONE, nullptr,
+                        0, 0, stream);
+    if (rc3) return rc3;
+    ScanCsFwd q{T, B, A, D, Hd, S, E, params, prev_belief, prev_state, actions, nonterms, eemb,
+                NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)}, min_std,
+                featx, post_mean, post_std, xsa, e, gates, hq};
+    return scan_cs_fwd(q, ws, ws_bytes, stream);
+  }
   float* w = (float*)ws;
   // W(n, k) = P[n*ld + k] (native (out, in) layout) -> k4-interleaved [k/4][n][4]
   const int X = (int)(S + A), d = (int)D, h = (int)Hd, s2 = (int)(2 * S);

@@ -1,0 +1,398 @@
+// Column-split, WEIGHT-STATIONARY observe scan on the fp32 matrix cores (north_star: "MFMA ... for the
+// dense hidden-to-hidden matmuls inside the GRU", "LDS staging of the deterministic/stochastic state across the
+// L-step scan").
+//
+// rssm.hip's scan gives a workgroup 1-2 batch rows and streams ALL in-scan weights (1.2 MB) from L2 every step:
+// 17-20 us per step whatever B is.  Here the weights never move: NW = ceil(D/16) workgroups each own 16 belief /
+// hidden columns -- their slices of W_ih, W_hh (6 x D x 16) and W_bq (D x 16) stay in LDS for all T steps, the two
+// small replicated layers (W_sa: (S+A) -> D, W_sq: Hd -> 2S) in registers -- and every workgroup carries the same 16
+// batch rows (one v_mfma_f32_16x16x4_f32 row tile; more rows = more independent groups of NW workgroups).  Per step:
+//   A  e = elu(W_sa x + b)                    all D columns, replicated                     (13 tiles x 3 blocks)
+//   B  GRU gates of the OWN 16 columns        K = D over e and over belief                  (6 x 13 blocks)
+//   X1 all-gather of the new belief           own slice published, NW slices gathered
+//   C  hq = elu(W_bq[:, :D] h + eemb + b)     own 16 columns, K split over the 4 waves      (13 blocks)
+//   X2 all-gather of hq
+//   D  posterior (mean, std) = W_sq hq + b    all 2S columns, replicated; sample            (4 tiles x 13 blocks)
+// An all-gather is the hand-off form measured by tools/probe/scan_exchange.hip (MI355X_MICROARCH.md's table, row 1):
+// ONE wave stores the slice with sc1 (write-through) 16-byte stores, waits vmcnt(0) and stores the step's epoch into
+// the workgroup's flag (sc1); one lane per flag polls with sc1 loads; after a workgroup barrier all threads gather
+// with sc1 16-byte loads.  2.6 us per exchange on an idle chip, 7-10 us beside a streaming kernel
+// (profiles/r03_scan_exchange_probe.txt): this engine is for the SHARDS of a strong-scaling job (B <= 16 per GPU, the
+// chip nearly idle), where a step costs ~8 us instead of 17; inside the N = 1 update at B = 50 it loses.
+// A poll that does not see its peers within `spin_limit` rounds raises the error word and the whole group leaves the
+// time loop (no hang if a peer workgroup never becomes resident).
+//
+// Prior head: not here (it is off the recurrence: repo_rssm_prior_head evaluates it for all steps at once).
+// Everything the reverse scan needs is written exactly as rssm.hip's forward writes it.
+// Reference: TransitionModel.observe, /root/reference/algorithms/repo/models/rssm.py:34-64,76-146.
+#include <algorithm>
+
+#include "rowtile.h"
+#include "scan_cs.h"
+
+namespace repo {
+
+constexpr int kSC1 = 16;  // cache-policy bit of the raw buffer builtins on gfx940+: sc1
+
+struct CsFwdArgs {
+  int T, B, A, D, Hd, S;
+  const float *Wsa, *Wih, *Whh, *Wbq, *Wsq;  // pack16 layout [k/4][N][4], K padded to 16
+  const float *bsa, *bih, *bhh, *bbq, *bsq;
+  const float *prev_belief, *prev_state, *actions, *nonterms, *eemb;
+  NoiseSrc eps_post;
+  float *featx, *post_mean, *post_std, *xsa, *e, *gates, *hq;
+  float min_std;
+  float* xbuf;      // [group][kind 2][parity 2][KP*16]
+  unsigned* flags;  // [group][NW] on 128-byte lines
+  unsigned* err;
+  int spin_limit;
+};
+
+__device__ __forceinline__ f32x4v ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kSC1));
+}
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, const f32x4v& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, kSC1);
+}
+__device__ __forceinline__ f32x4v mfma4(const f32x4v& w, const f32x4v& x, f32x4v acc) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], x[u], acc, 0, 0, 0);
+  return acc;
+}
+
+// KBX / KBD / KBH: 16-k blocks of X = S + A, of D, of Hd
+template <int KBX, int KBD, int KBH>
+__global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int DP = KBD * 16, HP = KBH * 16, XP = KBX * 16;
+  constexpr int KP = DP > HP ? DP : HP;
+  const int T = p.T, B = p.B, A = p.A, D = p.D, Hd = p.Hd, S = p.S;
+  const int X = S + A, F = D + S;
+  float* Wg = lds;                    // [6][DP*16]: W_ih r, z, n | W_hh r, z, n slices of the own columns
+  float* Wq = Wg + 6 * DP * 16;       // [DP*16]
+  float* XS = Wq + DP * 16;           // tiles, k4-interleaved: x, e, belief, hq
+  float* ES = XS + XP * 16;
+  float* HS = ES + DP * 16;
+  float* QS = HS + DP * 16;
+  float* G4 = QS + HP * 16;           // [4][16][16]: r, z, W_in e + b, W_hn h + b
+  float* PART = G4 + 4 * 256;         // [4 waves][16][16]
+  float* RAW = PART + 4 * 256;        // [16][64]
+  float* ST = RAW + 16 * 64;          // [16][32]
+  __shared__ int s_abort;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int w = blockIdx.x, NW = gridDim.x, grp = blockIdx.y;
+  const int c0 = 16 * w;
+  const int b0 = 16 * grp, nr = min(16, B - b0);
+  const int erow = tid >> 4, ecol = tid & 15;  // element role of the pointwise phases
+  const int ec = c0 + ecol;
+
+  // ---- zero the activation tiles (their K padding must stay finite), load the stationary weights
+  for (int i = tid; i < XP * 16 + 2 * DP * 16 + HP * 16 + 2 * 4 * 256 + 16 * 64 + 16 * 32; i += 256) XS[i] = 0.f;
+  if (tid == 0) s_abort = 0;
+  {
+    const f32x4v* Wih4 = reinterpret_cast<const f32x4v*>(p.Wih);
+    const f32x4v* Whh4 = reinterpret_cast<const f32x4v*>(p.Whh);
+    const f32x4v* Wbq4 = reinterpret_cast<const f32x4v*>(p.Wbq);
+    for (int i = tid; i < (DP / 4) * 16; i += 256) {
+      const int kg = i >> 4, col = min(c0 + (i & 15), D - 1), colh = min(c0 + (i & 15), Hd - 1);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        reinterpret_cast<f32x4v*>(Wg + g * DP * 16)[i] = Wih4[(size_t)kg * 3 * D + g * D + col];
+        reinterpret_cast<f32x4v*>(Wg + (3 + g) * DP * 16)[i] = Whh4[(size_t)kg * 3 * D + g * D + col];
+      }
+      reinterpret_cast<f32x4v*>(Wq)[i] = Wbq4[(size_t)kg * Hd + colh];
+    }
+  }
+  // register-stationary: W_sa tiles wave, wave+4, ... (stage A), W_sq tile `wave` (stage D)
+  constexpr int NTD = KBD;  // column tiles of D
+  f32x4v WA[4][KBX], WD[KBH], bA[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tA = wave + 4 * j, col = min(tA * 16 + li, D - 1);
+#pragma unroll
+    for (int kb = 0; kb < KBX; ++kb)
+      WA[j][kb] = reinterpret_cast<const f32x4v*>(p.Wsa)[(size_t)(kb * 4 + lq) * D + col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bA[j][r] = p.bsa[min(tA * 16 + 4 * lq + r, D - 1)];
+  }
+#pragma unroll
+  for (int kb = 0; kb < KBH; ++kb)
+    WD[kb] = reinterpret_cast<const f32x4v*>(p.Wsq)[(size_t)(kb * 4 + lq) * 2 * S + min(wave * 16 + li, 2 * S - 1)];
+  f32x4v bD, bG;  // stage D bias quad; stage B: this wave's gate bias quad (r: b_ir + b_hr, z, b_in, b_hn)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bD[r] = p.bsq[min(wave * 16 + 4 * lq + r, 2 * S - 1)];
+    const int c = min(c0 + 4 * lq + r, D - 1);
+    bG[r] = wave == 0 ? p.bih[c] + p.bhh[c] : wave == 1 ? p.bih[D + c] + p.bhh[D + c] : wave == 2 ? p.bih[2 * D + c] : p.bhh[2 * D + c];
+  }
+  const float b_q = p.bbq[min(ec, Hd - 1)];
+  __syncthreads();
+
+  // ---- slot 0: carried belief / state into the tiles; featx[0]
+  for (int i = tid; i < 16 * D; i += 256) {
+    const int row = i / D, c = i % D;
+    const float v = row < nr ? p.prev_belief[(size_t)(b0 + row) * D + c] : 0.f;
+    HS[ai(c, row)] = v;
+    if (row < nr && (c >> 4) == w) p.featx[(size_t)(b0 + row) * F + c] = v;
+  }
+  for (int i = tid; i < 16 * S; i += 256) {
+    const int row = i / S, s = i % S;
+    const float v = row < nr ? p.prev_state[(size_t)(b0 + row) * S + s] : 0.f;
+    ST[row * 32 + s] = v;
+    if (row < nr && w == 0) p.featx[(size_t)(b0 + row) * F + D + s] = v;
+  }
+
+  const __amdgpu_buffer_rsrc_t rx = wrsrc(p.xbuf + (size_t)grp * 4 * KP * 16, 4u * 4u * KP * 16);
+  unsigned* flags = p.flags + (size_t)grp * NW * 32;
+  // x-vector roles of this thread: elements tid, tid + 256, ... of the 16 x X tile
+  constexpr int XPER = (16 * XP + 255) / 256;
+  float xin[XPER];
+  auto load_x = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < XPER; ++j) {
+      const int i = tid + 256 * j, row = i / X, k = i % X;
+      const size_t gr = (size_t)t * B + b0 + row;
+      xin[j] = (i < 16 * X && row < nr) ? (k < S ? p.nonterms[gr] : p.actions[gr * A + (k - S)]) : 0.f;
+    }
+  };
+  float em_next = 0.f;
+  auto load_em = [&](int t) __attribute__((always_inline)) {
+    em_next = (erow < nr && ec < Hd) ? p.eemb[((size_t)t * B + b0 + erow) * Hd + ec] : 0.f;
+  };
+  if (T > 0) {
+    load_x(0);
+    load_em(0);
+  }
+  __syncthreads();
+
+  // all-gather of one own slice (already in `tile`, k-groups c0/4 .. c0/4+3): kind 0 = belief, 1 = hq
+  auto exchange = [&](float* tile, int kind, int t, int kp) __attribute__((always_inline)) -> bool {
+    const unsigned base = 4u * (unsigned)((kind * 2 + (t & 1)) * KP * 16);
+    const unsigned epoch = (unsigned)(2 * t + kind + 1);
+    if (wave == 0) {
+      const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + ((c0 >> 2) * 16 + lane) * 4);
+      st_sc1(rx, base + 16u * (unsigned)((c0 >> 2) * 16 + lane), v);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(flags + 32 * w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane < NW) {
+        int n = 0;
+        while (__hip_atomic_load(flags + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++n > p.spin_limit) {
+            s_abort = 1;
+            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (s_abort) return false;
+    f32x4v g[(KP * 4 + 255) / 256];
+#pragma unroll
+    for (int j = 0; j < (KP * 4 + 255) / 256; ++j) {
+      const int i = tid + 256 * j;
+      g[j] = ld_sc1(rx, i < kp * 4 ? base + 16u * (unsigned)i : 0xfffffff0u);
+    }
+#pragma unroll
+    for (int j = 0; j < (KP * 4 + 255) / 256; ++j) {
+      const int i = tid + 256 * j;
+      if (i < kp * 4) reinterpret_cast<f32x4v*>(tile)[i] = g[j];
+    }
+    __syncthreads();
+    return true;
+  };
+
+  for (int t = 0; t < T; ++t) {
+    const size_t row0 = (size_t)t * B + b0;
+    const float em = em_next;
+    // ---- x = [state * nonterm, action]
+#pragma unroll
+    for (int j = 0; j < XPER; ++j) {
+      const int i = tid + 256 * j, row = i / X, k = i % X;
+      if (i < 16 * X) {
+        const float v = row < nr ? (k < S ? ST[row * 32 + k] * xin[j] : xin[j]) : 0.f;
+        XS[ai(k, row)] = v;
+        if (w == 0 && row < nr) p.xsa[(row0 + row) * X + k] = v;
+      }
+    }
+    if (t + 1 < T) {
+      load_x(t + 1);
+      load_em(t + 1);
+    }
+    __syncthreads();
+    // ---- A: e = elu(W_sa x + b), every column tile (replicated in all workgroups); the own tile is saved
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tA = wave + 4 * j;
+      if (tA < NTD) {
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBX; ++kb)
+          acc = mfma4(WA[j][kb], *reinterpret_cast<const f32x4v*>(XS + ((kb * 4 + lq) * 16 + li) * 4), acc);
+        f32x4v v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = elu(acc[r] + bA[j][r]);
+        const int n0 = tA * 16 + 4 * lq;
+        stq(ES, n0, li, v);
+        if (tA == w && li < nr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < D) p.e[(row0 + li) * D + n0 + r] = v[r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B: GRU pre-activations of the own columns; wave 0: r, 1: z (both W_ih e + W_hh h), 2: W_in e, 3: W_hn h
+    {
+      f32x4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+      const float* wi = Wg + (wave < 3 ? wave : 0) * DP * 16;
+      const float* wh = Wg + (3 + (wave == 3 ? 2 : wave)) * DP * 16;
+#pragma unroll
+      for (int kb = 0; kb < KBD; ++kb) {
+        const int o = ((kb * 4 + lq) * 16 + li) * 4;
+        if (wave != 3) a0 = mfma4(*reinterpret_cast<const f32x4v*>(wi + o), *reinterpret_cast<const f32x4v*>(ES + o), a0);
+        if (wave != 2) a1 = mfma4(*reinterpret_cast<const f32x4v*>(wh + o), *reinterpret_cast<const f32x4v*>(HS + o), a1);
+      }
+      f32x4v v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sum = a0[r] + a1[r] + bG[r];
+        v[r] = wave < 2 ? sigmoidf(sum) : sum;
+      }
+      *reinterpret_cast<f32x4v*>(G4 + wave * 256 + li * 16 + 4 * lq) = v;
+    }
+    __syncthreads();
+    {
+      const float rg = G4[erow * 16 + ecol], zg = G4[256 + erow * 16 + ecol];
+      const float gin = G4[512 + erow * 16 + ecol], ghn = G4[768 + erow * 16 + ecol];
+      const float ng = tanh_fast(gin + rg * ghn);
+      const float hprev = HS[ai(ec, erow)];
+      const float hn = (1.f - zg) * ng + zg * hprev;
+      HS[ai(ec, erow)] = hn;  // own slice only: every product over the old belief is done (barrier above)
+      if (erow < nr && ec < D) {
+        float* g = p.gates + (row0 + erow) * 4 * D;
+        g[ec] = rg;
+        g[D + ec] = zg;
+        g[2 * D + ec] = ng;
+        g[3 * D + ec] = ghn;
+        p.featx[((size_t)(t + 1) * B + b0 + erow) * F + ec] = hn;
+      }
+    }
+    __syncthreads();
+    if (!exchange(HS, 0, t, DP)) return;
+    // ---- C: hq = elu(W_bq[:, :D] h + eemb + b), own columns, K split over the waves
+    {
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+      const int kb0 = (wave * KBD) / 4, kb1 = ((wave + 1) * KBD) / 4;
+      for (int kb = kb0; kb < kb1; ++kb) {
+        const int o = ((kb * 4 + lq) * 16 + li) * 4;
+        acc = mfma4(*reinterpret_cast<const f32x4v*>(Wq + o), *reinterpret_cast<const f32x4v*>(HS + o), acc);
+      }
+      *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = acc;
+    }
+    __syncthreads();
+    {
+      const int o = erow * 16 + ecol;
+      const float v = elu(PART[o] + PART[256 + o] + PART[512 + o] + PART[768 + o] + em + b_q);
+      QS[ai(ec, erow)] = v;
+      if (erow < nr && ec < Hd) p.hq[(row0 + erow) * Hd + ec] = v;
+    }
+    __syncthreads();
+    if (!exchange(QS, 1, t, HP)) return;
+    // ---- D: posterior (mean | raw std) = W_sq hq + b, replicated; softplus + sample
+    {
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KBH; ++kb)
+        acc = mfma4(WD[kb], *reinterpret_cast<const f32x4v*>(QS + ((kb * 4 + lq) * 16 + li) * 4), acc);
+      *reinterpret_cast<f32x4v*>(RAW + li * 64 + wave * 16 + 4 * lq) = acc + bD;
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * S; i += 256) {
+      const int row = i / S, s = i % S;
+      const float mean = RAW[row * 64 + s];
+      const float sd = softplus(RAW[row * 64 + S + s]) + p.min_std;
+      float smp = 0.f;
+      if (row < nr) {
+        const size_t o = (row0 + row) * S + s;
+        smp = fmaf(sd, p.eps_post.at(o), mean);
+        if (w == 0) {
+          p.post_mean[o] = mean;
+          p.post_std[o] = sd;
+          p.featx[((size_t)(t + 1) * B + b0 + row) * F + D + s] = smp;
+        }
+      }
+      ST[row * 32 + s] = smp;
+    }
+    __syncthreads();
+  }
+}
+
+static size_t cs_pack_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  return pack_floats(D, S + A) + 2 * pack_floats(3 * D, D) + pack_floats(Hd, D) + pack_floats(2 * S, Hd);
+}
+
+bool scan_cs_ok(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  (void)T;
+  // one instantiation: the reference shapes (belief = hidden = 200 -> 13 blocks, S + A <= 48, 2 S <= 64)
+  return B > 0 && pad16((int)D) == 208 && pad16((int)Hd) == 208 && pad16((int)(S + A)) == 48 && 2 * S <= 64 && S <= 32 &&
+         D % 4 == 0;
+}
+
+size_t scan_cs_fwd_ws_floats(int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  const int64_t G = (B + 15) / 16, NW = (std::max(D, Hd) + 15) / 16, KP = pad16((int)std::max(D, Hd));
+  return cs_pack_floats(A, D, Hd, S) + (size_t)(G * 4 * KP * 16) + (size_t)(G * NW * 32) + 32;
+}
+
+int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!scan_cs_ok(q.T, q.B, q.A, q.D, q.Hd, q.S)) return REPO_E_SHAPE;
+  if (!ws || ws_bytes < scan_cs_fwd_ws_floats(q.B, q.A, q.D, q.Hd, q.S) * sizeof(float)) return REPO_E_WS_TOO_SMALL;
+  const int d = (int)q.D, h = (int)q.Hd, X = (int)(q.S + q.A), s2 = (int)(2 * q.S);
+  const float* const* P = q.params;
+  float* w = (float*)ws;
+  float* Wsa = w;  w += pack_floats(d, X);
+  float* Wih = w;  w += pack_floats(3 * d, d);
+  float* Whh = w;  w += pack_floats(3 * d, d);
+  float* Wbq = w;  w += pack_floats(h, d);
+  float* Wsq = w;  w += pack_floats(s2, h);
+  const int64_t G = (q.B + 15) / 16, NW = (std::max(q.D, q.Hd) + 15) / 16, KP = pad16((int)std::max(q.D, q.Hd));
+  float* xbuf = w;  w += G * 4 * KP * 16;
+  unsigned* flags = (unsigned*)w;  w += G * NW * 32;
+  unsigned* err = (unsigned*)w;
+  PackArgs pa;
+  pa.njobs = 0;
+  pa.job[pa.njobs++] = PackJob{P[0], Wsa, d, X, X, 1};
+  pa.job[pa.njobs++] = PackJob{P[2], Wih, 3 * d, d, d, 1};
+  pa.job[pa.njobs++] = PackJob{P[3], Whh, 3 * d, d, d, 1};
+  pa.job[pa.njobs++] = PackJob{P[10], Wbq, h, d, (int)(q.D + q.E), 1};
+  pa.job[pa.njobs++] = PackJob{P[12], Wsq, s2, h, h, 1};
+  int rc = launch_pack(pa, s);
+  if (rc) return rc;
+  hipError_t he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
+  if (he != hipSuccess) return (int)he;
+  if (q.T == 0) return REPO_OK;
+  CsFwdArgs a;
+  a.T = (int)q.T; a.B = (int)q.B; a.A = (int)q.A; a.D = d; a.Hd = h; a.S = (int)q.S;
+  a.Wsa = Wsa; a.Wih = Wih; a.Whh = Whh; a.Wbq = Wbq; a.Wsq = Wsq;
+  a.bsa = P[1]; a.bih = P[4]; a.bhh = P[5]; a.bbq = P[11]; a.bsq = P[13];
+  a.prev_belief = q.prev_belief; a.prev_state = q.prev_state; a.actions = q.actions; a.nonterms = q.nonterms;
+  a.eemb = q.eemb; a.eps_post = q.eps_post;
+  a.featx = q.featx; a.post_mean = q.post_mean; a.post_std = q.post_std; a.xsa = q.xsa; a.e = q.e; a.gates = q.gates;
+  a.hq = q.hq; a.min_std = q.min_std;
+  a.xbuf = xbuf; a.flags = flags; a.err = err;
+  a.spin_limit = 1 << 22;
+  constexpr int DP = 208, HP = 208, XP = 48;
+  const size_t lds_b = (size_t)(7 * DP * 16 + XP * 16 + 2 * DP * 16 + HP * 16 + 2 * 4 * 256 + 16 * 64 + 16 * 32) * sizeof(float);
+  he = hipFuncSetAttribute((const void*)observe_cs_fwd_kernel<3, 13, 13>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                           (int)lds_b);
+  if (he != hipSuccess) return (int)he;
+  hipLaunchKernelGGL((observe_cs_fwd_kernel<3, 13, 13>), dim3((unsigned)NW, (unsigned)G), dim3(256), lds_b, s, a);
+  he = hipGetLastError();
+  return he == hipSuccess ? REPO_OK : (int)he;
+}
+
+}  // namespace repo

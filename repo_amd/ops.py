@@ -5,6 +5,8 @@ and the current HIP stream to librepo_hip.so, and returns the output tensor.  Py
 used for device memory and streams only -- there is no eager/CPU fallback here: a missing
 library or a CPU tensor raises.
 """
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -307,18 +309,34 @@ def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds,
     nb = lib().repo_rssm_observe_fwd_workspace_bytes(T, B, A, D, Hd, S, E)
     ws = workspace(nb, dev)
     pa = ptr_array(params)
+    # engine: the column-split, weight-stationary MFMA scan (csrc/scan_cs.hip, mode 3) pays where the chip is nearly
+    # idle -- the <= 16-row shards of a strong-scaling job (~8 us per step instead of 17); REPO_SCAN_CS=1 / 0 forces it
+    # on / off for any B.  It always leaves the prior head to repo_rssm_prior_head.
+    cs_env = os.environ.get("REPO_SCAN_CS", "auto")
+    use_cs = (not prior_only and cs_env != "0" and (cs_env == "1" or B <= 16)
+              and (D + 15) // 16 == 13 and (Hd + 15) // 16 == 13 and (S + A + 15) // 16 == 3 and S <= 32 and D % 4 == 0)
+    hoist = (prior_stream is not None or use_cs) and not prior_only
     check(
         lib().repo_rssm_observe_fwd(
             T, B, A, D, Hd, S, E, pa, _ptr(_f32c(prev_belief)), _ptr(_f32c(prev_state)), _ptr(_f32c(actions)),
             _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior), _ptr(sv.eps_post), sv.noise[0], sv.noise[1],
             float(min_std), _ptr(sv.featx), _ptr(sv.prior_state), _ptr(sv.prior_mean), _ptr(sv.prior_std), _ptr(sv.post_mean),
             _ptr(sv.post_std), _ptr(sv.xsa), _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(eemb),
-            2 if (prior_stream is not None and not prior_only) else int(prior_only), _ptr(ws), ws.numel(), _stream(),
+            3 if use_cs else 2 if hoist else int(prior_only), _ptr(ws), ws.numel(), _stream(),
         ),
         "repo_rssm_observe_fwd",
     )
     sv.prior_ready = None
-    if prior_stream is not None and not prior_only:
+    if hoist and prior_stream is None:   # the prior head of all steps, in line
+        nbp = lib().repo_rssm_prior_head_workspace_bytes(T, B, S)
+        wsp = workspace(nbp, dev)
+        check(
+            lib().repo_rssm_prior_head(T, B, D, Hd, S, pa, _ptr(sv.featx), _ptr(sv.eps_prior), sv.noise[0], sv.noise[1],
+                                       float(min_std), _ptr(sv.hp), _ptr(sv.prior_state), _ptr(sv.prior_mean),
+                                       _ptr(sv.prior_std), _ptr(wsp), nbp, _stream()),
+            "repo_rssm_prior_head",
+        )
+    elif hoist:
         main = torch.cuda.current_stream(dev)
         prior_stream.wait_stream(main)
         nbp = lib().repo_rssm_prior_head_workspace_bytes(T, B, S)

@@ -483,3 +483,35 @@ def test_prior_head_hoisted_out_of_the_scan_matches_in_scan_prior():
         for name in ("prior_mean", "prior_std", "prior_state", "hp"):
             np.testing.assert_allclose(getattr(h, name).cpu().numpy(), getattr(a, name).cpu().numpy(), rtol=2e-5, atol=2e-6,
                                        err_msg=name)
+
+
+@pytest.mark.parametrize("T,B,A,philox", [(9, 3, 6, False), (49, 7, 6, True), (12, 16, 7, False), (6, 17, 6, True),
+                                          (5, 50, 6, False)])
+def test_column_split_scan_matches_row_scan(monkeypatch, T, B, A, philox):
+    """csrc/scan_cs.hip (weight-stationary MFMA scan: 13 column-owner workgroups per 16 rows, two all-gathers per step)
+    against rssm.hip's row scan: every saved tensor within MFMA-vs-FMA summation-order rounding, with explicit noise
+    tensors and with in-kernel Philox noise; ragged row groups (17 = 16 + 1, 50 = 3 x 16 + 2) and A = 7 included."""
+    from repo_amd import ops
+
+    D, S, E = 200, 30, 1024
+    rs = np.random.RandomState(1000 * T + B)
+    p = cu(tparams("transition_model", A, requires_grad=False))
+    dev = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()  # noqa: E731
+    b0, s0 = dev(rs.standard_normal((B, D)) * 0.3), dev(rs.standard_normal((B, S)))
+    act = dev(rs.uniform(-1, 1, (T, B, A)))
+    non = dev(rs.uniform(size=(T, B)) > 0.15)
+    emb = dev(np.maximum(rs.standard_normal((T, B, E)), 0))
+    eps = (None, None) if philox else (dev(rs.standard_normal((T, B, S))), dev(rs.standard_normal((T, B, S))))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("REPO_SCAN_CS", mode)
+        out[mode] = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, eps[0], eps[1], 0.1, noise=(5, 64))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for name in ("featx", "post_mean", "post_std", "hq", "gates", "e", "xsa", "prior_mean", "prior_std", "prior_state", "hp"):
+        a, b = getattr(out["0"], name), getattr(out["1"], name)
+        assert torch.isfinite(b).all(), name
+        err = float((a - b).abs().max() / (a.abs().max() + 1e-12))
+        worst = max(worst, err)
+        assert err < 2e-5, (name, err)
+    log(f"column-split scan T={T} B={B} A={A} philox={philox}: worst rel-to-max error vs the row scan {worst:.2e}")
