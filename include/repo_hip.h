@@ -202,6 +202,11 @@ int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStre
  * Saved for backward: xsa (T,B,S+A), e (T,B,D), gates (T,B,4D) = r|z|n|W_hn h+b_hn,
  *          hp, hq (T,B,Hd); eemb (T,B,Hd) is scratch for the hoisted embedding GEMM.
  * prior_only == 2: the scan leaves the prior head out (repo_rssm_prior_head below computes it for all steps).
+ * prior_only == 3: as 2, on the COLUMN-SPLIT, WEIGHT-STATIONARY engine (csrc/scan_cs.hip): ceil(D/16) workgroups per
+ *          16 batch rows each keep their 16-column slices of W_ih / W_hh / W_bq in LDS for all T steps, the row tile
+ *          runs on v_mfma_f32_16x16x4_f32 and the belief / posterior-hidden activations are all-gathered through L2
+ *          twice per step (sc1 stores + flags).  ~12.5 us per step for any B <= 64 (the row scan: 18-20); shapes
+ *          D, Hd in (192, 208], S + A in (32, 48], S <= 32 only (else REPO_E_SHAPE).
  * prior_only == 1: the reference's `observations=None` branch (rssm.py:118): step t+1 is fed the PRIOR sample of
  *          step t, featx[t+1][D:] = prior sample; the posterior outputs are then computed from whatever
  *          `embeds` holds and mean nothing (forward only: repo_rssm_observe_bwd assumes prior_only == 0). */
@@ -235,7 +240,10 @@ int repo_rssm_prior_head(int64_t T, int64_t B, int64_t D, int64_t Hd, int64_t S,
  * pointers (same order/shapes as params) receiving the gradients ((+)= if accumulate);
  * dembeds (T,B,E), dprev_belief (B,D), dprev_state (B,S) are nullable.
  * Replaces autograd's traversal of the 49-step graph in model_loss.backward()
- * (algorithms/repo/repo.py:88 / dreamer.py:287). */
+ * (algorithms/repo/repo.py:88 / dreamer.py:287).
+ * `accumulate`: bit 0 = accumulate into dparams; bit 1 (value 2) = run the reverse scan on the column-split,
+ * weight-stationary engine (csrc/scan_cs.hip; D, Hd in (192, 208], S + A in (32, 48], S <= 32 only, else
+ * REPO_E_SHAPE), the counterpart of repo_rssm_observe_fwd(prior_only = 3). */
 size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
                                              int64_t S, int64_t E);
 int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,

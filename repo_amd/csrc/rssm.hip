@@ -976,6 +976,20 @@ static void obs_wgrad_jobs(WgradDesc* j, int64_t R_, int64_t B, int64_t A, int64
   j[6] = WgradDesc{R_, D, X, de, D, xsa, X, g(0), X, g(1)};
 }
 
+// output deltas of the PRIOR head for all steps (they depend on upstream gradients only, not on the recurrence)
+__global__ void prior_delta_kernel(int n, int S, const float* __restrict__ dstate, const float* __restrict__ dpm,
+                                   const float* __restrict__ dps, const float* __restrict__ prior_std, NoiseSrc eps,
+                                   float min_std, float* __restrict__ doutp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int row = i / S, s = i % S;
+    const float dsmp = dstate ? dstate[i] : 0.f;
+    const float dm = (dpm ? dpm[i] : 0.f) + dsmp;
+    const float dsd = fmaf(dsmp, eps.at(i), dps ? dps[i] : 0.f);
+    doutp[(size_t)row * 2 * S + s] = dm;
+    doutp[(size_t)row * 2 * S + S + s] = dsd * (-expm1f(-(prior_std[i] - min_std)));
+  }
+}
+
 extern "C" size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S, int64_t E) {
   // deltas + the largest wgrad slab
@@ -990,6 +1004,10 @@ extern "C" size_t repo_rssm_observe_bwd_workspace_bytes(int64_t T, int64_t B, in
   if (big > slab) slab = big;
   const size_t packs = bwd_pack_floats(A, D, Hd, S) * sizeof(float);  // live only during the scan kernel
   if (packs > slab) slab = packs;
+  if (scan_cs_ok(T, B, A, D, Hd, S)) {  // column-split engine: its packs and exchange buffers + the prior head's d belief
+    const size_t cs = (scan_cs_bwd_ws_floats(B, A, D, Hd, S) + rows * (size_t)D) * sizeof(float) + 256;
+    if (cs > slab) slab = cs;
+  }
   return deltas * sizeof(float) + slab + 256;
 }
 
@@ -1024,6 +1042,29 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
   const size_t slab_bytes = ws_bytes - (sl - (uintptr_t)ws);
 
   const float* const* P = params;
+  const bool cs_engine = (accumulate & 2) != 0;
+  accumulate &= 1;
+  if (cs_engine) {
+    // column-split, weight-stationary reverse scan (scan_cs.hip).  The prior head is off the recurrence: its output
+    // deltas, its hidden delta and its share of d belief_t are three launches over all T*B rows, in front of the scan
+    REPO_REQUIRE(scan_cs_ok(T, B, A, D, Hd, S), REPO_E_SHAPE);
+    const int n = (int)(rows * S);
+    hipLaunchKernelGGL(prior_delta_kernel, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, stream, n, (int)S,
+                       dprior_state, dpm, dps, prior_std, NoiseSrc{eps_prior, noise_seed, noise_offset}, min_std, doutp);
+    REPO_CHECK_LAUNCH();
+    int rc1 = repo_gemm(0, 0, (int64_t)rows, Hd, 2 * S, doutp, 2 * S, P[8], Hd, nullptr, 1, dhp, Hd, REPO_EPI_MUL_DELU, hp,
+                        Hd, 0, stream);
+    if (rc1) return rc1;
+    float* dbx = (float*)slab;
+    if ((rc1 = repo_gemm(0, 0, (int64_t)rows, D, Hd, dhp, Hd, P[6], D, nullptr, 1, dbx, D, REPO_EPI_NONE, nullptr, 0, 0,
+                         stream)))
+      return rc1;
+    void* cws = (void*)(((uintptr_t)(dbx + rows * D) + 255) & ~(uintptr_t)255);
+    ScanCsBwd q{T, B, A, D, Hd, S, E, params, nonterms,
+                NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)}, min_std,
+                featx, post_std, e, gates, hq, dfeat, dqm, dqs, dbx, doutq, dhq, dgi, dgh, de, dprev_belief, dprev_state};
+    if ((rc1 = scan_cs_bwd(q, cws, slab_bytes - ((uintptr_t)cws - (uintptr_t)slab), stream))) return rc1;
+  } else {
   ObsBwdArgs a;
   a.d = ObsDims{(int)T, (int)B, (int)A, (int)D, (int)Hd, (int)S};
   {  // packed weights at the head of the slab region: dead before the first weight-gradient GEMM uses it
@@ -1063,6 +1104,7 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
   }
   REPO_CHECK_LAUNCH();
 
+  }
   // deferred weight/bias gradients: (T*B)-row MFMA GEMMs
   float* const* G = dparams;
   const int64_t R_ = (int64_t)rows;

@@ -20,4 +20,20 @@ struct ScanCsFwd {
 // packs the weights, clears the flags and launches the scan; eemb (the hoisted embed product) must be complete on `s`
 int scan_cs_fwd(const ScanCsFwd& a, void* ws, size_t ws_bytes, hipStream_t s);
 
+// ---- reverse scan (posterior path; the prior head's share of d belief_t comes in as `dbx`, computed for all steps
+// by the caller: it is off the recurrence)
+struct ScanCsBwd {
+  int64_t T, B, A, D, Hd, S, E;
+  const float* const* params;
+  const float* nonterms;
+  NoiseSrc eps_post;
+  float min_std;
+  const float *featx, *post_std, *e, *gates, *hq;  // saved by the forward scan
+  const float *dfeat, *dqm, *dqs, *dbx;            // upstream, each nullable: (T,B,D+S), (T,B,S) x2, (T,B,D)
+  float *doutq, *dhq, *dgi, *dgh, *de;             // per-step deltas: (T,B,2S) (T,B,Hd) (T,B,3D) x2 (T,B,D)
+  float *dprev_belief, *dprev_state;               // nullable
+};
+size_t scan_cs_bwd_ws_floats(int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S);
+int scan_cs_bwd(const ScanCsBwd& a, void* ws, size_t ws_bytes, hipStream_t s);
+
 }  // namespace repo

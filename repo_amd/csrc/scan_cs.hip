@@ -395,4 +395,380 @@ int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   return he == hipSuccess ? REPO_OK : (int)he;
 }
 
+// ======================================================================================= reverse scan
+// The same column-split layout, walked backwards.  Workgroup w owns belief / hidden columns [16w, 16w+16):
+//   a  posterior output deltas (mean, raw std) from d state (upstream + carried), KL gradients    pointwise, replicated
+//   1  dhq = (W_sq^T d out) * elu'(hq)          all Hd columns, replicated (W_sq^T in registers)   13 tiles x 4 blocks
+//   2  d belief = carried + upstream + prior share + W_bq^T dhq   own columns, K split over waves  13 blocks
+//   d  GRU pointwise: d gates of the own columns; carried d belief = d belief * z
+//   X1 all-gather of (g_r, g_z, g_n, g_hn)      four tiles
+//   3  d belief_{t-1} += W_hh^T d gh ; d e = W_ih^T d gi          own columns, K = 3D, K split     78 blocks
+//   X2 all-gather of d e_pre = d e * elu'(e)
+//   4  d state_{t-1} = (W_sa[:, :S]^T d e_pre) * nonterm          replicated (W_sa^T in registers) 2 tiles x 13 blocks
+// LDS-resident: the own-column slices of W_hh^T and W_ih^T (2 x 3 x D x 16 floats = 80 KB).
+struct CsBwdArgs {
+  int T, B, A, D, Hd, S;
+  const float *WsqT, *WbqT, *WhhT, *WihT, *WsaT;  // pack16: [k/4][N][4]; WhhT / WihT: 3 packs (one per gate) back to back
+  const float *nonterms, *featx, *post_std, *e, *gates, *hq;
+  NoiseSrc eps_post;
+  const float *dfeat, *dqm, *dqs, *dbx;
+  float *doutq, *dhq, *dgi, *dgh, *de, *dprev_belief, *dprev_state;
+  float min_std;
+  float* xbuf;      // [group][parity 2][5 tiles][KP*16]: tiles 0..3 = g_r, g_z, g_n, g_hn; 4 = d e_pre
+  unsigned* flags;
+  unsigned* err;
+  int spin_limit;
+};
+
+template <int KBD, int KBH>
+__global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int DP = KBD * 16, HP = KBH * 16, KP = DP > HP ? DP : HP, TS = KP * 16;  // TS: floats of a tile
+  constexpr int KBO = 4;  // 16-k blocks of 2S (<= 64)
+  const int T = p.T, B = p.B, D = p.D, Hd = p.Hd, S = p.S;
+  const int F = D + S;
+  float* Wh = lds;               // [3][DP*16]: W_hh^T slices, gates r, z, n(hn)
+  float* Wi = Wh + 3 * DP * 16;  // [3][DP*16]: W_ih^T slices, gates r, z, n
+  float* G = Wi + 3 * DP * 16;   // [4][TS]: g_r, g_z, g_n, g_hn tiles; G[3] doubles as the dhq tile, G[0] as d e_pre
+  float* DO = G + 4 * TS;        // [64 x 16] posterior output deltas
+  float* PART = DO + 64 * 16;    // [2][4][256]
+  float* DST = PART + 2 * 4 * 256;  // [16][32] carried d state
+  __shared__ int s_abort;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int w = blockIdx.x, NW = gridDim.x, grp = blockIdx.y;
+  const int c0 = 16 * w;
+  const int b0 = 16 * grp, nr = min(16, B - b0);
+  const int erow = tid >> 4, ecol = tid & 15, ec = c0 + ecol;
+  const bool e_ok = erow < nr && ec < D, h_ok = erow < nr && ec < Hd;
+
+  for (int i = tid; i < 4 * TS + 64 * 16 + 2 * 4 * 256 + 16 * 32; i += 256) G[i] = 0.f;
+  if (tid == 0) s_abort = 0;
+  for (int i = tid; i < (DP / 4) * 16; i += 256) {
+    const int kg = i >> 4, col = min(c0 + (i & 15), D - 1);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      reinterpret_cast<f32x4v*>(Wh + g * DP * 16)[i] =
+          reinterpret_cast<const f32x4v*>(p.WhhT + (size_t)g * DP * D)[(size_t)kg * D + col];
+      reinterpret_cast<f32x4v*>(Wi + g * DP * 16)[i] =
+          reinterpret_cast<const f32x4v*>(p.WihT + (size_t)g * DP * D)[(size_t)kg * D + col];
+    }
+  }
+  // register-stationary weights
+  constexpr int NTH = KBH;
+  f32x4v W1[4][KBO];  // stage 1: W_sq^T, hidden-column tiles wave, wave + 4, ...
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int kb = 0; kb < KBO; ++kb)
+      W1[j][kb] = reinterpret_cast<const f32x4v*>(p.WsqT)[(size_t)(kb * 4 + lq) * Hd + min((wave + 4 * j) * 16 + li, Hd - 1)];
+  constexpr int KB2 = (KBH + 3) / 4;  // stage 2: this wave's blocks of the K = Hd reduction
+  const int kb2_0 = (wave * KBH) / 4, kb2_1 = ((wave + 1) * KBH) / 4;
+  f32x4v W2[KB2];
+#pragma unroll
+  for (int x = 0; x < KB2; ++x)
+    W2[x] = reinterpret_cast<const f32x4v*>(p.WbqT)[(size_t)((min(kb2_0 + x, KBH - 1)) * 4 + lq) * D + min(c0 + li, D - 1)];
+  // stage 4: d state tile (wave & 1), K half (wave >> 1)
+  constexpr int KB4 = (KBD + 1) / 2;
+  const int kb4_0 = (wave >> 1) * KB4;
+  f32x4v W4[KB4];
+#pragma unroll
+  for (int x = 0; x < KB4; ++x)
+    W4[x] = reinterpret_cast<const f32x4v*>(p.WsaT)[(size_t)(min(kb4_0 + x, KBD - 1) * 4 + lq) * S + min((wave & 1) * 16 + li, S - 1)];
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rx = wrsrc(p.xbuf + (size_t)grp * 2 * 5 * TS, 4u * 2u * 5u * TS);
+  unsigned* flags = p.flags + (size_t)grp * NW * 32;
+  const __amdgpu_buffer_rsrc_t rhq = arsrc(p.hq);
+
+  // ---- per-step operands, fetched one step ahead
+  constexpr int SPER = 2;  // (row, s) roles of the pointwise output stage: 16 * S <= 512
+  struct StepIn {
+    float dsm[SPER], dm[SPER], dsd[SPER], sd[SPER], nt[SPER];
+    f32x4v hq4[4];
+    float dfb, g_r, g_z, g_n, g_hn, hprev, ev;
+  } in;
+  auto load_step = [&](int t) __attribute__((always_inline)) {
+    const size_t row0 = (size_t)t * B + b0;
+#pragma unroll
+    for (int j = 0; j < SPER; ++j) {
+      const int i = tid + 256 * j, row = i / S, s = i % S;
+      const bool ok = i < 16 * S && row < nr;
+      const size_t o = (row0 + row) * S + s;
+      in.dsm[j] = (ok && p.dfeat) ? p.dfeat[(row0 + row) * F + D + s] : 0.f;
+      in.dm[j] = (ok && p.dqm) ? p.dqm[o] : 0.f;
+      in.dsd[j] = (ok && p.dqs) ? p.dqs[o] : 0.f;
+      in.sd[j] = ok ? p.post_std[o] : 1.f;
+      in.nt[j] = ok ? p.nonterms[row0 + row] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n0 = (wave + 4 * j) * 16 + 4 * lq;
+      const bool ok = (wave + 4 * j) < NTH && li < nr && n0 + 3 < Hd;
+      in.hq4[j] = ok ? bldq(rhq, 4u * (unsigned)(li * Hd + n0), 4u * (unsigned)(row0 * Hd)) : f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (!ok && (wave + 4 * j) < NTH && li < nr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in.hq4[j][r] = n0 + r < Hd ? p.hq[(row0 + li) * Hd + n0 + r] : 0.f;
+      }
+    }
+    const float* g = p.gates + (row0 + erow) * 4 * D;
+    in.dfb = e_ok ? ((p.dfeat ? p.dfeat[(row0 + erow) * F + ec] : 0.f) + (p.dbx ? p.dbx[(row0 + erow) * D + ec] : 0.f)) : 0.f;
+    in.g_r = e_ok ? g[ec] : 0.f;
+    in.g_z = e_ok ? g[D + ec] : 0.f;
+    in.g_n = e_ok ? g[2 * D + ec] : 0.f;
+    in.g_hn = e_ok ? g[3 * D + ec] : 0.f;
+    in.hprev = e_ok ? p.featx[((size_t)t * B + b0 + erow) * F + ec] : 0.f;
+    in.ev = e_ok ? p.e[(row0 + erow) * D + ec] : 0.f;
+  };
+  if (T > 0) load_step(T - 1);
+  float dh = 0.f;  // carried d belief of element (erow, ec)
+
+  // all-gather of `nt` own slices starting at tile index `t0` of this step's parity block
+  auto exchange = [&](int t0, int nt, float* tiles, unsigned epoch, int par) __attribute__((always_inline)) -> bool {
+    const unsigned base = 4u * (unsigned)((par * 5 + t0) * TS);
+    if (wave == 0) {
+      for (int x = 0; x < nt; ++x) {
+        const f32x4v v = *reinterpret_cast<const f32x4v*>(tiles + x * TS + ((c0 >> 2) * 16 + lane) * 4);
+        st_sc1(rx, base + 4u * (unsigned)(x * TS) + 16u * (unsigned)((c0 >> 2) * 16 + lane), v);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(flags + 32 * w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane < NW) {
+        int n = 0;
+        while (__hip_atomic_load(flags + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++n > p.spin_limit) {
+            s_abort = 1;
+            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (s_abort) return false;
+    const int nv = nt * TS / 4;
+    for (int i0 = 0; i0 < nv; i0 += 256 * 8) {
+      f32x4v g[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + tid + 256 * j;
+        g[j] = ld_sc1(rx, i < nv ? base + 16u * (unsigned)i : 0xfffffff0u);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + tid + 256 * j;
+        if (i < nv) reinterpret_cast<f32x4v*>(tiles)[i] = g[j];
+      }
+    }
+    __syncthreads();
+    return true;
+  };
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t row0 = (size_t)t * B + b0;
+    const int step = T - 1 - t;
+    // ---- a: posterior output deltas
+#pragma unroll
+    for (int j = 0; j < SPER; ++j) {
+      const int i = tid + 256 * j, row = i / S, s = i % S;
+      if (i < 16 * S) {
+        float dm = 0.f, draw = 0.f;
+        if (row < nr) {
+          const size_t o = (row0 + row) * S + s;
+          const float dsmp = in.dsm[j] + DST[row * 32 + s];
+          dm = in.dm[j] + dsmp;
+          const float dsd = fmaf(dsmp, p.eps_post.at(o), in.dsd[j]);
+          draw = dsd * (-expm1f(-(in.sd[j] - p.min_std)));
+          if (w == 0) {
+            p.doutq[(row0 + row) * 2 * S + s] = dm;
+            p.doutq[(row0 + row) * 2 * S + S + s] = draw;
+          }
+        }
+        DO[ai(s, row)] = dm;
+        DO[ai(S + s, row)] = draw;
+      }
+    }
+    const float nt0 = in.nt[0], nt1 = in.nt[1];
+    __syncthreads();
+    // ---- 1: dhq = (W_sq^T d out) * elu'(hq), every hidden tile (replicated); the own tile is saved.  Into G[3].
+    float* QD = G + 3 * TS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tA = wave + 4 * j;
+      if (tA < NTH) {
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBO; ++kb)
+          acc = mfma4(W1[j][kb], *reinterpret_cast<const f32x4v*>(DO + ((kb * 4 + lq) * 16 + li) * 4), acc);
+        f32x4v v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = li < nr ? acc[r] * elu_grad_from_out(in.hq4[j][r]) : 0.f;
+        const int n0 = tA * 16 + 4 * lq;
+        stq(QD, n0, li, v);
+        if (tA == w && li < nr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < Hd) p.dhq[(row0 + li) * Hd + n0 + r] = v[r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 2: d belief (own columns) = carried + upstream + W_bq^T dhq, K split over the waves
+    {
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int x = 0; x < KB2; ++x)
+        if (kb2_0 + x < kb2_1)
+          acc = mfma4(W2[x], *reinterpret_cast<const f32x4v*>(QD + (((kb2_0 + x) * 4 + lq) * 16 + li) * 4), acc);
+      *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = acc;
+    }
+    __syncthreads();
+    // ---- d: GRU pointwise on element (erow, ec)
+    {
+      const int o = erow * 16 + ecol;
+      const float db_ = dh + in.dfb + PART[o] + PART[256 + o] + PART[512 + o] + PART[768 + o];
+      float g_r = 0.f, g_z = 0.f, g_n = 0.f, g_hn = 0.f, dhprev = 0.f;
+      if (e_ok) {
+        const float rg = in.g_r, zg = in.g_z, ng = in.g_n, ghn = in.g_hn;
+        const float dn = db_ * (1.f - zg), dz = db_ * (in.hprev - ng);
+        dhprev = db_ * zg;
+        g_n = dn * (1.f - ng * ng);
+        g_hn = g_n * rg;
+        g_r = g_n * ghn * rg * (1.f - rg);
+        g_z = dz * zg * (1.f - zg);
+        float* gi = p.dgi + (row0 + erow) * 3 * D;
+        float* gh = p.dgh + (row0 + erow) * 3 * D;
+        gi[ec] = g_r;
+        gi[D + ec] = g_z;
+        gi[2 * D + ec] = g_n;
+        gh[ec] = g_r;
+        gh[D + ec] = g_z;
+        gh[2 * D + ec] = g_hn;
+      }
+      dh = dhprev;
+      const int a_ = ai(ec, erow);
+      // (G[3] held dhq: every read of it is behind the barrier above)
+      G[a_] = g_r;
+      G[TS + a_] = g_z;
+      G[2 * TS + a_] = g_n;
+      G[3 * TS + a_] = g_hn;
+    }
+    __syncthreads();
+    if (!exchange(0, 4, G, (unsigned)(2 * step + 1), step & 1)) return;
+    // ---- 3: d belief_{t-1} += W_hh^T (g_r, g_z, g_hn);  d e = W_ih^T (g_r, g_z, g_n): own columns, K = 3 D split
+    //         over the waves as (gate, block) pairs
+    {
+      f32x4v ah = {0.f, 0.f, 0.f, 0.f}, ae = ah;
+      constexpr int NB3 = 3 * KBD;
+      const int x0 = (wave * NB3) / 4, x1 = ((wave + 1) * NB3) / 4;
+      for (int x = x0; x < x1; ++x) {
+        const int g = x / KBD, kb = x % KBD;
+        const int o = ((kb * 4 + lq) * 16 + li) * 4;
+        const f32x4v gi4 = *reinterpret_cast<const f32x4v*>(G + g * TS + o);
+        const f32x4v gh4 = g < 2 ? gi4 : *reinterpret_cast<const f32x4v*>(G + 3 * TS + o);
+        ah = mfma4(*reinterpret_cast<const f32x4v*>(Wh + g * DP * 16 + o), gh4, ah);
+        ae = mfma4(*reinterpret_cast<const f32x4v*>(Wi + g * DP * 16 + o), gi4, ae);
+      }
+      *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = ah;
+      *reinterpret_cast<f32x4v*>(PART + 1024 + wave * 256 + li * 16 + 4 * lq) = ae;
+    }
+    __syncthreads();
+    {
+      const int o = erow * 16 + ecol;
+      dh += PART[o] + PART[256 + o] + PART[512 + o] + PART[768 + o];
+      const float ae = PART[1024 + o] + PART[1280 + o] + PART[1536 + o] + PART[1792 + o];
+      const float v = e_ok ? ae * elu_grad_from_out(in.ev) : 0.f;
+      if (e_ok) p.de[(row0 + erow) * D + ec] = v;
+      G[ai(ec, erow)] = v;  // G[0] now carries d e_pre (the gate tiles are consumed: barrier above)
+    }
+    if (t > 0) load_step(t - 1);
+    __syncthreads();
+    if (!exchange(4, 1, G, (unsigned)(2 * step + 2), step & 1)) return;
+    // ---- 4: d state_{t-1} = (W_sa[:, :S]^T d e_pre) * nonterm, replicated
+    {
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int x = 0; x < KB4; ++x)
+        if (kb4_0 + x < KBD)
+          acc = mfma4(W4[x], *reinterpret_cast<const f32x4v*>(G + (((kb4_0 + x) * 4 + lq) * 16 + li) * 4), acc);
+      *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SPER; ++j) {
+      const int i = tid + 256 * j, row = i / S, s = i % S;
+      if (i < 16 * S) {
+        const int tl = s >> 4, o = row * 16 + (s & 15);
+        const float v = PART[tl * 256 + o] + PART[(tl + 2) * 256 + o];
+        DST[row * 32 + s] = row < nr ? v * (j == 0 ? nt0 : nt1) : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  if (p.dprev_belief && e_ok) p.dprev_belief[(size_t)(b0 + erow) * D + ec] = dh;
+  if (p.dprev_state && w == 0)
+    for (int i = tid; i < nr * S; i += 256) p.dprev_state[(size_t)(b0 + i / S) * S + i % S] = DST[(i / S) * 32 + i % S];
+}
+
+static size_t cs_bwd_pack_floats(int64_t D, int64_t Hd, int64_t S) {
+  return pack_floats(Hd, 2 * S) + pack_floats(D, Hd) + 6 * pack_floats(D, D) + pack_floats(S, D);
+}
+
+size_t scan_cs_bwd_ws_floats(int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  (void)A;
+  const int64_t G = (B + 15) / 16, NW = (std::max(D, Hd) + 15) / 16, KP = pad16((int)std::max(D, Hd));
+  return cs_bwd_pack_floats(D, Hd, S) + (size_t)(G * 2 * 5 * KP * 16) + (size_t)(G * NW * 32) + 32;
+}
+
+int scan_cs_bwd(const ScanCsBwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!scan_cs_ok(q.T, q.B, q.A, q.D, q.Hd, q.S) || q.T <= 0) return REPO_E_SHAPE;
+  if (!ws || ws_bytes < scan_cs_bwd_ws_floats(q.B, q.A, q.D, q.Hd, q.S) * sizeof(float)) return REPO_E_WS_TOO_SMALL;
+  const int d = (int)q.D, h = (int)q.Hd, X = (int)(q.S + q.A), s2 = (int)(2 * q.S);
+  const float* const* P = q.params;
+  float* w = (float*)ws;
+  float* WsqT = w;  w += pack_floats(h, s2);
+  float* WbqT = w;  w += pack_floats(d, h);
+  float* WhhT = w;  w += 3 * pack_floats(d, d);
+  float* WihT = w;  w += 3 * pack_floats(d, d);
+  float* WsaT = w;  w += pack_floats(q.S, d);
+  const int64_t G = (q.B + 15) / 16, NW = (std::max(q.D, q.Hd) + 15) / 16, KP = pad16((int)std::max(q.D, q.Hd));
+  float* xbuf = w;  w += G * 2 * 5 * KP * 16;
+  unsigned* flags = (unsigned*)w;  w += G * NW * 32;
+  unsigned* err = (unsigned*)w;
+  // transposed products: W(n = input feature, k = output feature) = native[k * ld + n]
+  PackArgs pa;
+  pa.njobs = 0;
+  pa.job[pa.njobs++] = PackJob{P[12], WsqT, h, s2, 1, h};
+  pa.job[pa.njobs++] = PackJob{P[10], WbqT, d, h, 1, (int)(q.D + q.E)};
+  for (int g = 0; g < 3; ++g) {
+    pa.job[pa.njobs++] = PackJob{P[3] + (size_t)g * d * d, WhhT + g * pack_floats(d, d), d, d, 1, d};
+    pa.job[pa.njobs++] = PackJob{P[2] + (size_t)g * d * d, WihT + g * pack_floats(d, d), d, d, 1, d};
+  }
+  pa.job[pa.njobs++] = PackJob{P[0], WsaT, (int)q.S, d, 1, X};
+  int rc = launch_pack(pa, s);
+  if (rc) return rc;
+  hipError_t he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
+  if (he != hipSuccess) return (int)he;
+  CsBwdArgs a;
+  a.T = (int)q.T; a.B = (int)q.B; a.A = (int)q.A; a.D = d; a.Hd = h; a.S = (int)q.S;
+  a.WsqT = WsqT; a.WbqT = WbqT; a.WhhT = WhhT; a.WihT = WihT; a.WsaT = WsaT;
+  a.nonterms = q.nonterms; a.featx = q.featx; a.post_std = q.post_std; a.e = q.e; a.gates = q.gates; a.hq = q.hq;
+  a.eps_post = q.eps_post;
+  a.dfeat = q.dfeat; a.dqm = q.dqm; a.dqs = q.dqs; a.dbx = q.dbx;
+  a.doutq = q.doutq; a.dhq = q.dhq; a.dgi = q.dgi; a.dgh = q.dgh; a.de = q.de;
+  a.dprev_belief = q.dprev_belief; a.dprev_state = q.dprev_state; a.min_std = q.min_std;
+  a.xbuf = xbuf; a.flags = flags; a.err = err;
+  a.spin_limit = 1 << 22;
+  constexpr int DP = 208, TS = 208 * 16;
+  const size_t lds_b = (size_t)(6 * DP * 16 + 4 * TS + 64 * 16 + 2 * 4 * 256 + 16 * 32) * sizeof(float);
+  he = hipFuncSetAttribute((const void*)observe_cs_bwd_kernel<13, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+  if (he != hipSuccess) return (int)he;
+  hipLaunchKernelGGL((observe_cs_bwd_kernel<13, 13>), dim3((unsigned)NW, (unsigned)G), dim3(256), lds_b, s, a);
+  he = hipGetLastError();
+  return he == hipSuccess ? REPO_OK : (int)he;
+}
+
 }  // namespace repo

@@ -278,7 +278,7 @@ def reduce_ws(device):
 class ObserveSaved:
     __slots__ = ("T", "B", "A", "D", "Hd", "S", "E", "featx", "prior_state", "prior_mean", "prior_std", "post_mean",
                  "post_std", "xsa", "e", "gates", "hp", "hq", "nonterms", "embeds", "eps_prior", "eps_post", "noise",
-                 "prior_ready")
+                 "prior_ready", "cs")
 
 
 def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds, eps_prior, eps_post, min_std=0.1,
@@ -327,6 +327,7 @@ def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds,
         "repo_rssm_observe_fwd",
     )
     sv.prior_ready = None
+    sv.cs = use_cs   # the reverse scan takes the same engine
     if hoist and prior_stream is None:   # the prior head of all steps, in line
         nbp = lib().repo_rssm_prior_head_workspace_bytes(T, B, S)
         wsp = workspace(nbp, dev)
@@ -366,7 +367,7 @@ def rssm_observe_bwd(params, sv, dparams, dfeat=None, dprior_state=None, dpm=Non
             _ptr(sv.eps_post), sv.noise[0], sv.noise[1], float(min_std), _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.post_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(dfeat), _ptr(dprior_state), _ptr(dpm),
             _ptr(dps), _ptr(dqm), _ptr(dqs), ga, _ptr(dembeds), _ptr(dprev_belief), _ptr(dprev_state),
-            int(accumulate), _ptr(ws), ws.numel(), _stream(),
+            int(bool(accumulate)) | (2 if getattr(sv, "cs", False) else 0), _ptr(ws), ws.numel(), _stream(),
         ),
         "repo_rssm_observe_bwd",
     )

@@ -515,3 +515,42 @@ def test_column_split_scan_matches_row_scan(monkeypatch, T, B, A, philox):
         worst = max(worst, err)
         assert err < 2e-5, (name, err)
     log(f"column-split scan T={T} B={B} A={A} philox={philox}: worst rel-to-max error vs the row scan {worst:.2e}")
+
+
+@pytest.mark.parametrize("T,B,A,philox", [(9, 3, 6, False), (49, 7, 6, True), (6, 17, 7, False), (5, 50, 6, True)])
+def test_column_split_reverse_scan_matches_row_scan(monkeypatch, T, B, A, philox):
+    """Forward + reverse scan on the column-split engine (csrc/scan_cs.hip) against rssm.hip's row scans: all 14
+    parameter gradients, d embeds and the gradients into the carried belief / state, with every upstream gradient
+    non-zero (KL terms, prior sample, decoder / reward gradients on [belief | state])."""
+    from repo_amd import ops
+
+    D, S, E = 200, 30, 1024
+    rs = np.random.RandomState(2000 * T + B)
+    p = cu(tparams("transition_model", A, requires_grad=False))
+    dev = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()  # noqa: E731
+    b0, s0 = dev(rs.standard_normal((B, D)) * 0.3), dev(rs.standard_normal((B, S)))
+    act = dev(rs.uniform(-1, 1, (T, B, A)))
+    non = dev(rs.uniform(size=(T, B)) > 0.15)
+    emb = dev(np.maximum(rs.standard_normal((T, B, E)), 0))
+    eps = (None, None) if philox else (dev(rs.standard_normal((T, B, S))), dev(rs.standard_normal((T, B, S))))
+    ups = {k: dev(rs.standard_normal(shp) * 0.1) for k, shp in
+           (("dfeat", (T, B, D + S)), ("dprior_state", (T, B, S)), ("dpm", (T, B, S)), ("dps", (T, B, S)),
+            ("dqm", (T, B, S)), ("dqs", (T, B, S)))}
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("REPO_SCAN_CS", mode)
+        sv = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, eps[0], eps[1], 0.1, noise=(9, 128))
+        assert sv.cs == (mode == "1")
+        g = [torch.zeros_like(t) for t in p]
+        dembeds, dpb, dps_ = torch.empty(T, B, E).cuda(), torch.empty(B, D).cuda(), torch.empty(B, S).cuda()
+        ops.rssm_observe_bwd(p, sv, g, dembeds=dembeds, dprev_belief=dpb, dprev_state=dps_, **ups)
+        res[mode] = g + [dembeds, dpb, dps_]
+    torch.cuda.synchronize()
+    names = list(fx.param_shapes(A)["transition_model"].keys()) + ["dembeds", "dprev_belief", "dprev_state"]
+    worst = 0.0
+    for n, a, b in zip(names, res["0"], res["1"]):
+        assert torch.isfinite(b).all(), n
+        err = float((a - b).norm() / (a.norm() + 1e-20))
+        worst = max(worst, err)
+        assert err < 2e-5, (n, err)
+    log(f"column-split reverse scan T={T} B={B} A={A} philox={philox}: worst l2 error vs the row scans {worst:.2e}")
