@@ -50,8 +50,12 @@ def _ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream  # the handle only: torch.cuda.current_stream() builds a Stream
+                                                   # object per call (7 us x 120 calls per update on the host)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(torch.cuda.current_device())
 
 
 _ws = {}
@@ -60,8 +64,8 @@ _ws = {}
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, current stream): reuse is stream-ordered, and work
     running concurrently on a side stream never shares scratch with the main stream."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _raw_stream(idx))
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -309,11 +313,13 @@ def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds,
     nb = lib().repo_rssm_observe_fwd_workspace_bytes(T, B, A, D, Hd, S, E)
     ws = workspace(nb, dev)
     pa = ptr_array(params)
-    # engine: the column-split, weight-stationary MFMA scan (csrc/scan_cs.hip, mode 3) pays where the chip is nearly
-    # idle -- the <= 16-row shards of a strong-scaling job (~8 us per step instead of 17); REPO_SCAN_CS=1 / 0 forces it
-    # on / off for any B.  It always leaves the prior head to repo_rssm_prior_head.
+    # engine: the column-split, weight-stationary MFMA scan (csrc/scan_cs.hip, mode 3): 12.5 us per step for any
+    # B <= 64 (13 workgroups per 16 rows) against the row scan's 18-20; measured alone (fwd 880-980 -> 590-640 us,
+    # reverse 890-1030 -> 655-750) and inside the update (B=50: 8.51 -> 8.35 ms, the B=7 shard 3.37 -> 2.97 ms;
+    # profiles/r03_scan_cs.txt).  REPO_SCAN_CS=1 / 0 forces it on / off for any B.  It always leaves the prior head to
+    # repo_rssm_prior_head.
     cs_env = os.environ.get("REPO_SCAN_CS", "auto")
-    use_cs = (not prior_only and cs_env != "0" and (cs_env == "1" or B <= 16)
+    use_cs = (not prior_only and cs_env != "0" and (cs_env == "1" or B <= 64)
               and (D + 15) // 16 == 13 and (Hd + 15) // 16 == 13 and (S + A + 15) // 16 == 3 and S <= 32 and D % 4 == 0)
     hoist = (prior_stream is not None or use_cs) and not prior_only
     check(
