@@ -42,7 +42,7 @@ struct CsFwdArgs {
   NoiseSrc eps_post;
   float *featx, *post_mean, *post_std, *xsa, *e, *gates, *hq;
   float min_std;
-  float* xbuf;      // [group][kind 2][parity 2][KP*16]
+  float* xbuf;      // [group][kind 2][rotation 4][KP*16]
   unsigned* flags;  // [group][NW] on 128-byte lines
   unsigned* err;
   int spin_limit;
@@ -53,6 +53,22 @@ __device__ __forceinline__ f32x4v ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned off)
 }
 __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, const f32x4v& v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, kSC1);
+}
+// data-tagged all-gathers (no vmcnt(0) wait, no flag hop): forward 590 -> 539 us; the reverse scan's four-tile gather
+// polls 13 granules per thread and gains nothing (663 vs 655 us): it keeps the flags
+#ifndef REPO_CS_TAGGED
+#define REPO_CS_TAGGED 1
+#endif
+#ifndef REPO_CS_TAGGED_BWD
+#define REPO_CS_TAGGED_BWD 0
+#endif
+__device__ __forceinline__ f32x4v kSentinel4() {
+  const float n = __builtin_bit_cast(float, 0xffffffffu);
+  return f32x4v{n, n, n, n};
+}
+__device__ __forceinline__ bool has_sentinel(const f32x4v& v) {
+  return __builtin_bit_cast(unsigned, v[0]) == 0xffffffffu || __builtin_bit_cast(unsigned, v[1]) == 0xffffffffu ||
+         __builtin_bit_cast(unsigned, v[2]) == 0xffffffffu || __builtin_bit_cast(unsigned, v[3]) == 0xffffffffu;
 }
 __device__ __forceinline__ f32x4v mfma4(const f32x4v& w, const f32x4v& x, f32x4v acc) {
 #pragma unroll
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
     if (row < nr && w == 0) p.featx[(size_t)(b0 + row) * F + D + s] = v;
   }
 
-  const __amdgpu_buffer_rsrc_t rx = wrsrc(p.xbuf + (size_t)grp * 4 * KP * 16, 4u * 4u * KP * 16);
+  const __amdgpu_buffer_rsrc_t rx = wrsrc(p.xbuf + (size_t)grp * 8 * KP * 16, 4u * 8u * KP * 16);
   unsigned* flags = p.flags + (size_t)grp * NW * 32;
   // x-vector roles of this thread: elements tid, tid + 256, ... of the 16 x X tile
   constexpr int XPER = (16 * XP + 255) / 256;
@@ -170,7 +186,52 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
 
   // all-gather of one own slice (already in `tile`, k-groups c0/4 .. c0/4+3): kind 0 = belief, 1 = hq
   auto exchange = [&](float* tile, int kind, int t, int kp) __attribute__((always_inline)) -> bool {
-    const unsigned base = 4u * (unsigned)((kind * 2 + (t & 1)) * KP * 16);
+#if REPO_CS_TAGGED
+    // data-tagged hand-off: four rotating buffers per kind, all cells start as the sentinel (a NaN no activation can be);
+    // the producer stores its slice into buffer t % 4 and re-arms its slice of buffer (t + 2) % 4 (every consumer is
+    // done with it: a workgroup publishes exchange t only after gathering t - 1, which needed every peer's publish of
+    // t - 1, which each peer issued after gathering t - 2 -- and the re-arm is acknowledged before this workgroup's
+    // NEXT publish, its own gather in between waits for vmcnt(0)); a consumer re-loads a granule until it holds no
+    // sentinel.  No vmcnt(0) wait, no flag hop: 2.6 -> ~1.5 us per exchange.
+    const unsigned base = 4u * (unsigned)((kind * 4 + (t & 3)) * KP * 16);
+    const unsigned rearm = 4u * (unsigned)((kind * 4 + ((t + 2) & 3)) * KP * 16);
+    if (wave == 0) {
+      const unsigned o = 16u * (unsigned)((c0 >> 2) * 16 + lane);
+      st_sc1(rx, base + o, *reinterpret_cast<const f32x4v*>(tile + ((c0 >> 2) * 16 + lane) * 4));
+      st_sc1(rx, rearm + o, kSentinel4());
+    }
+    constexpr int NV = (KP * 4 + 255) / 256;
+    f32x4v g[NV];
+    bool okv[NV];
+    bool all = false;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) okv[j] = (tid + 256 * j) >= kp * 4;
+    for (int n = 0; !all; ++n) {
+      all = true;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (!okv[j]) g[j] = ld_sc1(rx, base + 16u * (unsigned)(tid + 256 * j));
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (!okv[j]) {
+          okv[j] = !has_sentinel(g[j]);
+          all = all && okv[j];
+        }
+      if (!all && n > p.spin_limit) {
+        s_abort = 1;
+        __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + 256 * j;
+      if (i < kp * 4) reinterpret_cast<f32x4v*>(tile)[i] = g[j];
+    }
+    __syncthreads();
+    return !s_abort;
+#else
+    const unsigned base = 4u * (unsigned)((kind * 4 + (t & 1)) * KP * 16);
     const unsigned epoch = (unsigned)(2 * t + kind + 1);
     if (wave == 0) {
       const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + ((c0 >> 2) * 16 + lane) * 4);
@@ -204,6 +265,7 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
     }
     __syncthreads();
     return true;
+#endif
   };
 
   for (int t = 0; t < T; ++t) {
@@ -345,7 +407,7 @@ bool scan_cs_ok(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t 
 
 size_t scan_cs_fwd_ws_floats(int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S) {
   const int64_t G = (B + 15) / 16, NW = (std::max(D, Hd) + 15) / 16, KP = pad16((int)std::max(D, Hd));
-  return cs_pack_floats(A, D, Hd, S) + (size_t)(G * 4 * KP * 16) + (size_t)(G * NW * 32) + 32;
+  return cs_pack_floats(A, D, Hd, S) + (size_t)(G * 8 * KP * 16) + (size_t)(G * NW * 32) + 32;
 }
 
 int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -360,7 +422,7 @@ int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   float* Wbq = w;  w += pack_floats(h, d);
   float* Wsq = w;  w += pack_floats(s2, h);
   const int64_t G = (q.B + 15) / 16, NW = (std::max(q.D, q.Hd) + 15) / 16, KP = pad16((int)std::max(q.D, q.Hd));
-  float* xbuf = w;  w += G * 4 * KP * 16;
+  float* xbuf = w;  w += G * 8 * KP * 16;
   unsigned* flags = (unsigned*)w;  w += G * NW * 32;
   unsigned* err = (unsigned*)w;
   PackArgs pa;
@@ -373,6 +435,8 @@ int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   int rc = launch_pack(pa, s);
   if (rc) return rc;
   hipError_t he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
+  if (he != hipSuccess) return (int)he;
+  he = hipMemsetAsync(xbuf, 0xff, (size_t)(G * 8 * KP * 16) * sizeof(float), s);  // every cell = the sentinel
   if (he != hipSuccess) return (int)he;
   if (q.T == 0) return REPO_OK;
   CsFwdArgs a;
@@ -414,7 +478,7 @@ struct CsBwdArgs {
   const float *dfeat, *dqm, *dqs, *dbx;
   float *doutq, *dhq, *dgi, *dgh, *de, *dprev_belief, *dprev_state;
   float min_std;
-  float* xbuf;      // [group][parity 2][5 tiles][KP*16]: tiles 0..3 = g_r, g_z, g_n, g_hn; 4 = d e_pre
+  float* xbuf;      // [group][20 tiles of KP*16]: [rotation 4][g_r, g_z, g_n, g_hn], then [rotation 4] d e_pre
   unsigned* flags;
   unsigned* err;
   int spin_limit;
@@ -479,7 +543,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
     W4[x] = reinterpret_cast<const f32x4v*>(p.WsaT)[(size_t)(min(kb4_0 + x, KBD - 1) * 4 + lq) * S + min((wave & 1) * 16 + li, S - 1)];
   __syncthreads();
 
-  const __amdgpu_buffer_rsrc_t rx = wrsrc(p.xbuf + (size_t)grp * 2 * 5 * TS, 4u * 2u * 5u * TS);
+  const __amdgpu_buffer_rsrc_t rx = wrsrc(p.xbuf + (size_t)grp * 20 * TS, 4u * 20u * TS);
   unsigned* flags = p.flags + (size_t)grp * NW * 32;
   const __amdgpu_buffer_rsrc_t rhq = arsrc(p.hq);
 
@@ -526,8 +590,56 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
   float dh = 0.f;  // carried d belief of element (erow, ec)
 
   // all-gather of `nt` own slices starting at tile index `t0` of this step's parity block
-  auto exchange = [&](int t0, int nt, float* tiles, unsigned epoch, int par) __attribute__((always_inline)) -> bool {
-    const unsigned base = 4u * (unsigned)((par * 5 + t0) * TS);
+  // kind 0: the four gate tiles (xbuf tiles [rot 4][4]); kind 1: d e_pre ([rot 4][1] behind them).  `seq` = step.
+  auto exchange = [&](int kind, float* tiles, int seq) __attribute__((always_inline)) -> bool {
+    const int nt = kind == 0 ? 4 : 1;
+#if REPO_CS_TAGGED_BWD
+    // data-tagged hand-off, see the forward kernel
+    const unsigned base = 4u * (unsigned)((kind == 0 ? (seq & 3) * 4 : 16 + (seq & 3)) * TS);
+    const unsigned rearm = 4u * (unsigned)((kind == 0 ? ((seq + 2) & 3) * 4 : 16 + ((seq + 2) & 3)) * TS);
+    if (wave == 0) {
+      const unsigned o = 16u * (unsigned)((c0 >> 2) * 16 + lane);
+      for (int x = 0; x < nt; ++x) {
+        st_sc1(rx, base + 4u * (unsigned)(x * TS) + o,
+               *reinterpret_cast<const f32x4v*>(tiles + x * TS + ((c0 >> 2) * 16 + lane) * 4));
+        st_sc1(rx, rearm + 4u * (unsigned)(x * TS) + o, kSentinel4());
+      }
+    }
+    const int nv = nt * TS / 4;
+    for (int i0 = 0; i0 < nv; i0 += 256 * 7) {
+      f32x4v g[7];
+      bool okv[7];
+      bool all = false;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) okv[j] = (i0 + tid + 256 * j) >= nv;
+      for (int n = 0; !all; ++n) {
+        all = true;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+          if (!okv[j]) g[j] = ld_sc1(rx, base + 16u * (unsigned)(i0 + tid + 256 * j));
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+          if (!okv[j]) {
+            okv[j] = !has_sentinel(g[j]);
+            all = all && okv[j];
+          }
+        if (!all && n > p.spin_limit) {
+          s_abort = 1;
+          __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int i = i0 + tid + 256 * j;
+        if (i < nv) reinterpret_cast<f32x4v*>(tiles)[i] = g[j];
+      }
+    }
+    __syncthreads();
+    return !s_abort;
+#else
+    const unsigned epoch = (unsigned)(2 * seq + kind + 1);
+    const unsigned base = 4u * (unsigned)((kind == 0 ? (seq & 1) * 4 : 16 + (seq & 1)) * TS);
     if (wave == 0) {
       for (int x = 0; x < nt; ++x) {
         const f32x4v v = *reinterpret_cast<const f32x4v*>(tiles + x * TS + ((c0 >> 2) * 16 + lane) * 4);
@@ -565,6 +677,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
     }
     __syncthreads();
     return true;
+#endif
   };
 
   for (int t = T - 1; t >= 0; --t) {
@@ -657,7 +770,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
       G[3 * TS + a_] = g_hn;
     }
     __syncthreads();
-    if (!exchange(0, 4, G, (unsigned)(2 * step + 1), step & 1)) return;
+    if (!exchange(0, G, step)) return;
     // ---- 3: d belief_{t-1} += W_hh^T (g_r, g_z, g_hn);  d e = W_ih^T (g_r, g_z, g_n): own columns, K = 3 D split
     //         over the waves as (gate, block) pairs
     {
@@ -686,7 +799,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
     }
     if (t > 0) load_step(t - 1);
     __syncthreads();
-    if (!exchange(4, 1, G, (unsigned)(2 * step + 2), step & 1)) return;
+    if (!exchange(1, G, step)) return;
     // ---- 4: d state_{t-1} = (W_sa[:, :S]^T d e_pre) * nonterm, replicated
     {
       f32x4v acc = {0.f, 0.f, 0.f, 0.f};
@@ -720,7 +833,7 @@ static size_t cs_bwd_pack_floats(int64_t D, int64_t Hd, int64_t S) {
 size_t scan_cs_bwd_ws_floats(int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S) {
   (void)A;
   const int64_t G = (B + 15) / 16, NW = (std::max(D, Hd) + 15) / 16, KP = pad16((int)std::max(D, Hd));
-  return cs_bwd_pack_floats(D, Hd, S) + (size_t)(G * 2 * 5 * KP * 16) + (size_t)(G * NW * 32) + 32;
+  return cs_bwd_pack_floats(D, Hd, S) + (size_t)(G * 20 * KP * 16) + (size_t)(G * NW * 32) + 32;
 }
 
 int scan_cs_bwd(const ScanCsBwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -735,7 +848,7 @@ int scan_cs_bwd(const ScanCsBwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   float* WihT = w;  w += 3 * pack_floats(d, d);
   float* WsaT = w;  w += pack_floats(q.S, d);
   const int64_t G = (q.B + 15) / 16, NW = (std::max(q.D, q.Hd) + 15) / 16, KP = pad16((int)std::max(q.D, q.Hd));
-  float* xbuf = w;  w += G * 2 * 5 * KP * 16;
+  float* xbuf = w;  w += G * 20 * KP * 16;
   unsigned* flags = (unsigned*)w;  w += G * NW * 32;
   unsigned* err = (unsigned*)w;
   // transposed products: W(n = input feature, k = output feature) = native[k * ld + n]
@@ -751,6 +864,8 @@ int scan_cs_bwd(const ScanCsBwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   int rc = launch_pack(pa, s);
   if (rc) return rc;
   hipError_t he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
+  if (he != hipSuccess) return (int)he;
+  he = hipMemsetAsync(xbuf, 0xff, (size_t)(G * 20 * KP * 16) * sizeof(float), s);  // every cell = the sentinel
   if (he != hipSuccess) return (int)he;
   CsBwdArgs a;
   a.T = (int)q.T; a.B = (int)q.B; a.A = (int)q.A; a.D = d; a.Hd = h; a.S = (int)q.S;

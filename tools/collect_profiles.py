@@ -19,6 +19,12 @@ pairs = [
     ("r03_lane_time.txt", "r03_lane_time.txt"),
     ("r03_phase_time.txt", "r03_phase_time.txt"),
     ("dominant_kernel_rocprof.json", "dominant_kernel_rocprof.json"),
+    ("r03_scan_cs.txt", "r03_scan_cs.txt"),
+    ("r03_layers_isolated_128.txt", "r03_layers_isolated_128.txt"),
+    ("r03_c4x128_layers_in_update.txt", "r03_c4x128_layers_in_update.txt"),
+    ("r03_c4x128_kernel_stats.csv", "r03_bench_kernel_stats_c4x128.csv"),
+    ("r03_bench_c4x128.json", "r03_bench_c4x128.json"),
+    ("r03_bench_tia.json", "r03_bench_tia.json"),
 ]
 for src, dst in pairs:
     s = os.path.join(G, src)
