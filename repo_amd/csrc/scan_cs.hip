@@ -20,7 +20,8 @@
 // (profiles/r03_scan_exchange_probe.txt): this engine is for the SHARDS of a strong-scaling job (B <= 16 per GPU, the
 // chip nearly idle), where a step costs ~8 us instead of 17; inside the N = 1 update at B = 50 it loses.
 // A poll that does not see its peers within `spin_limit` rounds raises the error word and the whole group leaves the
-// time loop (no hang if a peer workgroup never becomes resident).
+// time loop (no hang if a peer workgroup never becomes resident) after writing NaN into its outputs (the last belief
+// slot / the first d e row), so the update's losses and gradient norms show it.
 //
 // Prior head: not here (it is off the recurrence: repo_rssm_prior_head evaluates it for all steps at once).
 // Everything the reverse scan needs is written exactly as rssm.hip's forward writes it.
@@ -268,6 +269,10 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
 #endif
   };
 
+  // a group that gave up on its peers (error word raised) must not leave plausible numbers behind
+  auto poison = [&]() __attribute__((always_inline)) {
+    if (erow < nr && ec < D) p.featx[((size_t)T * B + b0 + erow) * F + ec] = __builtin_bit_cast(float, 0x7fc00000u);
+  };
   for (int t = 0; t < T; ++t) {
     const size_t row0 = (size_t)t * B + b0;
     const float em = em_next;
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
       }
     }
     __syncthreads();
-    if (!exchange(HS, 0, t, DP)) return;
+    if (!exchange(HS, 0, t, DP)) return poison();
     // ---- C: hq = elu(W_bq[:, :D] h + eemb + b), own columns, K split over the waves
     {
       f32x4v acc = {0.f, 0.f, 0.f, 0.f};
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
       if (erow < nr && ec < Hd) p.hq[(row0 + erow) * Hd + ec] = v;
     }
     __syncthreads();
-    if (!exchange(QS, 1, t, HP)) return;
+    if (!exchange(QS, 1, t, HP)) return poison();
     // ---- D: posterior (mean | raw std) = W_sq hq + b, replicated; softplus + sample
     {
       f32x4v acc = {0.f, 0.f, 0.f, 0.f};
@@ -680,6 +685,10 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
 #endif
   };
 
+  // a group that gave up on its peers (error word raised) must not leave plausible numbers behind
+  auto poison = [&]() __attribute__((always_inline)) {
+    if (e_ok) p.de[(size_t)(b0 + erow) * D + ec] = __builtin_bit_cast(float, 0x7fc00000u);
+  };
   for (int t = T - 1; t >= 0; --t) {
     const size_t row0 = (size_t)t * B + b0;
     const int step = T - 1 - t;
@@ -770,7 +779,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
       G[3 * TS + a_] = g_hn;
     }
     __syncthreads();
-    if (!exchange(0, G, step)) return;
+    if (!exchange(0, G, step)) return poison();
     // ---- 3: d belief_{t-1} += W_hh^T (g_r, g_z, g_hn);  d e = W_ih^T (g_r, g_z, g_n): own columns, K = 3 D split
     //         over the waves as (gate, block) pairs
     {
@@ -799,7 +808,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
     }
     if (t > 0) load_step(t - 1);
     __syncthreads();
-    if (!exchange(1, G, step)) return;
+    if (!exchange(1, G, step)) return poison();
     // ---- 4: d state_{t-1} = (W_sa[:, :S]^T d e_pre) * nonterm, replicated
     {
       f32x4v acc = {0.f, 0.f, 0.f, 0.f};
