@@ -520,3 +520,60 @@ class PerParamAdam(Adam):
             v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
             denom = (v.sqrt() / math.sqrt(1 - self.b2**t)).add_(self.eps)
             p.addcdiv_(m, denom, value=-(self.lr / (1 - self.b1**t)))
+
+
+# --------------------------------------------------------------------------- encoder fine-tuning (adaptation)
+class OracleFinetuned(OracleAgent):
+    """FinetunedRePo.train_encoder, /root/reference/algorithms/repo/repo_adapt.py:26-94: the encoder alone is trained
+    (its own Adam) on reward NLL + beta * (KL(post || prior) - target_kl) through the FROZEN filter and reward head; the
+    dual variable follows as in RePo.  Parity status: PINNED by tests/golden/finetune_tiny.npz (the reference's class run
+    by tests/golden/gen_golden.py)."""
+
+    def __init__(self, cfg, action_size, params=None, seed=7):
+        super().__init__(cfg, action_size, params=params, seed=seed)
+        assert self.is_repo
+        self.encoder_params = list(self.p["encoder"].values())
+        self.encoder_opt = Adam(self.encoder_params, cfg.model_lr)
+
+    def train_encoder(self, obs, actions, rewards, nonterms, eps_prior, eps_post, apply=True):
+        c, p = self.c, self.p
+        L, B = obs.shape[:2]
+        T = L - 1
+        embeds = encoder_fwd(p["encoder"], obs.reshape(L * B, *obs.shape[2:])).reshape(L, B, -1)
+        frozen = list(p["transition_model"].values()) + list(p["reward_model"].values())
+        for q in frozen:
+            q.requires_grad_(False)
+        try:
+            beliefs, _, pm, ps, post_s, qm, qs = observe(p["transition_model"], torch.zeros(B, c.belief_size),
+                                                         torch.zeros(B, c.state_size), actions[:-1], embeds[1:],
+                                                         nonterms[:-1], eps_prior, eps_post)
+            r_pred = scalar_head(p["reward_model"], beliefs.reshape(T * B, -1), post_s.reshape(T * B, -1)).reshape(T, B)
+        finally:
+            for q in frozen:
+                q.requires_grad_(True)
+        mask = nonterms[:-1].squeeze(-1)
+        reward_loss = ((0.5 * (r_pred - rewards[:-1].squeeze(-1)) ** 2 + 0.5 * LOG_2PI) * mask).mean((0, 1))
+        kl_div = normal_kl(qm, qs, pm, ps).sum(2).mean((0, 1))
+        kl_viol = kl_div - c.target_kl
+        kl_loss = self.log_beta.exp().detach() * kl_viol
+        encoder_loss = reward_loss + kl_loss
+        self.encoder_opt.zero_grad()
+        encoder_loss.backward()
+        self.last["encoder_grads"] = [q.grad.detach().clone() for q in self.encoder_params]
+        self.last["encoder_total_norm"] = float(clip_grad_norm(self.encoder_params, c.grad_clip_norm))
+        if apply:
+            self.encoder_opt.step()
+        beta_loss = -self.log_beta * kl_viol.detach()
+        self.beta_opt.zero_grad()
+        beta_loss.backward()
+        if apply:
+            self.beta_opt.step()
+        out = {"train/reward_loss": reward_loss, "train/kl_loss": kl_loss, "train/kl_div": kl_div,
+               "train/encoder_loss": encoder_loss, "train/beta": self.log_beta.exp(), "train/beta_loss": beta_loss}
+        return {k: float(v.detach()) for k, v in out.items()}
+
+    def update(self, obs_u8, actions, rewards, dones, noise):
+        obs = torch.from_numpy(fx.preprocess_u8(np.asarray(obs_u8)))
+        t = {k: torch.as_tensor(v) for k, v in noise.items()}
+        return self.train_encoder(obs, torch.as_tensor(actions), torch.as_tensor(rewards), 1 - torch.as_tensor(dones),
+                                  t["obs_prior"], t["obs_post"])

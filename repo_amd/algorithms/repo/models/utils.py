@@ -74,6 +74,24 @@ class FlatAdam:
                 p.grad = gv
                 self.gviews.append(gv)
 
+    @classmethod
+    def view(cls, parent, n_params, lr):
+        """A second optimiser over the FIRST n_params parameters of `parent` (same storage for values and gradients,
+        its own moments and step count): the reference's `Adam(self.encoder.parameters())` beside the model optimiser
+        (repo_adapt.py:29) -- two torch optimisers over shared parameters."""
+        self = cls.__new__(cls)
+        self.params = parent.params[:n_params]
+        self.lr, self.betas, self.eps = float(lr), parent.betas, parent.eps
+        self.step_count = 0
+        self.offsets = parent.offsets[:n_params]
+        self.numel = parent.offsets[n_params] if n_params < len(parent.params) else parent.numel
+        self.flat, self.grad = parent.flat[: self.numel], parent.grad[: self.numel]
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.sqnorm = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+        self.gviews = parent.gviews[:n_params]
+        return self
+
     # -- reference-style surface -----------------------------------------------------
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()

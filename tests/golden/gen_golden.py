@@ -265,6 +265,48 @@ def run_tia_case(TIA, L, B, H, A, n_updates, feeder, record, out_path, **cfg_ove
     print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
 
 
+def run_finetune_case(L, B, A, n_updates, feeder, record, out_path):
+    """The reference's FinetunedRePo.train_encoder (repo_adapt.py:26-94) on seeded parameters / batches / noise."""
+    from algorithms.repo.repo_adapt import FinetunedRePo
+
+    H = 5
+    cfg = fx.default_config(algo="repo", batch_size=B, chunk_size=L, horizon=H, init_beta=0.05, target_kl=0.1)
+    logger = RecLogger()
+    algo = FinetunedRePo(cfg, FakeEnv(A), FakeEnv(A), logger)
+    load_params(algo, fx.make_params(A, seed=7))
+    T = L - 1
+    g = OrderedDict()
+    g["meta"] = np.array([L, B, H, A, n_updates], dtype=np.int64)
+    g["cfg"] = np.array([cfg.init_beta, cfg.target_kl], dtype=np.float64)
+    keys = None
+    for u in range(n_updates):
+        obs_u8, actions, rewards, dones = fx.make_batch(L, B, A, seed=11 + u)
+        noise = fx.make_noise(L, B, H, A, seed=101 + u)
+        feeder.queue = [x for t in range(T) for x in (noise["obs_prior"][t], noise["obs_post"][t])]
+        record["clip_calls"].clear()
+        record["total_norms"].clear()
+        logger.kv.clear()
+        algo.train_encoder(torch.from_numpy(fx.preprocess_u8(obs_u8)), torch.from_numpy(actions), torch.from_numpy(rewards),
+                           torch.from_numpy(1 - dones))
+        assert not feeder.queue
+        keys = keys or sorted(logger.kv.keys())
+        g[f"u{u}/scalars"] = np.array([logger.kv[k] for k in keys], dtype=np.float64)
+        g[f"u{u}/total_norms"] = np.array(record["total_norms"], dtype=np.float64)
+        g[f"u{u}/log_beta"] = np.array(algo.log_beta.item(), dtype=np.float64)
+        print(f"  [{os.path.basename(out_path)}] update {u}: " + " ".join(f"{k.split('/')[-1]}={logger.kv[k]:.6g}" for k in keys),
+              flush=True)
+    g["scalar_keys"] = np.array(keys)
+    names, sums, abssums = [], [], []
+    for mod in fx.MODULES:
+        for k, v in getattr(algo, mod).state_dict().items():
+            names.append(f"{mod}.{k}")
+            sums.append(float(v.double().sum()))
+            abssums.append(float(v.double().abs().sum()))
+    g["param_names"], g["param_sums"], g["param_abssums"] = np.array(names), np.array(sums), np.array(abssums)
+    np.savez_compressed(out_path, **g)
+    print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -273,6 +315,9 @@ def main():
     record = {"clip_calls": [], "total_norms": []}
     install_patches(feeder, record)
 
+    if "--finetune-only" in sys.argv:
+        run_finetune_case(8, 4, 6, 3, feeder, record, os.path.join(HERE, "finetune_tiny.npz"))
+        return
     if "--tia-only" in sys.argv:
         run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(HERE, "tia_tiny.npz"))
         run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(HERE, "tia_coefs.npz"), tia_obs_coef=0.5,
@@ -286,6 +331,8 @@ def main():
     run_case(RePo, "repo", 6, 3, 3, 7, 2, True, feeder, record, os.path.join(HERE, "repo_odd.npz"))
     # config 1 shapes, scalar + sliced latents only
     run_case(RePo, "repo", 50, 16, 15, 6, 2, False, feeder, record, os.path.join(HERE, "repo_c1.npz"))
+    # FinetunedRePo (f4): encoder-only adaptation, beta large enough for the KL term to matter
+    run_finetune_case(8, 4, 6, 3, feeder, record, os.path.join(HERE, "finetune_tiny.npz"))
     # TIA (f4): default coefficients, and non-default ones with two distractor-reward fitting steps
     run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(HERE, "tia_tiny.npz"))
     run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(HERE, "tia_coefs.npz"), tia_obs_coef=0.5,

@@ -254,3 +254,105 @@ def test_tia_data_parallel_two_shards_equal_full_batch():
             assert e < 2e-5, (name, e)
     assert torch.equal(agents[0].model_optimizer.flat, agents[1].model_optimizer.flat)
     assert torch.equal(agents[0].d_reward_optimizer.flat, agents[1].d_reward_optimizer.flat)
+
+
+# --------------------------------------------------------------------------- FinetunedRePo (repo_adapt.py:26-127)
+def make_finetuned(L, B, H, A, **over):
+    from repo_amd.algorithms.repo import FinetunedRePo
+    from repo_amd.common.utils import set_gpu_mode
+
+    set_gpu_mode(True)
+    cfg = fx.default_config(algo="repo", batch_size=B, chunk_size=L, horizon=H, **over)
+    agent = FinetunedRePo(cfg, Env(A), Env(A), Logger())
+    params = fx.make_params(A, 7)
+    for mod in fx.MODULES:
+        agent._load_module(getattr(agent, mod), {k: torch.from_numpy(v) for k, v in params[mod].items()})
+    return agent, cfg
+
+
+def test_finetuned_repo_matches_reference_golden_and_oracle(golden_dir):
+    """Encoder-only adaptation steps: logged scalars, the encoder's pre-clip gradient norm, log_beta and every
+    module's parameter checksums against the reference's FinetunedRePo (tests/golden/finetune_tiny.npz); the flat
+    encoder gradient against the CPU oracle; the frozen modules do not move."""
+    from oracle.repo_oracle import OracleFinetuned
+
+    g = np.load(os.path.join(golden_dir, "finetune_tiny.npz"))
+    L, B, H, A, n_updates = (int(x) for x in g["meta"])
+    init_beta, target_kl = (float(x) for x in g["cfg"])
+    agent, cfg = make_finetuned(L, B, H, A, init_beta=init_beta, target_kl=target_kl)
+    oracle = OracleFinetuned(cfg, A, seed=7)
+    frozen0 = {m: torch.cat([p.detach().reshape(-1).clone() for p in getattr(agent, m).parameters()])
+               for m in ("transition_model", "reward_model", "obs_model", "actor_model", "value_model")}
+    keys = [str(k) for k in g["scalar_keys"]]
+    for u in range(n_updates):
+        batch, host = dev_batch(L, B, A, 11 + u, u8=(u % 2 == 0))
+        nzd, nz = {k: torch.from_numpy(v).cuda() for k, v in fx.make_noise(L, B, H, A, seed=101 + u).items()}, None
+        agent.noise_source = nzd
+        snap = {}
+        opt = agent.encoder_optimizer
+        orig = opt.clip_and_step
+
+        def hooked(max_norm, _o=orig, _s=snap, _opt=opt):
+            _s["g"] = _opt.grad.clone()
+            _o(max_norm)
+
+        opt.clip_and_step = hooked
+        with torch.no_grad():
+            for q, pp in zip(oracle.encoder_params, agent.encoder.parameters()):
+                q.copy_(pp.detach().cpu())
+            oracle.log_beta.copy_(agent.log_beta.detach().cpu())
+        agent.train_encoder(batch[0], batch[1], batch[2], 1.0 - batch[3])
+        opt.clip_and_step = orig
+        scal = agent.last_scalars
+        for k, w in zip(keys, g[f"u{u}/scalars"]):
+            r = abs(scal[k] - w) / (abs(w) + 1e-12)
+            log(f"[finetune_tiny.npz] update {u} {k}: got {scal[k]:.7g} ref {w:.7g} rel {r:.2e}")
+            assert r < 1e-3, (u, k, scal[k], w)
+        tn = float(g[f"u{u}/total_norms"][0])
+        assert abs(agent.last_grad_norms["encoder"] - tn) / tn < 2e-3
+        assert abs(float(agent.log_beta) - float(g[f"u{u}/log_beta"])) < 1e-5
+        # (the oracle starts every step from the GPU agent's pre-step encoder: Adam's sign-like first steps turn
+        # rounding differences in near-zero gradients into +-lr parameter differences, which is not what is compared)
+        oracle.update(*host, fx.make_noise(L, B, H, A, seed=101 + u))
+        want = torch.zeros(opt.numel)
+        for gr, o, p in zip(oracle.last["encoder_grads"], opt.offsets, opt.params):
+            want[o : o + p.numel()] = gr.reshape(-1)
+        e = ((snap["g"].cpu() - want).norm() / want.norm()).item()
+        log(f"[oracle finetune] update {u} flat encoder grad: l2 rel {e:.2e}")
+        assert e < 1e-3, e
+    have = {}
+    for m in fx.MODULES:
+        for k, v in getattr(agent, m).state_dict().items():
+            have[f"{m}.{k}"] = (float(v.double().sum()), float(v.double().abs().sum()))
+    for n, s_, a_ in zip((str(n) for n in g["param_names"]), g["param_sums"], g["param_abssums"]):
+        assert abs(have[n][1] - a_) <= 1e-3 * abs(a_) + 1e-6, (n, have[n][1], a_)
+        assert abs(have[n][0] - s_) <= 1e-3 * abs(a_) + 1e-6, (n, have[n][0], s_)
+    for m, before in frozen0.items():
+        after = torch.cat([p.detach().reshape(-1) for p in getattr(agent, m).parameters()])
+        assert torch.equal(before, after), m
+    # the encoder optimiser is a view of the model buffer: a world-model step afterwards sees the adapted encoder
+    enc_flat = torch.cat([p.detach().reshape(-1) for p in agent.encoder.parameters()])
+    assert torch.equal(agent.model_optimizer.flat[: agent.encoder_optimizer.numel][: enc_flat.numel()][:32], enc_flat[:32])
+
+
+def test_finetuned_repo_train_agent_and_source_checkpoint(tmp_path):
+    """train_agent() = encoder steps on replay batches; load_source_models() adopts a reference-layout models.pt."""
+    L, B, H, A = 6, 3, 4, 6
+    src, _ = make_finetuned(L, B, H, A)
+    torch.save(src.get_param_dict(), os.path.join(tmp_path, "models.pt"))
+    agent, cfg = make_finetuned(L, B, H, A, train_steps=3, source_dir=str(tmp_path), replay_size=64)
+    with torch.no_grad():
+        for p in agent.encoder.parameters():
+            p.add_(0.01)
+    agent.load_source_models()
+    for a, b in zip(agent.encoder.parameters(), src.encoder.parameters()):
+        assert torch.equal(a, b)
+    rs = np.random.RandomState(0)
+    for i in range(40):
+        agent.buffer.push(rs.randint(0, 256, (3, 64, 64)).astype(np.uint8), rs.uniform(-1, 1, A).astype(np.float32),
+                          float(rs.uniform()), i % 13 == 12)
+    enc0 = torch.cat([p.detach().reshape(-1).clone() for p in agent.encoder.parameters()])
+    agent.train_agent()
+    assert agent.encoder_optimizer.step_count == 3 and agent.beta_optimizer.step_count == 3
+    assert all(np.isfinite(v) for v in agent.last_scalars.values())
+    assert not torch.equal(enc0, torch.cat([p.detach().reshape(-1) for p in agent.encoder.parameters()]))
