@@ -138,13 +138,12 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
 #pragma unroll
   for (int kb = 0; kb < KBH; ++kb)
     WD[kb] = reinterpret_cast<const f32x4v*>(p.Wsq)[(size_t)(kb * 4 + lq) * 2 * S + min(wave * 16 + li, 2 * S - 1)];
-  f32x4v bD, bG;  // stage D bias quad; stage B: this wave's gate bias quad (r: b_ir + b_hr, z, b_in, b_hn)
+  f32x4v bD;  // stage D bias quad
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    bD[r] = p.bsq[min(wave * 16 + 4 * lq + r, 2 * S - 1)];
-    const int c = min(c0 + 4 * lq + r, D - 1);
-    bG[r] = wave == 0 ? p.bih[c] + p.bhh[c] : wave == 1 ? p.bih[D + c] + p.bhh[D + c] : wave == 2 ? p.bih[2 * D + c] : p.bhh[2 * D + c];
-  }
+  for (int r = 0; r < 4; ++r) bD[r] = p.bsq[min(wave * 16 + 4 * lq + r, 2 * S - 1)];
+  const int ecc = min(ec, D - 1);  // gate biases of the pointwise role's column
+  const float bg_r = p.bih[ecc] + p.bhh[ecc], bg_z = p.bih[D + ecc] + p.bhh[D + ecc];
+  const float bg_in = p.bih[2 * D + ecc], bg_hn = p.bhh[2 * D + ecc];
   const float b_q = p.bbq[min(ec, Hd - 1)];
   __syncthreads();
 
@@ -313,29 +312,38 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
       }
     }
     __syncthreads();
-    // ---- B: GRU pre-activations of the own columns; wave 0: r, 1: z (both W_ih e + W_hh h), 2: W_in e, 3: W_hn h
+    // ---- B: GRU pre-activations of the own columns, 6 products x KBD blocks spread evenly over the 4 waves:
+    //         wave 0: W_ir e, 1: W_hr h, 2: W_iz e, 3: W_hz h, then W_in e split over waves 0 / 1 and W_hn h over 2 / 3
+    //         (the sums meet in the pointwise phase: 78-80 MFMAs per wave instead of 104 on two of them)
     {
       f32x4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-      const float* wi = Wg + (wave < 3 ? wave : 0) * DP * 16;
-      const float* wh = Wg + (3 + (wave == 3 ? 2 : wave)) * DP * 16;
+      const bool from_e = (wave & 1) == 0;
+      const float* wfull = Wg + (wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 1 : 4) * DP * 16;
+      const float* xfull = from_e ? ES : HS;
 #pragma unroll
       for (int kb = 0; kb < KBD; ++kb) {
         const int o = ((kb * 4 + lq) * 16 + li) * 4;
-        if (wave != 3) a0 = mfma4(*reinterpret_cast<const f32x4v*>(wi + o), *reinterpret_cast<const f32x4v*>(ES + o), a0);
-        if (wave != 2) a1 = mfma4(*reinterpret_cast<const f32x4v*>(wh + o), *reinterpret_cast<const f32x4v*>(HS + o), a1);
+        a0 = mfma4(*reinterpret_cast<const f32x4v*>(wfull + o), *reinterpret_cast<const f32x4v*>(xfull + o), a0);
       }
-      f32x4v v;
+      constexpr int KH = (KBD + 1) / 2;
+      const float* whalf = Wg + (wave < 2 ? 2 : 5) * DP * 16;   // W_in (over e) / W_hn (over h)
+      const float* xhalf = wave < 2 ? ES : HS;
+      const int kb0 = (wave & 1) * KH;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float sum = a0[r] + a1[r] + bG[r];
-        v[r] = wave < 2 ? sigmoidf(sum) : sum;
-      }
-      *reinterpret_cast<f32x4v*>(G4 + wave * 256 + li * 16 + 4 * lq) = v;
+      for (int x = 0; x < KH; ++x)
+        if (kb0 + x < KBD) {
+          const int o = (((kb0 + x) * 4 + lq) * 16 + li) * 4;
+          a1 = mfma4(*reinterpret_cast<const f32x4v*>(whalf + o), *reinterpret_cast<const f32x4v*>(xhalf + o), a1);
+        }
+      // G4[0..3] = W_ir e, W_hr h, W_iz e, W_hz h;  PART[0..3] = the halves of W_in e (0, 1) and of W_hn h (2, 3)
+      *reinterpret_cast<f32x4v*>(G4 + wave * 256 + li * 16 + 4 * lq) = a0;
+      *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = a1;
     }
     __syncthreads();
     {
-      const float rg = G4[erow * 16 + ecol], zg = G4[256 + erow * 16 + ecol];
-      const float gin = G4[512 + erow * 16 + ecol], ghn = G4[768 + erow * 16 + ecol];
+      const int o = erow * 16 + ecol;
+      const float rg = sigmoidf(G4[o] + G4[256 + o] + bg_r), zg = sigmoidf(G4[512 + o] + G4[768 + o] + bg_z);
+      const float gin = PART[o] + PART[256 + o] + bg_in, ghn = PART[512 + o] + PART[768 + o] + bg_hn;
       const float ng = tanh_fast(gin + rg * ghn);
       const float hprev = HS[ai(ec, erow)];
       const float hn = (1.f - zg) * ng + zg * hprev;
