@@ -240,3 +240,25 @@ def test_module_autograd_wrappers(image):
     e = ((got - want).norm() / want.norm()).item()
     log(f"[autograd wrappers] loss {loss.item():.6g} vs {ol.item():.6g}; model grad l2 rel {e:.2e}")
     assert e < 5e-3
+
+
+def test_pipelined_updates_are_bit_deterministic():
+    """Two identically seeded agents, 25 pipelined updates each (in-kernel Philox noise, two 16-row groups in the
+    column-split scans): bit-identical parameters.  A stale or torn read in the scans' all-gathers through L2
+    (csrc/scan_cs.hip), or any other race between the update's streams, would show here (tools/determinism_soak.py is
+    the long version: 400 updates at B=50, 600 at B=7)."""
+    L, B, H, A = 12, 20, 6, 6
+    batches = [dev_batch(L, B, A, 300 + i)[0] for i in range(3)]
+    finals = []
+    for _ in range(2):
+        agent, _cfg = make_agent("repo", L, B, H, A)
+        agent.seed_noise(99)
+        for i in range(25):
+            agent.update(batches[i % 3], join=False)
+        agent.synchronize()
+        torch.cuda.synchronize()
+        assert all(np.isfinite(v) for v in agent.last_scalars.values())
+        finals.append([o.flat.clone() for o in (agent.model_optimizer, agent.actor_optimizer, agent.value_optimizer)]
+                      + [agent.log_beta.clone().reshape(1)])
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
