@@ -554,3 +554,30 @@ def test_column_split_reverse_scan_matches_row_scan(monkeypatch, T, B, A, philox
         worst = max(worst, err)
         assert err < 2e-5, (n, err)
     log(f"column-split reverse scan T={T} B={B} A={A} philox={philox}: worst l2 error vs the row scans {worst:.2e}")
+
+
+def test_scan_engine_selection(monkeypatch):
+    """REPO_SCAN_CS=auto: the column-split engine up to 64 rows at the reference's widths, the row scan beyond and for
+    `observations=None`; both give the same numbers at the boundary; T = 1 (the acting step) works on either."""
+    from repo_amd import ops
+
+    A, D, S, E = 6, 200, 30, 1024
+    p = cu(tparams("transition_model", A, requires_grad=False))
+    rs = np.random.RandomState(3)
+    dev = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()  # noqa: E731
+    monkeypatch.setenv("REPO_SCAN_CS", "auto")
+    for T, B, want_cs in ((1, 1, True), (3, 64, True), (3, 65, False)):
+        b0, s0 = dev(rs.standard_normal((B, D)) * 0.3), dev(rs.standard_normal((B, S)))
+        act, non = dev(rs.uniform(-1, 1, (T, B, A))), torch.ones(T, B).cuda()
+        emb = dev(np.maximum(rs.standard_normal((T, B, E)), 0))
+        sv = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0))
+        assert sv.cs == want_cs, (B, sv.cs)
+        monkeypatch.setenv("REPO_SCAN_CS", "0" if want_cs else "1")
+        other = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0))
+        monkeypatch.setenv("REPO_SCAN_CS", "auto")
+        assert other.cs != want_cs
+        for name in ("featx", "post_mean", "post_std", "prior_mean", "prior_std"):
+            a, b = getattr(sv, name), getattr(other, name)
+            assert float((a - b).abs().max() / (a.abs().max() + 1e-12)) < 2e-5, (B, name)
+    prior = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0), prior_only=True)
+    assert not prior.cs
