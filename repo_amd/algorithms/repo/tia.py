@@ -18,6 +18,7 @@ and stepped `tia_reward_train_steps` times afterwards).  Here that is two FlatAd
 load_param_dict merge / split them in the reference's parameter order (tia.py:71-82).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -156,16 +157,23 @@ class TIA(Dreamer):
         pr_d, gr_d = self._pg(self.distractor_transition_model)
         side = self._wgrad_stream
         dfeat_t = torch.empty(rows, D + S, device=dev)
-        ops.mlp_bwd(pw_t, feat_t, rt_hid, drew_t.view(rows, 1), dparams=gw_t, dx=dfeat_t)
-        Fn.decoder_bwd(pd_t, feat_t, (*saved_t, dt_out), gd_t, dfeat=dfeat_t, accumulate_dfeat=True, side=side)
         dembeds = torch.empty(rows, c.embedding_size, device=dev)
         dembeds_d = torch.empty(rows, c.embedding_size, device=dev)
         dfeat_d = torch.empty(rows, D + S, device=dev)
-        # the task filter's reverse scan (latency-bound, ~25 CUs) runs on the side stream beside the distractor
-        # side's three compute-bound backward passes; the distractor's reverse scan follows on this stream
+        # The task chain (reward head, task decoder, the task filter's reverse scan) and the distractor chain (reward,
+        # two decoders, reverse scan) meet only in the encoder backward: the task chain runs on the side stream with
+        # its weight gradients in line, the distractor chain here (REPO_TIA_SPLIT=0: only the task's reverse scan goes
+        # to the side stream)
         rs = side2 if side2 is not None else main
+        split = os.environ.get("REPO_TIA_SPLIT", "1") == "1" and side2 is not None
+        if not split:
+            ops.mlp_bwd(pw_t, feat_t, rt_hid, drew_t.view(rows, 1), dparams=gw_t, dx=dfeat_t)
+            Fn.decoder_bwd(pd_t, feat_t, (*saved_t, dt_out), gd_t, dfeat=dfeat_t, accumulate_dfeat=True, side=side)
         rs.wait_stream(main)
         with torch.cuda.stream(rs):
+            if split:
+                ops.mlp_bwd(pw_t, feat_t, rt_hid, drew_t.view(rows, 1), dparams=gw_t, dx=dfeat_t)
+                Fn.decoder_bwd(pd_t, feat_t, (*saved_t, dt_out), gd_t, dfeat=dfeat_t, accumulate_dfeat=True, side=None)
             ops.rssm_observe_bwd(pr_t, sv_t, gr_t, dfeat=dfeat_t, dpm=klg_t[0], dps=klg_t[1], dqm=klg_t[2],
                                  dqs=klg_t[3], dembeds=dembeds, min_std=self.transition_model.min_std_dev)
         # -- distractor side: adversarial reward (input gradient only), both decoders, reverse scan
