@@ -4,8 +4,10 @@
 //
 // rssm.hip's scan gives a workgroup 1-2 batch rows and streams ALL in-scan weights (1.2 MB) from L2 every step:
 // 17-20 us per step whatever B is.  Here the weights never move: NW = ceil(D/16) workgroups each own 16 belief /
-// hidden columns -- their slices of W_ih, W_hh (6 x D x 16) and W_bq (D x 16) stay in LDS for all T steps, the two
-// small replicated layers (W_sa: (S+A) -> D, W_sq: Hd -> 2S) in registers -- and every workgroup carries the same 16
+// hidden columns -- their slices of W_ih, W_hh (6 x D x 16), W_bq (D x 16) and the two small replicated layers (W_sa:
+// (S+A) -> D, W_sq: Hd -> 2S) stay in REGISTERS for all T steps, each lane holding exactly the MFMA fragments it feeds
+// (LDS holds activation tiles only, 57 / 67 KB, so the CU stays open to the convolutions of the other lanes: +0.9 % on the
+// update against LDS-resident slices, which were 4 % faster alone) -- and every workgroup carries the same 16
 // batch rows (one v_mfma_f32_16x16x4_f32 row tile; more rows = more independent groups of NW workgroups).  Per step:
 //   A  e = elu(W_sa x + b)                    all D columns, replicated                     (13 tiles x 3 blocks)
 //   B  GRU gates of the OWN 16 columns        K = D over e and over belief                  (6 x 13 blocks)
@@ -85,9 +87,7 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
   constexpr int KP = DP > HP ? DP : HP;
   const int T = p.T, B = p.B, A = p.A, D = p.D, Hd = p.Hd, S = p.S;
   const int X = S + A, F = D + S;
-  float* Wg = lds;                    // [6][DP*16]: W_ih r, z, n | W_hh r, z, n slices of the own columns
-  float* Wq = Wg + 6 * DP * 16;       // [DP*16]
-  float* XS = Wq + DP * 16;           // tiles, k4-interleaved: x, e, belief, hq
+  float* XS = lds;                    // tiles, k4-interleaved: x, e, belief, hq
   float* ES = XS + XP * 16;
   float* HS = ES + DP * 16;
   float* QS = HS + DP * 16;
@@ -109,19 +109,27 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
   // ---- zero the activation tiles (their K padding must stay finite), load the stationary weights
   for (int i = tid; i < XP * 16 + 2 * DP * 16 + HP * 16 + 2 * 4 * 256 + 16 * 64 + 16 * 32; i += 256) XS[i] = 0.f;
   if (tid == 0) s_abort = 0;
+  // ---- every weight this workgroup multiplies by is REGISTER-stationary: a lane keeps exactly the fragments it feeds
+  //      the MFMAs with (column `own` = its column of the own 16, k = 16 kb + 4 lq + 0..3) -- 196 VGPRs; LDS holds the
+  //      activation tiles only (57 KB), so the CU stays open to the other lanes' convolution workgroups
+  const int own = min(c0 + li, D - 1), ownh = min(c0 + li, Hd - 1);
+  constexpr int KH = (KBD + 1) / 2;   // blocks of a half of the K = D reduction
+  f32x4v WBf[KBD], WBh[KH], WC[(KBD + 3) / 4];
   {
-    const f32x4v* Wih4 = reinterpret_cast<const f32x4v*>(p.Wih);
-    const f32x4v* Whh4 = reinterpret_cast<const f32x4v*>(p.Whh);
-    const f32x4v* Wbq4 = reinterpret_cast<const f32x4v*>(p.Wbq);
-    for (int i = tid; i < (DP / 4) * 16; i += 256) {
-      const int kg = i >> 4, col = min(c0 + (i & 15), D - 1), colh = min(c0 + (i & 15), Hd - 1);
+    // stage B: wave 0: W_ir, 1: W_hr, 2: W_iz, 3: W_hz (whole K); then W_in halves on waves 0 / 1, W_hn halves on 2 / 3
+    const f32x4v* full = reinterpret_cast<const f32x4v*>((wave & 1) ? p.Whh : p.Wih);
+    const int gfull = wave >> 1;
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        reinterpret_cast<f32x4v*>(Wg + g * DP * 16)[i] = Wih4[(size_t)kg * 3 * D + g * D + col];
-        reinterpret_cast<f32x4v*>(Wg + (3 + g) * DP * 16)[i] = Whh4[(size_t)kg * 3 * D + g * D + col];
-      }
-      reinterpret_cast<f32x4v*>(Wq)[i] = Wbq4[(size_t)kg * Hd + colh];
-    }
+    for (int kb = 0; kb < KBD; ++kb) WBf[kb] = full[(size_t)(kb * 4 + lq) * 3 * D + gfull * D + own];
+    const f32x4v* half = reinterpret_cast<const f32x4v*>(wave < 2 ? p.Wih : p.Whh);
+    const int kbh = (wave & 1) * KH;
+#pragma unroll
+    for (int x = 0; x < KH; ++x) WBh[x] = half[(size_t)(min(kbh + x, KBD - 1) * 4 + lq) * 3 * D + 2 * D + own];
+    // stage C: this wave's blocks of the K = D reduction of W_bq
+    const int kc0 = (wave * KBD) / 4;
+#pragma unroll
+    for (int x = 0; x < (KBD + 3) / 4; ++x)
+      WC[x] = reinterpret_cast<const f32x4v*>(p.Wbq)[(size_t)(min(kc0 + x, KBD - 1) * 4 + lq) * Hd + ownh];
   }
   // register-stationary: W_sa tiles wave, wave+4, ... (stage A), W_sq tile `wave` (stage D)
   constexpr int NTD = KBD;  // column tiles of D
@@ -317,24 +325,16 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
     //         (the sums meet in the pointwise phase: 78-80 MFMAs per wave instead of 104 on two of them)
     {
       f32x4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-      const bool from_e = (wave & 1) == 0;
-      const float* wfull = Wg + (wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 1 : 4) * DP * 16;
-      const float* xfull = from_e ? ES : HS;
+      const float* xfull = (wave & 1) == 0 ? ES : HS;
 #pragma unroll
-      for (int kb = 0; kb < KBD; ++kb) {
-        const int o = ((kb * 4 + lq) * 16 + li) * 4;
-        a0 = mfma4(*reinterpret_cast<const f32x4v*>(wfull + o), *reinterpret_cast<const f32x4v*>(xfull + o), a0);
-      }
-      constexpr int KH = (KBD + 1) / 2;
-      const float* whalf = Wg + (wave < 2 ? 2 : 5) * DP * 16;   // W_in (over e) / W_hn (over h)
+      for (int kb = 0; kb < KBD; ++kb)
+        a0 = mfma4(WBf[kb], *reinterpret_cast<const f32x4v*>(xfull + ((kb * 4 + lq) * 16 + li) * 4), a0);
       const float* xhalf = wave < 2 ? ES : HS;
       const int kb0 = (wave & 1) * KH;
 #pragma unroll
       for (int x = 0; x < KH; ++x)
-        if (kb0 + x < KBD) {
-          const int o = (((kb0 + x) * 4 + lq) * 16 + li) * 4;
-          a1 = mfma4(*reinterpret_cast<const f32x4v*>(whalf + o), *reinterpret_cast<const f32x4v*>(xhalf + o), a1);
-        }
+        if (kb0 + x < KBD)
+          a1 = mfma4(WBh[x], *reinterpret_cast<const f32x4v*>(xhalf + (((kb0 + x) * 4 + lq) * 16 + li) * 4), a1);
       // G4[0..3] = W_ir e, W_hr h, W_iz e, W_hz h;  PART[0..3] = the halves of W_in e (0, 1) and of W_hn h (2, 3)
       *reinterpret_cast<f32x4v*>(G4 + wave * 256 + li * 16 + 4 * lq) = a0;
       *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = a1;
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
     {
       f32x4v acc = {0.f, 0.f, 0.f, 0.f};
       const int kb0 = (wave * KBD) / 4, kb1 = ((wave + 1) * KBD) / 4;
-      for (int kb = kb0; kb < kb1; ++kb) {
-        const int o = ((kb * 4 + lq) * 16 + li) * 4;
-        acc = mfma4(*reinterpret_cast<const f32x4v*>(Wq + o), *reinterpret_cast<const f32x4v*>(HS + o), acc);
-      }
+#pragma unroll
+      for (int x = 0; x < (KBD + 3) / 4; ++x)
+        if (kb0 + x < kb1)
+          acc = mfma4(WC[x], *reinterpret_cast<const f32x4v*>(HS + (((kb0 + x) * 4 + lq) * 16 + li) * 4), acc);
       *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = acc;
     }
     __syncthreads();
@@ -463,7 +463,7 @@ int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   a.xbuf = xbuf; a.flags = flags; a.err = err;
   a.spin_limit = 1 << 22;
   constexpr int DP = 208, HP = 208, XP = 48;
-  const size_t lds_b = (size_t)(7 * DP * 16 + XP * 16 + 2 * DP * 16 + HP * 16 + 2 * 4 * 256 + 16 * 64 + 16 * 32) * sizeof(float);
+  const size_t lds_b = (size_t)(XP * 16 + 2 * DP * 16 + HP * 16 + 2 * 4 * 256 + 16 * 64 + 16 * 32) * sizeof(float);
   he = hipFuncSetAttribute((const void*)observe_cs_fwd_kernel<3, 13, 13>, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)lds_b);
   if (he != hipSuccess) return (int)he;
@@ -482,7 +482,7 @@ int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
 //   3  d belief_{t-1} += W_hh^T d gh ; d e = W_ih^T d gi          own columns, K = 3D, K split     78 blocks
 //   X2 all-gather of d e_pre = d e * elu'(e)
 //   4  d state_{t-1} = (W_sa[:, :S]^T d e_pre) * nonterm          replicated (W_sa^T in registers) 2 tiles x 13 blocks
-// LDS-resident: the own-column slices of W_hh^T and W_ih^T (2 x 3 x D x 16 floats = 80 KB).
+// Every weight fragment is register-stationary (a lane keeps what it feeds the MFMAs with); LDS: the activation tiles.
 struct CsBwdArgs {
   int T, B, A, D, Hd, S;
   const float *WsqT, *WbqT, *WhhT, *WihT, *WsaT;  // pack16: [k/4][N][4]; WhhT / WihT: 3 packs (one per gate) back to back
@@ -504,9 +504,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
   constexpr int KBO = 4;  // 16-k blocks of 2S (<= 64)
   const int T = p.T, B = p.B, D = p.D, Hd = p.Hd, S = p.S;
   const int F = D + S;
-  float* Wh = lds;               // [3][DP*16]: W_hh^T slices, gates r, z, n(hn)
-  float* Wi = Wh + 3 * DP * 16;  // [3][DP*16]: W_ih^T slices, gates r, z, n
-  float* G = Wi + 3 * DP * 16;   // [4][TS]: g_r, g_z, g_n, g_hn tiles; G[3] doubles as the dhq tile, G[0] as d e_pre
+  float* G = lds;                // [4][TS]: g_r, g_z, g_n, g_hn tiles; G[3] doubles as the dhq tile, G[0] as d e_pre
   float* DO = G + 4 * TS;        // [64 x 16] posterior output deltas
   float* PART = DO + 64 * 16;    // [2][4][256]
   float* DST = PART + 2 * 4 * 256;  // [16][32] carried d state
@@ -523,14 +521,18 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
 
   for (int i = tid; i < 4 * TS + 64 * 16 + 2 * 4 * 256 + 16 * 32; i += 256) G[i] = 0.f;
   if (tid == 0) s_abort = 0;
-  for (int i = tid; i < (DP / 4) * 16; i += 256) {
-    const int kg = i >> 4, col = min(c0 + (i & 15), D - 1);
+  // stage 3's weights (the own-column slices of W_hh^T and W_ih^T, K = 3 D as (gate, block) pairs split over the
+  // waves) are register-stationary like everything else: LDS holds the activation tiles only (67 KB)
+  constexpr int NB3 = 3 * KBD, MX3 = (NB3 + 3) / 4;
+  const int x3_0 = (wave * NB3) / 4, x3_1 = ((wave + 1) * NB3) / 4;
+  f32x4v WH3[MX3], WI3[MX3];
+  {
+    const int own = min(c0 + li, D - 1);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      reinterpret_cast<f32x4v*>(Wh + g * DP * 16)[i] =
-          reinterpret_cast<const f32x4v*>(p.WhhT + (size_t)g * DP * D)[(size_t)kg * D + col];
-      reinterpret_cast<f32x4v*>(Wi + g * DP * 16)[i] =
-          reinterpret_cast<const f32x4v*>(p.WihT + (size_t)g * DP * D)[(size_t)kg * D + col];
+    for (int i = 0; i < MX3; ++i) {
+      const int x = min(x3_0 + i, NB3 - 1), g = x / KBD, kb = x % KBD;
+      WH3[i] = reinterpret_cast<const f32x4v*>(p.WhhT + (size_t)g * DP * D)[(size_t)(kb * 4 + lq) * D + own];
+      WI3[i] = reinterpret_cast<const f32x4v*>(p.WihT + (size_t)g * DP * D)[(size_t)(kb * 4 + lq) * D + own];
     }
   }
   // register-stationary weights
@@ -792,15 +794,17 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
     //         over the waves as (gate, block) pairs
     {
       f32x4v ah = {0.f, 0.f, 0.f, 0.f}, ae = ah;
-      constexpr int NB3 = 3 * KBD;
-      const int x0 = (wave * NB3) / 4, x1 = ((wave + 1) * NB3) / 4;
-      for (int x = x0; x < x1; ++x) {
-        const int g = x / KBD, kb = x % KBD;
-        const int o = ((kb * 4 + lq) * 16 + li) * 4;
-        const f32x4v gi4 = *reinterpret_cast<const f32x4v*>(G + g * TS + o);
-        const f32x4v gh4 = g < 2 ? gi4 : *reinterpret_cast<const f32x4v*>(G + 3 * TS + o);
-        ah = mfma4(*reinterpret_cast<const f32x4v*>(Wh + g * DP * 16 + o), gh4, ah);
-        ae = mfma4(*reinterpret_cast<const f32x4v*>(Wi + g * DP * 16 + o), gi4, ae);
+#pragma unroll
+      for (int i = 0; i < MX3; ++i) {
+        const int x = x3_0 + i;
+        if (x < x3_1) {
+          const int g = x / KBD, kb = x % KBD;
+          const int o = ((kb * 4 + lq) * 16 + li) * 4;
+          const f32x4v gi4 = *reinterpret_cast<const f32x4v*>(G + g * TS + o);
+          const f32x4v gh4 = g < 2 ? gi4 : *reinterpret_cast<const f32x4v*>(G + 3 * TS + o);
+          ah = mfma4(WH3[i], gh4, ah);
+          ae = mfma4(WI3[i], gi4, ae);
+        }
       }
       *reinterpret_cast<f32x4v*>(PART + wave * 256 + li * 16 + 4 * lq) = ah;
       *reinterpret_cast<f32x4v*>(PART + 1024 + wave * 256 + li * 16 + 4 * lq) = ae;
@@ -895,7 +899,7 @@ int scan_cs_bwd(const ScanCsBwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   a.xbuf = xbuf; a.flags = flags; a.err = err;
   a.spin_limit = 1 << 22;
   constexpr int DP = 208, TS = 208 * 16;
-  const size_t lds_b = (size_t)(6 * DP * 16 + 4 * TS + 64 * 16 + 2 * 4 * 256 + 16 * 32) * sizeof(float);
+  const size_t lds_b = (size_t)(4 * TS + 64 * 16 + 2 * 4 * 256 + 16 * 32) * sizeof(float);
   he = hipFuncSetAttribute((const void*)observe_cs_bwd_kernel<13, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
   if (he != hipSuccess) return (int)he;
   hipLaunchKernelGGL((observe_cs_bwd_kernel<13, 13>), dim3((unsigned)NW, (unsigned)G), dim3(256), lds_b, s, a);
