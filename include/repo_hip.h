@@ -203,10 +203,11 @@ int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStre
  *          hp, hq (T,B,Hd); eemb (T,B,Hd) is scratch for the hoisted embedding GEMM.
  * prior_only == 2: the scan leaves the prior head out (repo_rssm_prior_head below computes it for all steps).
  * prior_only == 3: as 2, on the COLUMN-SPLIT, WEIGHT-STATIONARY engine (csrc/scan_cs.hip): ceil(D/16) workgroups per
- *          16 batch rows each keep their 16-column slices of W_ih / W_hh / W_bq in LDS for all T steps, the row tile
- *          runs on v_mfma_f32_16x16x4_f32 and the belief / posterior-hidden activations are all-gathered through L2
- *          twice per step (sc1 stores + flags).  ~12.5 us per step for any B <= 64 (the row scan: 18-20); shapes
- *          D, Hd in (192, 208], S + A in (32, 48], S <= 32 only (else REPO_E_SHAPE).
+ *          16 batch rows each keep their 16-column slices of W_ih / W_hh / W_bq (and the small replicated layers) in
+ *          REGISTERS for all T steps, the row tile runs on v_mfma_f32_16x16x4_f32 and the belief / posterior-hidden
+ *          activations are all-gathered through L2 twice per step (sc1 write-through stores, data-tagged granules).
+ *          ~8.5 us per step in the kernel for any B <= 64 (the row scan: 17-19); shapes D, Hd in (192, 208], S + A in
+ *          (32, 48], S <= 32 only (else REPO_E_SHAPE).  The workspace must not be shared with a concurrent call.
  * prior_only == 1: the reference's `observations=None` branch (rssm.py:118): step t+1 is fed the PRIOR sample of
  *          step t, featx[t+1][D:] = prior sample; the posterior outputs are then computed from whatever
  *          `embeds` holds and mean nothing (forward only: repo_rssm_observe_bwd assumes prior_only == 0). */
