@@ -29,6 +29,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
+# --out DIR: write the fixtures somewhere else (tests/test_golden_recipe.py regenerates into a temp dir and compares)
+OUT = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
 
 from oracle import fixtures as fx  # noqa: E402
 
@@ -316,26 +318,27 @@ def main():
     install_patches(feeder, record)
 
     if "--finetune-only" in sys.argv:
-        run_finetune_case(8, 4, 6, 3, feeder, record, os.path.join(HERE, "finetune_tiny.npz"))
+        run_finetune_case(8, 4, 6, 3, feeder, record, os.path.join(OUT, "finetune_tiny.npz"))
         return
     if "--tia-only" in sys.argv:
-        run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(HERE, "tia_tiny.npz"))
-        run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(HERE, "tia_coefs.npz"), tia_obs_coef=0.5,
+        run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(OUT, "tia_tiny.npz"))
+        run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(OUT, "tia_coefs.npz"), tia_obs_coef=0.5,
                      tia_adv_coef=2.0, tia_reward_train_steps=2)
         return
     # tiny unit-test size, full latents
-    run_case(RePo, "repo", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(HERE, "repo_tiny.npz"))
+    run_case(RePo, "repo", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(OUT, "repo_tiny.npz"))
     # config 5: Dreamer objective (free-nats KL, attached decoder)
-    run_case(Dreamer, "dreamer", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(HERE, "dreamer_tiny.npz"))
+    run_case(Dreamer, "dreamer", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(OUT, "dreamer_tiny.npz"))
     # ragged / odd sizes: B not a multiple of anything, A=7 (config 4's action size)
-    run_case(RePo, "repo", 6, 3, 3, 7, 2, True, feeder, record, os.path.join(HERE, "repo_odd.npz"))
+    run_case(RePo, "repo", 6, 3, 3, 7, 2, True, feeder, record, os.path.join(OUT, "repo_odd.npz"))
     # config 1 shapes, scalar + sliced latents only
-    run_case(RePo, "repo", 50, 16, 15, 6, 2, False, feeder, record, os.path.join(HERE, "repo_c1.npz"))
+    if "--skip-c1" not in sys.argv:  # the one fixture that takes a minute of CPU
+        run_case(RePo, "repo", 50, 16, 15, 6, 2, False, feeder, record, os.path.join(OUT, "repo_c1.npz"))
     # FinetunedRePo (f4): encoder-only adaptation, beta large enough for the KL term to matter
-    run_finetune_case(8, 4, 6, 3, feeder, record, os.path.join(HERE, "finetune_tiny.npz"))
+    run_finetune_case(8, 4, 6, 3, feeder, record, os.path.join(OUT, "finetune_tiny.npz"))
     # TIA (f4): default coefficients, and non-default ones with two distractor-reward fitting steps
-    run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(HERE, "tia_tiny.npz"))
-    run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(HERE, "tia_coefs.npz"), tia_obs_coef=0.5,
+    run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(OUT, "tia_tiny.npz"))
+    run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(OUT, "tia_coefs.npz"), tia_obs_coef=0.5,
                  tia_adv_coef=2.0, tia_reward_train_steps=2)
 
 
