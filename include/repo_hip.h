@@ -33,7 +33,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define REPO_ABI_VERSION 4
+#define REPO_ABI_VERSION 5
 
 #define REPO_OK 0
 #define REPO_E_BADARG (-1)
@@ -63,6 +63,10 @@ const char* repo_strerror(int code);
 int repo_device_check(int device);
 /* Test aid: fills every CU's LDS with NaN patterns (see tests/test_ops_gpu.py::test_no_uninitialised_lds). */
 int repo_debug_poison_lds(hipStream_t stream);
+/* Test aid: polls a spin-wait of the column-split scans makes before it gives up (default 1 << 22; `polls` < 0
+ * restores it).  Process-wide and meant for tests only (tests/test_rssm_gpu.py::test_scan_timeout_reaches_the_host
+ * sets 0 to see the status word of repo_rssm_observe_fwd / _bwd raised); returns the previous value. */
+int repo_debug_scan_spin_limit(int polls);
 
 /* ------------------------------------------------------------------ reparameterisation noise
  * The reference draws its noise from torch's global generator (torch.randn_like in models/rssm.py:49,61-63;
@@ -210,7 +214,17 @@ int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStre
  *          (32, 48], S <= 32 only (else REPO_E_SHAPE).  The workspace must not be shared with a concurrent call.
  * prior_only == 1: the reference's `observations=None` branch (rssm.py:118): step t+1 is fed the PRIOR sample of
  *          step t, featx[t+1][D:] = prior sample; the posterior outputs are then computed from whatever
- *          `embeds` holds and mean nothing (forward only: repo_rssm_observe_bwd assumes prior_only == 0). */
+ *          `embeds` holds and mean nothing (forward only: repo_rssm_observe_bwd assumes prior_only == 0).
+ * status: ASYNCHRONOUS errors.  A launch error is this call's return value; what can only be known once the kernel runs
+ *          is reported through `status`, a caller-owned device word (nullable; zero it once, it is sticky): the
+ *          column-split engine's exchanges are cross-workgroup spin-waits, and a group whose peers do not answer within
+ *          the spin limit (2^22 polls; a peer workgroup that never became resident) ORs REPO_SCAN_STATUS_FWD_TIMEOUT
+ *          (the reverse scan: REPO_SCAN_STATUS_BWD_TIMEOUT) into it, writes NaN into its outputs and leaves -- it never
+ *          hangs.  The caller reads the word whenever it next copies results to the host (the agents: inside their one
+ *          per-update scalar copy, algorithms/repo/dreamer.py `_log_update`, raising RepoHipError).  The row-scan
+ *          engine has no cross-workgroup waits and never touches it. */
+#define REPO_SCAN_STATUS_FWD_TIMEOUT 1u
+#define REPO_SCAN_STATUS_BWD_TIMEOUT 2u
 size_t repo_rssm_observe_fwd_workspace_bytes(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd,
                                              int64_t S, int64_t E);
 int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t E,
@@ -220,8 +234,8 @@ int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd
                           uint64_t noise_seed, uint64_t noise_offset,
                           float min_std, float* featx, float* prior_state, float* prior_mean,
                           float* prior_std, float* post_mean, float* post_std, float* xsa, float* e,
-                          float* gates, float* hp, float* hq, float* eemb, int prior_only, void* ws,
-                          size_t ws_bytes, hipStream_t stream);
+                          float* gates, float* hp, float* hq, float* eemb, int prior_only, unsigned* status,
+                          void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* The prior head (fc_embed_belief_prior, fc_state_prior, softplus + sample: rssm.py:42-50) of ALL T steps at once.
  * It depends on belief_t only, i.e. it is off the recurrence: repo_rssm_observe_fwd(prior_only = 2) leaves it out of
@@ -256,7 +270,7 @@ int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D, int64_t Hd
                           const float* hq, const float* dfeat, const float* dprior_state,
                           const float* dpm, const float* dps, const float* dqm, const float* dqs,
                           float* const* dparams, float* dembeds, float* dprev_belief,
-                          float* dprev_state, int accumulate, void* ws, size_t ws_bytes,
+                          float* dprev_state, int accumulate, unsigned* status, void* ws, size_t ws_bytes,
                           hipStream_t stream);
 
 /* ------------------------------------------------------------------ ELU-MLP heads

@@ -191,9 +191,18 @@ class Dreamer:
             return None
         return torch.randn(*shape, device=self.device)
 
-    # one update draws 2*T*B*S + Hm*N*(A+S) + 100*Hm*N*A normals (21.3 M at B=50, L=50, H=15, A=6): a resumed run
-    # skips 2**26 per optimiser step already taken, so it never replays the noise of the run that wrote the checkpoint
-    _NOISE_STRIDE_PER_STEP = 1 << 26
+    _N_SCANS = 1   # observe scans per update (TIA: 2)
+
+    def _noise_stride(self):
+        """Upper bound (a power of two) of the normals ONE update draws at this configuration:
+        scans * 2*T*B*S + Hm*N*(A+S) + samples*Hm*N*A (21.3 M at B=50, L=50, H=15, A=6 -> 2**25; it grows with B, A and
+        the horizon, so it is computed, not a constant).  A resumed run skips this many per optimiser step already
+        taken and therefore never replays the noise of the run that wrote the checkpoint."""
+        c = self.c
+        T, B, Hm = c.chunk_size - 1, c.batch_size, c.horizon - 1
+        S, A, N = self.transition_model.state_size, self.action_size, T * B
+        per_update = self._N_SCANS * 2 * T * B * S + Hm * N * (A + S) + self.actor_model._samples * Hm * N * A
+        return 1 << max(int(per_update) - 1, 1).bit_length()
 
     def seed_noise(self, seed):
         """Re-key the in-kernel Philox stream of the update's reparameterisation noise and rewind its counter."""
@@ -460,6 +469,8 @@ class Dreamer:
                  self.value_optimizer.sqnorm, xn]
         if dual is not None:
             parts.append(dual)
+        # LAST: the scans' sticky status word (bits reinterpreted, the copy is exact), see ops.scan_status
+        parts.append(ops.scan_status(self.device).view(torch.float32))
         buf = torch.cat([p.reshape(-1) for p in parts])
         # the leading entries (losses) are per-rank partial sums; the gradient norms behind them are already global
         self._allreduce_scalars(buf, n_sum=sum(p.numel() for p in parts[:6]))
@@ -479,7 +490,8 @@ class Dreamer:
         self._log_pending = None
         ev.synchronize()
         c = self.c
-        h = self._log_host[:n].tolist()
+        ops.raise_scan_status(int(self._log_host[n - 1 : n].view(torch.int32).item()))
+        h = self._log_host[: n - 1].tolist()
         nll, rsq, rmask, kl, ret, ent, lat, vsq, _vn = h[:9]
         xsums, h = h[9 : 9 + nxs], h[:9] + h[9 + nxs :]
         gm, ga_, gv_ = h[9:12]
@@ -757,7 +769,7 @@ class Dreamer:
         self.value_optimizer.load_state_dict(params["value_optimizer"])
         # the checkpoint keeps the reference's key layout (no noise state in it): resume behind every normal the
         # saved run can have drawn, instead of replaying the first updates' noise at offset 0
-        self._noise_counter = max(self._noise_counter, self.model_optimizer.step_count * self._NOISE_STRIDE_PER_STEP)
+        self._noise_counter = max(self._noise_counter, self.model_optimizer.step_count * self._noise_stride())
 
     def load_offline_data(self):
         """Replace the replay ring by the concatenation of every `buffer*.npz` under c.offline_dir

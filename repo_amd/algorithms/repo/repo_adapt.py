@@ -78,9 +78,9 @@ class FinetunedRePo(RePo):
                       betas=bo.betas, eps=bo.eps, out=self._dual_out)
         # logging: one asynchronous copy, read when first needed
         self._flush_enc_log()
-        buf = torch.cat([rew_sums, self._dual_out, opt.sqnorm])
+        buf = torch.cat([rew_sums, self._dual_out, opt.sqnorm, ops.scan_status(dev).view(torch.float32)])
         self._allreduce_scalars(buf, n_sum=2)
-        self._enc_host[:7].copy_(buf, non_blocking=True)
+        self._enc_host[:8].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         self._enc_log = (ev, grow)
@@ -91,6 +91,7 @@ class FinetunedRePo(RePo):
         ev, grow = self._enc_log
         self._enc_log = None
         ev.synchronize()
+        ops.raise_scan_status(int(self._enc_host[7:8].view(torch.int32).item()))
         rsq, rmask, kl_div, kl_loss, beta_loss, beta, gsq = self._enc_host[:7].tolist()
         reward_loss = (rsq + 0.5 * LOG_2PI * rmask) / grow
         out = {"train/reward_loss": reward_loss, "train/kl_loss": kl_loss, "train/kl_div": kl_div,

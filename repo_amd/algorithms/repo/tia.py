@@ -31,7 +31,13 @@ from .models.rssm import TransitionModel
 from .models.utils import FlatAdam, adam_param_group
 
 
+TIA_EXTRA_KEYS = ("distractor_transition_model", "distractor_obs_model", "distractor_only_obs_model",
+                  "distractor_reward_model", "mask_head")
+
+
 class TIA(Dreamer):
+    _N_SCANS = 2   # task + distractor observe scans draw noise (Dreamer._noise_stride)
+
     # ------------------------------------------------------------------ construction
     def build_models(self, config, env):
         super().build_models(config, env)
@@ -248,6 +254,10 @@ class TIA(Dreamer):
         # not in its checkpoints); the model optimiser's state covers all of model_params
         params = super().get_param_dict()
         params["model_optimizer"] = self._merged_model_state()
+        # EXTRA keys behind the reference's (its loader reads its own keys only, so the layout stays compatible): without
+        # them a resumed TIA run restores the Adam moments of five modules whose weights restart from their initial values
+        for k in TIA_EXTRA_KEYS:
+            params[k] = getattr(self, k).state_dict()
         return params
 
     def load_param_dict(self, params):
@@ -262,3 +272,11 @@ class TIA(Dreamer):
                     sub["state"][k] = st
             opt.load_state_dict(sub)
         super().load_param_dict({**params, "model_optimizer": main.state_dict()})
+        missing = [k for k in TIA_EXTRA_KEYS if k not in params]
+        for k in TIA_EXTRA_KEYS:
+            if k in params:
+                self._load_module(getattr(self, k), params[k])
+        if missing:   # a reference-written checkpoint: the reference resumes the same way
+            import warnings
+            warnings.warn(f"TIA checkpoint without {missing}: these modules keep their current weights while their "
+                          "Adam state is restored (the reference's TIA saves Dreamer's keys only)")

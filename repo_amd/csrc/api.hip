@@ -91,3 +91,12 @@ extern "C" int repo_debug_poison_lds(hipStream_t stream) {
   e = hipGetLastError();
   return e == hipSuccess ? REPO_OK : (int)e;
 }
+
+// Test aid: the spin limit of the column-split scans' exchanges (scan_cs.hip reads it per launch).
+namespace repo {
+static std::atomic<int> g_scan_spin_limit{1 << 22};
+int scan_cs_spin_limit() { return g_scan_spin_limit.load(std::memory_order_relaxed); }
+}  // namespace repo
+extern "C" int repo_debug_scan_spin_limit(int polls) {
+  return repo::g_scan_spin_limit.exchange(polls < 0 ? (1 << 22) : polls, std::memory_order_relaxed);
+}

@@ -497,7 +497,10 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
 extern "C" size_t repo_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int splits = wgrad_splits(M, N, K);
-  if (splits < kWdMaxSplits) splits = kWdMaxSplits;  // room for the direct kernel's row ranges (wgrad_direct.h)
+  // room for the direct kernel's row ranges (wgrad_direct.h) -- only for jobs that can take that path (its shape
+  // conditions; the leading dimensions are not known here): a 128-slab floor for every job made decoder fc1's and
+  // W_bq's workspaces 6-10x larger than the tile engine needs
+  if (wgrad_direct_ok(M, N, K, 4, 4) && splits < kWdMaxSplits) splits = kWdMaxSplits;
   return (size_t)splits * (size_t)N * (size_t)(K + 1) * sizeof(float);
 }
 

@@ -832,7 +832,8 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
                                      uint64_t noise_offset, float min_std, float* featx,
                                      float* prior_state, float* prior_mean, float* prior_std, float* post_mean,
                                      float* post_std, float* xsa, float* e, float* gates, float* hp, float* hq,
-                                     float* eemb, int prior_only, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                     float* eemb, int prior_only, unsigned* status, void* ws, size_t ws_bytes,
+                                     hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0, REPO_E_SHAPE);
   REPO_REQUIRE(params && prev_belief && prev_state && actions && nonterms && embeds && !eps_prior == !eps_post,
@@ -851,7 +852,7 @@ extern "C" int repo_rssm_observe_fwd(int64_t T, int64_t B, int64_t A, int64_t D,
     if (rc3) return rc3;
     ScanCsFwd q{T, B, A, D, Hd, S, E, params, prev_belief, prev_state, actions, nonterms, eemb,
                 NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)}, min_std,
-                featx, post_mean, post_std, xsa, e, gates, hq};
+                featx, post_mean, post_std, xsa, e, gates, hq, status};
     return scan_cs_fwd(q, ws, ws_bytes, stream);
   }
   float* w = (float*)ws;
@@ -1019,8 +1020,8 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
                                      const float* gates, const float* hp, const float* hq, const float* dfeat,
                                      const float* dprior_state, const float* dpm, const float* dps, const float* dqm,
                                      const float* dqs, float* const* dparams, float* dembeds, float* dprev_belief,
-                                     float* dprev_state, int accumulate, void* ws, size_t ws_bytes,
-                                     hipStream_t stream) {
+                                     float* dprev_state, int accumulate, unsigned* status, void* ws,
+                                     size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(dims_ok(T, B, A, D, Hd, S) && E > 0 && T > 0, REPO_E_SHAPE);
   REPO_REQUIRE(params && nonterms && embeds && !eps_prior == !eps_post && featx && prior_std && post_std && xsa && e &&
@@ -1062,7 +1063,7 @@ extern "C" int repo_rssm_observe_bwd(int64_t T, int64_t B, int64_t A, int64_t D,
     void* cws = (void*)(((uintptr_t)(dbx + rows * D) + 255) & ~(uintptr_t)255);
     ScanCsBwd q{T, B, A, D, Hd, S, E, params, nonterms,
                 NoiseSrc{eps_post, noise_seed, noise_offset + (uint64_t)(T * B * S)}, min_std,
-                featx, post_std, e, gates, hq, dfeat, dqm, dqs, dbx, doutq, dhq, dgi, dgh, de, dprev_belief, dprev_state};
+                featx, post_std, e, gates, hq, dfeat, dqm, dqs, dbx, doutq, dhq, dgi, dgh, de, dprev_belief, dprev_state, status};
     if ((rc1 = scan_cs_bwd(q, cws, slab_bytes - ((uintptr_t)cws - (uintptr_t)slab), stream))) return rc1;
   } else {
   ObsBwdArgs a;

@@ -16,6 +16,7 @@ struct ScanCsFwd {
   NoiseSrc eps_post;
   float min_std;
   float *featx, *post_mean, *post_std, *xsa, *e, *gates, *hq;
+  unsigned* status;  // nullable: the caller's sticky status word (REPO_SCAN_STATUS_* bits)
 };
 // packs the weights, clears the flags and launches the scan; eemb (the hoisted embed product) must be complete on `s`
 int scan_cs_fwd(const ScanCsFwd& a, void* ws, size_t ws_bytes, hipStream_t s);
@@ -32,7 +33,10 @@ struct ScanCsBwd {
   const float *dfeat, *dqm, *dqs, *dbx;            // upstream, each nullable: (T,B,D+S), (T,B,S) x2, (T,B,D)
   float *doutq, *dhq, *dgi, *dgh, *de;             // per-step deltas: (T,B,2S) (T,B,Hd) (T,B,3D) x2 (T,B,D)
   float *dprev_belief, *dprev_state;               // nullable
+  unsigned* status;                                // nullable, as in ScanCsFwd
 };
+// polls a spin-wait makes before giving up (1 << 22 unless repo_debug_scan_spin_limit changed it)
+int scan_cs_spin_limit();
 size_t scan_cs_bwd_ws_floats(int64_t B, int64_t A, int64_t D, int64_t Hd, int64_t S);
 int scan_cs_bwd(const ScanCsBwd& a, void* ws, size_t ws_bytes, hipStream_t s);
 

@@ -19,11 +19,17 @@
 // ONE wave stores the slice with sc1 (write-through) 16-byte stores, waits vmcnt(0) and stores the step's epoch into
 // the workgroup's flag (sc1); one lane per flag polls with sc1 loads; after a workgroup barrier all threads gather
 // with sc1 16-byte loads.  2.6 us per exchange on an idle chip, 7-10 us beside a streaming kernel
-// (profiles/r03_scan_exchange_probe.txt): this engine is for the SHARDS of a strong-scaling job (B <= 16 per GPU, the
-// chip nearly idle), where a step costs ~8 us instead of 17; inside the N = 1 update at B = 50 it loses.
-// A poll that does not see its peers within `spin_limit` rounds raises the error word and the whole group leaves the
-// time loop (no hang if a peer workgroup never becomes resident) after writing NaN into its outputs (the last belief
-// slot / the first d e row), so the update's losses and gradient norms show it.
+// (profiles/r03_scan_exchange_probe.txt).  The forward scan replaced the flag hop by DATA-TAGGED granules (below:
+// ~1.5 us per exchange).  With INDEPENDENT 16-row groups every exchange stays at the 16-row price, and the engine is
+// the default for every B <= 64 (ops.py): a step costs 11 / 13.5 us instead of 17-20 for a 7-row shard of a
+// strong-scaling job and, measured inside the N = 1 update at B = 50, 577 / 721 us per scan against 901 / 1722.
+// Failure mode: the exchanges are cross-workgroup spin-waits and a plain launch does not guarantee co-residency of a
+// group's 13 workgroups (DESIGN.md section 5 has the argument why they are resident in practice).  A poll that does
+// not see its peers within `spin_limit` rounds (debug knob: repo_debug_scan_spin_limit) therefore gives up instead of
+// hanging: it ORs REPO_SCAN_STATUS_{FWD,BWD}_TIMEOUT into the caller's sticky `status` word (an argument of
+// repo_rssm_observe_fwd / _bwd; the agents read it back inside their ONE per-update scalar copy and raise
+// RepoHipError), the whole group leaves the time loop, and NaN is written into its outputs (the last belief slot /
+// the first d e row) so that nothing plausible is left behind.
 //
 // Prior head: not here (it is off the recurrence: repo_rssm_prior_head evaluates it for all steps at once).
 // Everything the reverse scan needs is written exactly as rssm.hip's forward writes it.
@@ -48,6 +54,7 @@ struct CsFwdArgs {
   float* xbuf;      // [group][kind 2][rotation 4][KP*16]
   unsigned* flags;  // [group][NW] on 128-byte lines
   unsigned* err;
+  unsigned* status;  // caller's sticky status word (nullable): REPO_SCAN_STATUS_* bits are OR-ed in on an abort
   int spin_limit;
 };
 
@@ -57,14 +64,14 @@ __device__ __forceinline__ f32x4v ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned off)
 __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, const f32x4v& v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, kSC1);
 }
-// data-tagged all-gathers (no vmcnt(0) wait, no flag hop): forward 590 -> 539 us; the reverse scan's four-tile gather
-// polls 13 granules per thread and gains nothing (663 vs 655 us): it keeps the flags
-#ifndef REPO_CS_TAGGED
-#define REPO_CS_TAGGED 1
-#endif
-#ifndef REPO_CS_TAGGED_BWD
-#define REPO_CS_TAGGED_BWD 0
-#endif
+// The forward scan's all-gathers are data-tagged (no vmcnt(0) wait, no flag hop: 590 -> 539 us); the reverse scan's
+// four-tile gather would poll 13 granules per thread and gained nothing that way (663 vs 655 us): it keeps epoch flags.
+// a bounded poll ran out: the per-launch word in the workspace (peers of the group read nothing from it; kept for
+// debuggers) and the caller's sticky status word, which the host reads back with its per-update scalar copy
+__device__ __forceinline__ void raise_status(unsigned* err, unsigned* status, unsigned bit) {
+  __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (status) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ f32x4v kSentinel4() {
   const float n = __builtin_bit_cast(float, 0xffffffffu);
   return f32x4v{n, n, n, n};
@@ -194,7 +201,6 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
 
   // all-gather of one own slice (already in `tile`, k-groups c0/4 .. c0/4+3): kind 0 = belief, 1 = hq
   auto exchange = [&](float* tile, int kind, int t, int kp) __attribute__((always_inline)) -> bool {
-#if REPO_CS_TAGGED
     // data-tagged hand-off: four rotating buffers per kind, all cells start as the sentinel (a NaN no activation can be);
     // the producer stores its slice into buffer t % 4 and re-arms its slice of buffer (t + 2) % 4 (every consumer is
     // done with it: a workgroup publishes exchange t only after gathering t - 1, which needed every peer's publish of
@@ -225,9 +231,9 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
           okv[j] = !has_sentinel(g[j]);
           all = all && okv[j];
         }
-      if (!all && n > p.spin_limit) {
+      if (!all && n >= p.spin_limit) {
         s_abort = 1;
-        __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raise_status(p.err, p.status, REPO_SCAN_STATUS_FWD_TIMEOUT);
         break;
       }
     }
@@ -238,42 +244,6 @@ __global__ __launch_bounds__(256) void observe_cs_fwd_kernel(CsFwdArgs p) {
     }
     __syncthreads();
     return !s_abort;
-#else
-    const unsigned base = 4u * (unsigned)((kind * 4 + (t & 1)) * KP * 16);
-    const unsigned epoch = (unsigned)(2 * t + kind + 1);
-    if (wave == 0) {
-      const f32x4v v = *reinterpret_cast<const f32x4v*>(tile + ((c0 >> 2) * 16 + lane) * 4);
-      st_sc1(rx, base + 16u * (unsigned)((c0 >> 2) * 16 + lane), v);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(flags + 32 * w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane < NW) {
-        int n = 0;
-        while (__hip_atomic_load(flags + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++n > p.spin_limit) {
-            s_abort = 1;
-            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (s_abort) return false;
-    f32x4v g[(KP * 4 + 255) / 256];
-#pragma unroll
-    for (int j = 0; j < (KP * 4 + 255) / 256; ++j) {
-      const int i = tid + 256 * j;
-      g[j] = ld_sc1(rx, i < kp * 4 ? base + 16u * (unsigned)i : 0xfffffff0u);
-    }
-#pragma unroll
-    for (int j = 0; j < (KP * 4 + 255) / 256; ++j) {
-      const int i = tid + 256 * j;
-      if (i < kp * 4) reinterpret_cast<f32x4v*>(tile)[i] = g[j];
-    }
-    __syncthreads();
-    return true;
-#endif
   };
 
   // a group that gave up on its peers (error word raised) must not leave plausible numbers behind
@@ -460,8 +430,8 @@ int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   a.eemb = q.eemb; a.eps_post = q.eps_post;
   a.featx = q.featx; a.post_mean = q.post_mean; a.post_std = q.post_std; a.xsa = q.xsa; a.e = q.e; a.gates = q.gates;
   a.hq = q.hq; a.min_std = q.min_std;
-  a.xbuf = xbuf; a.flags = flags; a.err = err;
-  a.spin_limit = 1 << 22;
+  a.xbuf = xbuf; a.flags = flags; a.err = err; a.status = q.status;
+  a.spin_limit = scan_cs_spin_limit();
   constexpr int DP = 208, HP = 208, XP = 48;
   const size_t lds_b = (size_t)(XP * 16 + 2 * DP * 16 + HP * 16 + 2 * 4 * 256 + 16 * 64 + 16 * 32) * sizeof(float);
   he = hipFuncSetAttribute((const void*)observe_cs_fwd_kernel<3, 13, 13>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -494,6 +464,7 @@ struct CsBwdArgs {
   float* xbuf;      // [group][20 tiles of KP*16]: [rotation 4][g_r, g_z, g_n, g_hn], then [rotation 4] d e_pre
   unsigned* flags;
   unsigned* err;
+  unsigned* status;  // caller's sticky status word (nullable): REPO_SCAN_STATUS_* bits are OR-ed in on an abort
   int spin_limit;
 };
 
@@ -608,51 +579,6 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
   // kind 0: the four gate tiles (xbuf tiles [rot 4][4]); kind 1: d e_pre ([rot 4][1] behind them).  `seq` = step.
   auto exchange = [&](int kind, float* tiles, int seq) __attribute__((always_inline)) -> bool {
     const int nt = kind == 0 ? 4 : 1;
-#if REPO_CS_TAGGED_BWD
-    // data-tagged hand-off, see the forward kernel
-    const unsigned base = 4u * (unsigned)((kind == 0 ? (seq & 3) * 4 : 16 + (seq & 3)) * TS);
-    const unsigned rearm = 4u * (unsigned)((kind == 0 ? ((seq + 2) & 3) * 4 : 16 + ((seq + 2) & 3)) * TS);
-    if (wave == 0) {
-      const unsigned o = 16u * (unsigned)((c0 >> 2) * 16 + lane);
-      for (int x = 0; x < nt; ++x) {
-        st_sc1(rx, base + 4u * (unsigned)(x * TS) + o,
-               *reinterpret_cast<const f32x4v*>(tiles + x * TS + ((c0 >> 2) * 16 + lane) * 4));
-        st_sc1(rx, rearm + 4u * (unsigned)(x * TS) + o, kSentinel4());
-      }
-    }
-    const int nv = nt * TS / 4;
-    for (int i0 = 0; i0 < nv; i0 += 256 * 7) {
-      f32x4v g[7];
-      bool okv[7];
-      bool all = false;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) okv[j] = (i0 + tid + 256 * j) >= nv;
-      for (int n = 0; !all; ++n) {
-        all = true;
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-          if (!okv[j]) g[j] = ld_sc1(rx, base + 16u * (unsigned)(i0 + tid + 256 * j));
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-          if (!okv[j]) {
-            okv[j] = !has_sentinel(g[j]);
-            all = all && okv[j];
-          }
-        if (!all && n > p.spin_limit) {
-          s_abort = 1;
-          __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int i = i0 + tid + 256 * j;
-        if (i < nv) reinterpret_cast<f32x4v*>(tiles)[i] = g[j];
-      }
-    }
-    __syncthreads();
-    return !s_abort;
-#else
     const unsigned epoch = (unsigned)(2 * seq + kind + 1);
     const unsigned base = 4u * (unsigned)((kind == 0 ? (seq & 1) * 4 : 16 + (seq & 1)) * TS);
     if (wave == 0) {
@@ -668,7 +594,7 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
           __builtin_amdgcn_s_sleep(1);
           if (++n > p.spin_limit) {
             s_abort = 1;
-            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_status(p.err, p.status, REPO_SCAN_STATUS_BWD_TIMEOUT);
             break;
           }
         }
@@ -692,7 +618,6 @@ __global__ __launch_bounds__(256) void observe_cs_bwd_kernel(CsBwdArgs p) {
     }
     __syncthreads();
     return true;
-#endif
   };
 
   // a group that gave up on its peers (error word raised) must not leave plausible numbers behind
@@ -896,8 +821,8 @@ int scan_cs_bwd(const ScanCsBwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   a.dfeat = q.dfeat; a.dqm = q.dqm; a.dqs = q.dqs; a.dbx = q.dbx;
   a.doutq = q.doutq; a.dhq = q.dhq; a.dgi = q.dgi; a.dgh = q.dgh; a.de = q.de;
   a.dprev_belief = q.dprev_belief; a.dprev_state = q.dprev_state; a.min_std = q.min_std;
-  a.xbuf = xbuf; a.flags = flags; a.err = err;
-  a.spin_limit = 1 << 22;
+  a.xbuf = xbuf; a.flags = flags; a.err = err; a.status = q.status;
+  a.spin_limit = scan_cs_spin_limit();
   constexpr int DP = 208, TS = 208 * 16;
   const size_t lds_b = (size_t)(4 * TS + 64 * 16 + 2 * 4 * 256 + 16 * 32) * sizeof(float);
   he = hipFuncSetAttribute((const void*)observe_cs_bwd_kernel<13, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);

@@ -279,6 +279,39 @@ def reduce_ws(device):
 
 
 # ----------------------------------------------------------------------------- RSSM observe
+_scan_status = {}
+
+
+def scan_status(device):
+    """The device's sticky status word for ASYNCHRONOUS scan errors (include/repo_hip.h, repo_rssm_observe_fwd: the
+    column-split engine ORs REPO_SCAN_STATUS_* bits into it when a spin-wait on a peer workgroup times out).  One int32
+    per device, zeroed once; every scan launch of this process passes it.  The agents append it to their per-update
+    scalar copy (`Dreamer._log_update`) -- no extra transfer -- and raise; anyone else calls `check_scan_status`."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _scan_status.get(idx)
+    if w is None:
+        w = _scan_status[idx] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+SCAN_STATUS_TEXT = {1: "forward", 2: "reverse", 3: "forward and reverse"}
+
+
+def raise_scan_status(word):
+    """word: the status value read on the host (0 = fine)."""
+    if word:
+        from ._lib import RepoHipError
+        raise RepoHipError(
+            f"column-split observe scan ({SCAN_STATUS_TEXT.get(word & 3, word)}): a spin-wait on a peer workgroup timed "
+            "out (the group's workgroups were not co-resident); the outputs of that update are NaN-poisoned.  "
+            "REPO_SCAN_CS=0 selects the row-scan engine, which has no cross-workgroup waits.")
+
+
+def check_scan_status(device):
+    """Synchronising read of the status word (tests, callers outside the agents' update loop)."""
+    raise_scan_status(int(scan_status(device).item()))
+
+
 class ObserveSaved:
     __slots__ = ("T", "B", "A", "D", "Hd", "S", "E", "featx", "prior_state", "prior_mean", "prior_std", "post_mean",
                  "post_std", "xsa", "e", "gates", "hp", "hq", "nonterms", "embeds", "eps_prior", "eps_post", "noise",
@@ -328,7 +361,7 @@ def rssm_observe_fwd(params, prev_belief, prev_state, actions, nonterms, embeds,
             _ptr(sv.nonterms), _ptr(sv.embeds), _ptr(sv.eps_prior), _ptr(sv.eps_post), sv.noise[0], sv.noise[1],
             float(min_std), _ptr(sv.featx), _ptr(sv.prior_state), _ptr(sv.prior_mean), _ptr(sv.prior_std), _ptr(sv.post_mean),
             _ptr(sv.post_std), _ptr(sv.xsa), _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(eemb),
-            3 if use_cs else 2 if hoist else int(prior_only), _ptr(ws), ws.numel(), _stream(),
+            3 if use_cs else 2 if hoist else int(prior_only), _ptr(scan_status(dev)), _ptr(ws), ws.numel(), _stream(),
         ),
         "repo_rssm_observe_fwd",
     )
@@ -373,7 +406,8 @@ def rssm_observe_bwd(params, sv, dparams, dfeat=None, dprior_state=None, dpm=Non
             _ptr(sv.eps_post), sv.noise[0], sv.noise[1], float(min_std), _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.post_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(sv.hq), _ptr(dfeat), _ptr(dprior_state), _ptr(dpm),
             _ptr(dps), _ptr(dqm), _ptr(dqs), ga, _ptr(dembeds), _ptr(dprev_belief), _ptr(dprev_state),
-            int(bool(accumulate)) | (2 if getattr(sv, "cs", False) else 0), _ptr(ws), ws.numel(), _stream(),
+            int(bool(accumulate)) | (2 if getattr(sv, "cs", False) else 0), _ptr(scan_status(dev)), _ptr(ws), ws.numel(),
+            _stream(),
         ),
         "repo_rssm_observe_bwd",
     )

@@ -581,3 +581,58 @@ def test_scan_engine_selection(monkeypatch):
             assert float((a - b).abs().max() / (a.abs().max() + 1e-12)) < 2e-5, (B, name)
     prior = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0), prior_only=True)
     assert not prior.cs
+
+
+def test_scan_timeout_reaches_the_host():
+    """The column-split scans wait on peer workgroups with bounded spins; a timeout is an ASYNCHRONOUS error and must
+    reach the host as an exception, not as NaN losses (include/repo_hip.h: the `status` word of repo_rssm_observe_fwd /
+    _bwd).  A spin limit of 0 (debug entry) makes the first unanswered poll give up: the forward scan raises bit 1,
+    the reverse scan bit 2; ops.check_scan_status and the agent's per-update scalar read-back both raise RepoHipError;
+    with the limit restored and the word cleared the same calls are clean again."""
+    from repo_amd import ops
+    from repo_amd._lib import RepoHipError, lib
+    from tests.test_update_gpu import dev_batch, make_agent
+
+    A, D, S, E, T, B = 6, 200, 30, 1024, 6, 16
+    p = cu(tparams("transition_model", A, requires_grad=False))
+    rs = np.random.RandomState(5)
+    dev = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()  # noqa: E731
+    b0, s0 = dev(rs.standard_normal((B, D)) * 0.3), dev(rs.standard_normal((B, S)))
+    act, non = dev(rs.uniform(-1, 1, (T, B, A))), torch.ones(T, B).cuda()
+    emb = dev(np.maximum(rs.standard_normal((T, B, E)), 0))
+    word = ops.scan_status(b0.device)
+    word.zero_()
+    grads = [torch.zeros_like(t) for t in p]
+    dfeat = dev(rs.standard_normal((T, B, D + S)))
+    try:
+        sv = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0))
+        assert sv.cs
+        ops.check_scan_status(b0.device)                       # clean run: nothing raised
+        assert lib().repo_debug_scan_spin_limit(0) == 1 << 22
+        ops.rssm_observe_bwd(p, sv, grads, dfeat=dfeat)
+        torch.cuda.synchronize()
+        assert int(word.item()) == 2, int(word.item())         # reverse scan only
+        with pytest.raises(RepoHipError, match="reverse"):
+            ops.check_scan_status(b0.device)
+        bad = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0))
+        torch.cuda.synchronize()
+        assert int(word.item()) == 3
+        assert not bool(torch.isfinite(bad.featx).all())       # and nothing plausible is left behind
+        # the agent: the word travels inside the update's one scalar copy
+        word.zero_()
+        agent, _ = make_agent("repo", 6, 3, 4, 6)
+        batch, _ = dev_batch(6, 3, 6, 11)
+        agent.update(batch)
+        with pytest.raises(RepoHipError, match="column-split observe scan"):
+            agent.last_scalars
+    finally:
+        lib().repo_debug_scan_spin_limit(-1)
+        torch.cuda.synchronize()
+        word.zero_()
+    good = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0))
+    ops.rssm_observe_bwd(p, good, grads, dfeat=dfeat)
+    ops.check_scan_status(b0.device)
+    assert torch.equal(good.featx, sv.featx)
+    agent, _ = make_agent("repo", 6, 3, 4, 6)
+    agent.update(dev_batch(6, 3, 6, 11)[0])
+    assert all(math.isfinite(v) for v in agent.last_scalars.values())
