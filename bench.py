@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: RePo world-model + imagination updates per second.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|c4x128|tia]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5|c4x128|tia|mt]
 
 Workload (default `--config c2` = BASELINE.json configs[1]): algo=repo, B=50
 sequences per GPU, L=50, H=15, A=6, 64x64x3 uint8 frames, parameters at torch default init under
@@ -60,6 +60,11 @@ CONFIGS = {
     # f4 widening: the reference's TIA (algorithms/repo/tia.py) on configs[1]'s shapes: two filters, three decoders
     "tia": ("tia", 50, 6, "algo=tia (tia.py: distractor filter, masked pair of decoders, distractor-only decoder) on "
             "dmc_distracted-walker-walk shapes", 64),
+    # f4 widening: the reference's MultitaskRePo (repo_mt.py; 3 tasks like every multitask environment of the reference:
+    # environments/__init__.py:121-147) on configs[1]'s shapes.  FLOPs: the c2 figure (FiLM is elementwise, the task
+    # one-hot adds 3 K columns to five dense layers)
+    "mt": ("repo_multitask", 50, 6, "algo=repo_multitask (repo_mt.py: FiLM-conditioned conv stacks, task-conditioned RSSM / "
+           "heads / rollout, per-task beta; 3 tasks) on dmc_distracted-walker-walk shapes", 64),
     "c4x128": ("repo", 32, 7, "maniskill-PushCubeMatterport shapes at 128x128 frames through the BUILD-DEFINED 128x128 "
                "conv stack (no reference model exists for it), A=7", 128),
 }
@@ -79,6 +84,7 @@ def flop_per_update(B, image=64, algo="repo"):
     """Algorithmic FLOPs of one update of B sequences (L=50, H=15)."""
     return (FLOP_PER_UPDATE_B50 * B / 50.0 + (EXTRA_FLOP_PER_FRAME_128 * (L - 1) * B if image == 128 else 0.0)
             + (EXTRA_FLOP_PER_FRAME_TIA * (L - 1) * B if algo == "tia" else 0.0))
+N_TASKS = 3                    # --config mt
 RING_FRAMES = 6000             # synthetic replay ring per rank (72 MB of frames; 120 windows of 50)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")
 
@@ -89,9 +95,11 @@ class Space:
 
 
 class Env:
-    def __init__(self, A=6, image=64):
+    def __init__(self, A=6, image=64, num_tasks=None):
         self.observation_space = Space((3, image, image))
         self.action_space = Space((A,))
+        if num_tasks:
+            self.num_tasks = num_tasks
 
 
 class NullLogger:
@@ -114,25 +122,32 @@ def config(algo="repo", B=50):
         gamma=0.99, gae_lambda=0.95, action_noise=0.0, action_ent_coef=3e-4, latent_ent_coef=0.0, free_nats=3,
         model_lr=3e-4, actor_lr=8e-5, value_lr=8e-5, grad_clip_norm=100.0, target_kl=3.0, beta_lr=1e-4,
         init_beta=1e-5, prior_train_steps=5, disag_model=False, inv_dynamics=False, disag_coef=0.0,
-        tia_obs_coef=1.0, tia_adv_coef=1.0, tia_reward_train_steps=1,
+        tia_obs_coef=1.0, tia_adv_coef=1.0, tia_reward_train_steps=1, share_repr=False,
         replay_size=8, train_steps=1, prefill=0, load_checkpoint=False, load_offline=False, save_buffer=False,
     )
 
 
-def synthetic_batch(seed=1234, B=50, A=6, image=64):
+def synthetic_batch(seed=1234, B=50, A=6, image=64, num_tasks=0):
     rs = np.random.RandomState(seed)
     obs = rs.randint(0, 256, (L, B, 3, image, image)).astype(np.uint8)
     actions = rs.uniform(-1, 1, (L, B, A)).astype(np.float32)
     rewards = rs.uniform(0, 1, (L, B, 1)).astype(np.float32)
     dones = (rs.uniform(size=(L, B, 1)) < 1 / 500).astype(np.float32)
+    if num_tasks:   # multitask batches lead with the task one-hots (one task per sequence)
+        tasks = np.eye(num_tasks, dtype=np.float32)[np.broadcast_to(rs.randint(0, num_tasks, B)[None], (L, B))]
+        return np.ascontiguousarray(tasks), obs, actions, rewards, dones
     return obs, actions, rewards, dones
 
 
-def synthetic_ring(buffer_cls, seed, A, device, image=64):
+def synthetic_ring(buffer_cls, seed, A, device, image=64, num_tasks=0):
     """A full replay ring of RING_FRAMES synthetic transitions (same distributions as synthetic_batch:
     uniform u8 frames, uniform actions / rewards, episode ends with probability 1/500), mirrored in HBM."""
     rs = np.random.RandomState(seed)
-    ring = buffer_cls(RING_FRAMES, (3, image, image), (A,), obs_type=np.uint8)
+    if num_tasks:
+        ring = buffer_cls(RING_FRAMES, num_tasks, (3, image, image), (A,), obs_type=np.uint8)
+        ring.tasks[:] = np.eye(num_tasks, dtype=np.float32)[np.repeat(rs.randint(0, num_tasks, RING_FRAMES // 500 + 1), 500)[:RING_FRAMES]]
+    else:
+        ring = buffer_cls(RING_FRAMES, (3, image, image), (A,), obs_type=np.uint8)
     ring.observations[:] = rs.randint(0, 256, size=ring.observations.shape, dtype=np.uint8)
     ring.actions[:] = rs.uniform(-1, 1, ring.actions.shape)
     ring.rewards[:] = rs.uniform(0, 1, ring.rewards.shape)
@@ -302,12 +317,16 @@ def _cpu_baseline_worker(q, threads, warm, timed, B, A, algo, image=64):
     from oracle import fixtures as fx
     from oracle.repo_oracle import OracleAgent
 
-    batch = synthetic_batch(1234, B, A, image)
-    cfg = fx.default_config(algo=algo, batch_size=B, chunk_size=L, horizon=H)
+    batch = synthetic_batch(1234, B, A, image, N_TASKS if algo.endswith("multitask") else 0)
+    cfg = fx.default_config(algo=algo, batch_size=B, chunk_size=L, horizon=H, share_repr=False)
     if algo == "tia":
         from oracle.repo_oracle import OracleTIA
 
         agent = OracleTIA(cfg, A, seed=7)
+    elif algo.endswith("multitask"):
+        from oracle.repo_oracle import OracleMultitask
+
+        agent = OracleMultitask(cfg, A, N_TASKS, seed=7)
     else:
         agent = OracleAgent(cfg, A, seed=7, image=image)
     noise = fx.make_noise(L, B, H, A, seed=1, tia=algo == "tia")
@@ -388,7 +407,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--algo", default=None, help="override the config's algorithm (repo | dreamer | tia)")
+    ap.add_argument("--algo", default=None, help="override the config's algorithm (repo | dreamer | tia | repo_multitask | dreamer_multitask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--join", action="store_true", help="join the two update lanes after every update (no overlap)")
     ap.add_argument("--strong", action="store_true",
@@ -411,8 +430,8 @@ def main():
         return rendezvous_only(world, rank)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
 
-    from repo_amd.algorithms.repo import TIA, Dreamer, RePo
-    from repo_amd.common.buffers import SequenceReplayBuffer
+    from repo_amd.algorithms.repo import TIA, Dreamer, MultitaskDreamer, MultitaskRePo, RePo
+    from repo_amd.common.buffers import MultitaskSequenceReplayBuffer, SequenceReplayBuffer
     from repo_amd.common.utils import set_gpu_mode
 
     algo, B, A, label, image = CONFIGS[args.config]
@@ -437,17 +456,19 @@ def main():
 
     torch.manual_seed(0)
     cfg = config(algo, B)
-    agent = {"repo": RePo, "dreamer": Dreamer, "tia": TIA}[algo](cfg, Env(A, image), Env(A, image), NullLogger())
+    ntasks = N_TASKS if algo.endswith("multitask") else 0
+    agent = {"repo": RePo, "dreamer": Dreamer, "tia": TIA, "repo_multitask": MultitaskRePo,
+             "dreamer_multitask": MultitaskDreamer}[algo](cfg, Env(A, image, ntasks), Env(A, image, ntasks), NullLogger())
     if dp is not None:
         dp.attach(agent)
     if args.strong:
         from repo_amd.parallel import shard_rows
 
         lo, hi = shard_rows(B, world, rank)
-        host = tuple(np.ascontiguousarray(x[:, lo:hi]) for x in synthetic_batch(1234, B, A, image))
+        host = tuple(np.ascontiguousarray(x[:, lo:hi]) for x in synthetic_batch(1234, B, A, image, ntasks))
         cfg.batch_size = hi - lo
     else:
-        host = synthetic_batch(1234 + rank, B, A, image)  # each rank holds its own B-sequence shard of the global batch
+        host = synthetic_batch(1234 + rank, B, A, image, ntasks)  # each rank holds its own B-sequence shard of the global batch
     resident = tuple(torch.from_numpy(x).to(dev) for x in host)
     Bl = cfg.batch_size
 
@@ -459,7 +480,8 @@ def main():
         agent.synchronize()
 
     np.random.seed(4321 + rank)  # the sampler's RNG (np.random.choice, like the reference)
-    agent.buffer = synthetic_ring(SequenceReplayBuffer, 1234 + rank, A, dev, image)
+    agent.buffer = synthetic_ring(MultitaskSequenceReplayBuffer if ntasks else SequenceReplayBuffer, 1234 + rank, A, dev,
+                                  image, ntasks)
 
     def run_from_ring(k):
         # train_agent()'s loop body K times: fresh indices on the host, device gather, pipelined update

@@ -321,12 +321,19 @@ int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, const float
  *          prior_mean/std (Hm,N,S).
  * Saved  : a_hidden (n_actor_layers-1, a_layer_rows, Hd) with a_layer_rows >= Hm*N (row stride of a
  *          layer, so the caller can keep one spare step slot behind the rollout's rows), a_raw
- *          (Hm*N,2A), a_mean/a_std (Hm*N,A), xsa (Hm*N,S+A), e (Hm*N,D), gates (Hm*N,4D), hp (Hm*N,Hd). */
+ *          (Hm*N,2A), a_mean/a_std (Hm*N,A), xsa (Hm*N,S+A+C), e (Hm*N,D), gates (Hm*N,4D), hp (Hm*N,Hd).
+ * cond (N,C), C > 0: the CONDITIONED rollout of the multitask agents (ConditionalTransitionModel.imagine,
+ *          models/rssm.py:221-249; ConditionalActorModel, models/actor_critic.py:104-139): the policy sees
+ *          [belief | state | cond], the belief update the pseudo-action [action | cond]; then actor_params[0] is
+ *          (Hd, D+S+C), rssm_params[0] is (D, S+A+C), and the saved xsa rows are [state | action | cond].  The
+ *          condition rides in the K padding of the persistent engine's tiles: D+S+C <= 240 and S+A+C <= 48 at the
+ *          reference's widths, else REPO_E_SHAPE.  C = 0 (cond ignored): the reference's unconditioned rollout. */
 size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                              int64_t S);
 int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                           int n_actor_layers, const float* const* rssm_params,
                           const float* const* actor_params, const float* belief0, const float* state0,
+                          const float* cond, int64_t C,
                           const float* eps_act, const float* eps_prior, uint64_t noise_seed,
                           uint64_t noise_offset, float min_std, float a_min_std,
                           float a_init_std, float a_mean_scale, float* featx, float* prior_mean,
@@ -339,7 +346,7 @@ int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t H
  * finishes with repo_mlp_bwd over all Hm*N rows), and optionally dfeat0 (N,D+S). */
 size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                              int64_t S);
-int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
+int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t C,
                           const float* const* rssm_params, const float* eps_act,
                           const float* eps_prior, uint64_t noise_seed, uint64_t noise_offset,
                           float min_std, float a_min_std, float a_mean_scale,
@@ -408,6 +415,41 @@ int repo_normal_entropy(int64_t n, const float* std, float gscale, float* dstd, 
 int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, const float* values, float gamma,
                        float lambda_, float gret, float* returns, float* drewards, float* dvalues,
                        float* ret_sum, void* ws, size_t ws_bytes, hipStream_t stream);
+
+/* ------------------------------------------------------------------ multitask (task-conditioned) agents
+ * MultitaskDreamer / MultitaskRePo (algorithms/repo/dreamer_mt.py, repo_mt.py) condition every module on the task
+ * one-hot: dense layers by concatenation -- K columns of the caller's rows, no kernel of their own (heads:
+ * repo_mlp_fwd with in_dim = D+S+C; observe scan: pseudo-actions [action | task] = repo_rssm_observe_fwd with
+ * A + C "actions"; rollout: repo_rssm_imagine_fwd's `cond`) -- and the conv stacks by FiLM:
+ *   h[n][c][p] = relu((1 + gamma[n][c]) * y[n][c][p] + beta[n][c])
+ * (ConditionalVisualEncoder.mod, models/encoder.py:75-88; ConditionalVisualObservationModel.mod, models/decoder.py:
+ * 108-123), y = the layer's conv output incl. bias (repo_conv_down / repo_conv_up / repo_gemm with REPO_EPI_NONE),
+ * gamma = film[n*ldfilm + gamma_off + c], beta = film[n*ldfilm + beta_off + c] with film (nimg, ldfilm) = the FiLM
+ * linear layer's output (film(condition).chunk(2).split(...) of the reference, by offsets).  P = pixels per plane.
+ * Backward: dh = the gradient at the ReLU's input (the ReLU mask already applied by the producer: a data-gradient
+ * kernel with REPO_EPI_MUL_DRELU on h, or repo_relu_mask);  dy = dh * (1 + gamma);
+ * dfilm[n][gamma_off + c] = sum_p dh * y,  dfilm[n][beta_off + c] = sum_p dh  (written, fixed summation order). */
+int repo_film_fwd(int64_t nimg, int64_t C, int64_t P, const float* y, const float* film, int64_t ldfilm,
+                  int64_t gamma_off, int64_t beta_off, float* out, hipStream_t stream);
+int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* y, const float* film,
+                  int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm, hipStream_t stream);
+/* MultitaskRePo's KL balance (repo_mt.py:75-93): the Lagrange multiplier is PER ROW, beta_row = exp(lb_row) with
+ * lb_row = tasks[row] . log_beta (tasks (rows, C) one-hot, log_beta (C), C <= 13).  Gradients (nullable) of
+ *   scale * sum_rows beta_row * (alpha*KL(sg q||p) + (1-alpha)*KL(q||sg p)),
+ * sums[3 + C] = { sum KL_row, sum beta_row*viol_row, sum lb_row*viol_row, sum tasks[row][i]*viol_row (i < C) } with
+ * viol_row = KL_row - target_kl: this rank's partial sums (a data-parallel job all-reduces them) for
+ * repo_dual_step_tasks. */
+size_t repo_kl_balance_tasks_workspace_bytes(void);
+int repo_kl_balance_tasks(int64_t rows, int64_t S, int64_t C, const float* pm, const float* ps, const float* qm,
+                          const float* qs, float alpha, const float* log_beta, const float* tasks, float target_kl,
+                          float scale, float* dpm, float* dps, float* dqm, float* dqs, float* sums, void* ws,
+                          size_t ws_bytes, hipStream_t stream);
+/* Dual ascent on the per-task log_beta vector (repo_mt.py:95-112): beta_loss = -mean_rows(lb_row * viol_row), so
+ * grad[i] = -sums[3+i] / rows; ONE Adam step on the C-vector if apply (`step` = 1-based count, state on device).
+ * rows = the GLOBAL row count.  scalars_out[3 + C] = { kl_div, kl_loss, beta_loss, exp(log_beta[i]) after the step }. */
+int repo_dual_step_tasks(int64_t C, float* log_beta, float* exp_avg, float* exp_avg_sq, const float* sums,
+                         int64_t rows, float lr, float beta1, float beta2, float eps, int64_t step, int apply,
+                         float* scalars_out, hipStream_t stream);
 
 /* ------------------------------------------------------------------ optimiser
  * *sqnorm = sum g^2 over a flat, 16-byte aligned buffer (global norm of

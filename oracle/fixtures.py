@@ -90,14 +90,19 @@ def default_config(**over):
     return SimpleNamespace(**c)
 
 
-def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, image=64, tia=False):
+def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, image=64, tia=False, cond=0):
     """Ordered {module: OrderedDict(name -> shape)} in state_dict order.
     image=128: the BUILD-DEFINED 128 x 128 stack (no reference model exists at that size: the reference's encoder
     hard-codes the 64 x 64 flatten, encoder.py:39): the same four encoder convs (-> 256x6x6) + fc 9216 -> embed; the
-    decoder's conv4 becomes 32 -> 16 (k6, 30 -> 64) and a conv5 16 -> 3 (k2, 64 -> 128) follows."""
-    A = action_size
-    feat = belief + state
+    decoder's conv4 becomes 32 -> 16 (k6, 30 -> 64) and a conv5 16 -> 3 (k2, 64 -> 128) follows.
+    cond > 0: the task-conditioned modules of the multitask agents (models/encoder.py:68-88, models/decoder.py:96-123,
+    198-213, models/rssm.py:187-210, models/actor_critic.py:28-55,104-139): FiLM layers behind the conv stacks, `cond`
+    more input columns in fc_embed_state_action and every head's fc1 (the pixel decoder's fc1 stays belief + state wide:
+    ConditionalVisualObservationModel concatenates nothing, decoder.py:116)."""
+    A = action_size + cond      # pseudo-actions [action | condition]
+    feat = belief + state + cond
     assert image in (64, 128), image
+    assert not cond or (image == 64 and not tia)
     enc = OrderedDict()
     for i, (co, ci) in enumerate([(32, 3), (64, 32), (128, 64), (256, 128)], 1):
         enc[f"conv{i}.weight"] = (co, ci, 4, 4)
@@ -105,6 +110,9 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, imag
     if image == 128:
         enc["fc.weight"] = (embed, 256 * 6 * 6)
         enc["fc.bias"] = (embed,)
+    if cond:
+        enc["film.weight"] = (2 * (32 + 64 + 128 + 256), cond)
+        enc["film.bias"] = (2 * (32 + 64 + 128 + 256),)
     rssm = OrderedDict(
         [
             ("fc_embed_state_action.weight", (belief, state + A)),
@@ -125,7 +133,7 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, imag
     )
     dec = OrderedDict(
         [
-            ("fc1.weight", (embed, feat)),
+            ("fc1.weight", (embed, belief + state)),  # the PIXEL decoder's fc1 never sees the condition (FiLM only)
             ("fc1.bias", (embed,)),
             ("conv1.weight", (embed, 128, 5, 5)),
             ("conv1.bias", (128,)),
@@ -140,6 +148,9 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, imag
     if image == 128:
         dec["conv4.weight"], dec["conv4.bias"] = (32, 16, 6, 6), (16,)
         dec["conv5.weight"], dec["conv5.bias"] = (16, 3, 2, 2), (3,)
+    if cond:
+        dec["film.weight"] = (2 * (128 + 64 + 32), cond)
+        dec["film.bias"] = (2 * (128 + 64 + 32),)
 
     def mlp(n_hidden_layers, out):
         d = OrderedDict()
@@ -158,7 +169,7 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, imag
             ("transition_model", rssm),
             ("obs_model", dec),
             ("reward_model", mlp(3, 1)),
-            ("actor_model", mlp(4, 2 * A)),
+            ("actor_model", mlp(4, 2 * action_size)),
             ("value_model", mlp(3, 1)),
         ]
     )
@@ -176,7 +187,7 @@ def param_shapes(action_size, belief=200, state=30, hidden=200, embed=1024, imag
     return out
 
 
-def make_params(action_size, seed=7, image=64, tia=False):
+def make_params(action_size, seed=7, image=64, tia=False, cond=0):
     """{module: OrderedDict(name -> float32 ndarray)}; uniform(-k, k), k = fan_in**-0.5.
 
     One RandomState drawn sequentially in (module, state_dict) order; a bias uses
@@ -184,7 +195,7 @@ def make_params(action_size, seed=7, image=64, tia=False):
     """
     rs = np.random.RandomState(seed)
     out = OrderedDict()
-    for mod, shapes in param_shapes(action_size, image=image, tia=tia).items():
+    for mod, shapes in param_shapes(action_size, image=image, tia=tia, cond=cond).items():
         d = OrderedDict()
         k = 1.0
         for name, shp in shapes.items():
@@ -207,6 +218,19 @@ def make_batch(L, B, action_size, seed=11, planted_dones=((3, 1), (5, 2)), p_don
         if t < L and b < B:
             dones[t, b, 0] = 1.0
     return obs, actions, rewards, dones
+
+
+def make_tasks(L, B, num_tasks, seed=11):
+    """Task one-hots (L, B, num_tasks) float32 as MultitaskSequenceReplayBuffer.sample returns them first
+    (/root/reference/common/buffers.py:222-225).  A task is constant within an episode, but a sampled window may
+    straddle an episode boundary: every other sequence switches task part-way."""
+    rs = np.random.RandomState(seed + 7919)
+    first = rs.randint(0, num_tasks, size=B)
+    second = (first + 1 + rs.randint(0, max(num_tasks - 1, 1), size=B)) % num_tasks
+    switch = rs.randint(1, max(L, 2), size=B)
+    idx = np.where((np.arange(L)[:, None] >= switch[None, :]) & (np.arange(B)[None, :] % 2 == 1), second[None, :],
+                   first[None, :])
+    return np.eye(num_tasks, dtype=np.float32)[idx]
 
 
 def preprocess_u8(obs_u8):

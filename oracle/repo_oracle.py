@@ -577,3 +577,180 @@ class OracleFinetuned(OracleAgent):
         t = {k: torch.as_tensor(v) for k, v in noise.items()}
         return self.train_encoder(obs, torch.as_tensor(actions), torch.as_tensor(rewards), 1 - torch.as_tensor(dones),
                                   t["obs_prior"], t["obs_post"])
+
+
+# --------------------------------------------------------------------------- multitask (task-conditioned) agents
+# MultitaskDreamer / MultitaskRePo, /root/reference/algorithms/repo/dreamer_mt.py:28-301, repo_mt.py:13-135, with the
+# conditioned modules of models/encoder.py:68-88, models/decoder.py:96-123,198-213, models/rssm.py:187-249,
+# models/actor_critic.py:28-55,104-139.  share_repr=False (the default of experiments/train_repo.py:70).
+# Parity status: PINNED on the reference's own classes (tests/golden/gen_golden.py: run_mt_case ->
+# mt_dreamer_tiny.npz, mt_repo_tiny.npz; tests/test_oracle_golden.py).
+def _film(p, cond, channels):
+    g, b = F.linear(cond, p["film.weight"], p["film.bias"]).chunk(2, dim=1)
+    return g.split(list(channels), dim=1), b.split(list(channels), dim=1)
+
+
+def _mod(x, gamma, beta):
+    return (1 + gamma[..., None, None]) * x + beta[..., None, None]
+
+
+def cond_encoder_fwd(p, obs, cond):
+    """ConditionalVisualEncoder.forward, encoder.py:78-88."""
+    gs, bs = _film(p, cond, (32, 64, 128, 256))
+    h = obs
+    for i in range(4):
+        h = F.relu(_mod(F.conv2d(h, p[f"conv{i + 1}.weight"], p[f"conv{i + 1}.bias"], stride=2), gs[i], bs[i]))
+    return h.reshape(h.shape[0], -1)
+
+
+def cond_decoder_fwd(p, belief, state, cond):
+    """ConditionalVisualObservationModel.forward, decoder.py:111-123: fc1 on cat([belief, state]) -- the pixel decoder
+    concatenates NOTHING, the condition enters through FiLM on conv1..conv3 only (conv4 is not modulated)."""
+    gs, bs = _film(p, cond, (128, 64, 32))
+    h = F.linear(torch.cat([belief, state], 1), p["fc1.weight"], p["fc1.bias"])
+    h = h.view(-1, p["fc1.weight"].shape[0], 1, 1)
+    for i in range(3):
+        h = F.relu(_mod(F.conv_transpose2d(h, p[f"conv{i + 1}.weight"], p[f"conv{i + 1}.bias"], stride=2), gs[i], bs[i]))
+    return F.conv_transpose2d(h, p["conv4.weight"], p["conv4.bias"], stride=2)
+
+
+def cond_imagine(rssm, actor, belief0, state0, cond, horizon, eps_act, eps_prior):
+    """ConditionalTransitionModel.imagine, rssm.py:221-249: the policy sees [belief | state | cond] (detached), the
+    belief update the pseudo-action [action | cond]."""
+    beliefs, states, means, stds = [], [], [], []
+    belief, state = belief0, state0
+    for t in range(horizon - 1):
+        a_mean, a_std = actor_fwd(actor, belief.detach(), torch.cat([state.detach(), cond], 1))
+        action = torch.tanh(a_mean + a_std * eps_act[t])
+        belief = compute_belief(rssm, belief, state, torch.cat([action, cond], 1))
+        state, pm, ps = gaussian_head(rssm, "fc_embed_belief_prior", "fc_state_prior", belief, eps_prior[t])
+        beliefs.append(belief)
+        states.append(state)
+        means.append(pm)
+        stds.append(ps)
+    return [torch.stack(x, 0) for x in (beliefs, states, means, stds)]
+
+
+class OracleMultitask(OracleAgent):
+    """cfg.algo: "dreamer_multitask" or "repo_multitask"; num_tasks = C.  Batches carry tasks (L, B, C) first."""
+
+    def __init__(self, cfg, action_size, num_tasks, params=None, seed=7):
+        np_params = params if params is not None else fx.make_params(action_size, seed, cond=num_tasks)
+        super().__init__(cfg, action_size, params=np_params)
+        self.C = num_tasks
+        self.is_repo = cfg.algo == "repo_multitask"
+        if self.is_repo:   # one dual variable per task (repo_mt.py:24-32)
+            self.log_beta = torch.full((num_tasks,), float(np.log(cfg.init_beta)), dtype=torch.float32, requires_grad=True)
+            self.beta_opt = Adam([self.log_beta], cfg.beta_lr)
+
+    def train_dynamics(self, tasks, obs, actions, rewards, nonterms, eps_prior, eps_post, apply=True):
+        c, p = self.c, self.p
+        L, B = obs.shape[:2]
+        T = L - 1
+        embeds = cond_encoder_fwd(p["encoder"], obs.reshape(L * B, *obs.shape[2:]), tasks.reshape(L * B, -1)).reshape(L, B, -1)
+        b0 = torch.zeros(B, c.belief_size)
+        s0 = torch.zeros(B, c.state_size)
+        pseudo = torch.cat((actions[:-1], tasks[:-1]), dim=2)
+        beliefs, prior_s, pm, ps, post_s, qm, qs = observe(
+            p["transition_model"], b0, s0, pseudo, embeds[1:], nonterms[:-1], eps_prior, eps_post)
+        tk = tasks[1:].reshape(T * B, -1)   # "Match task timestep" (dreamer_mt.py:186-187)
+        fb, fs = beliefs.reshape(T * B, -1), post_s.reshape(T * B, -1)
+        if self.is_repo:
+            recon = cond_decoder_fwd(p["obs_model"], fb.detach(), fs.detach(), tk)
+        else:
+            recon = cond_decoder_fwd(p["obs_model"], fb, fs, tk)
+        recon = recon.reshape(T, B, *obs.shape[2:])
+        obs_loss = (0.5 * (recon - obs[1:]) ** 2 + 0.5 * LOG_2PI).sum((2, 3, 4)).mean((0, 1))
+        r_pred = scalar_head(p["reward_model"], fb, torch.cat([fs, tk], 1)).reshape(T, B)
+        mask = nonterms[:-1].squeeze(-1)
+        reward_loss = ((0.5 * (r_pred - rewards[:-1].squeeze(-1)) ** 2 + 0.5 * LOG_2PI) * mask).mean((0, 1))
+        out = {}
+        if self.is_repo:
+            kl_prior = normal_kl(qm.detach(), qs.detach(), pm, ps).sum(2)
+            kl_post = normal_kl(qm, qs, pm.detach(), ps.detach()).sum(2)
+            alpha = c.prior_train_steps / (1 + c.prior_train_steps)
+            kl_div = alpha * kl_prior + (1 - alpha) * kl_post          # (T, B): per row, repo_mt.py:86-88
+            kl_viol = kl_div - c.target_kl
+            log_beta = tasks[1:] @ self.log_beta                       # (T, B)
+            kl_loss = (log_beta.exp().detach() * kl_viol).mean()
+            out["train/kl_div"] = kl_div.mean()
+        else:
+            kl = normal_kl(qm, qs, pm, ps).sum(2)
+            kl_loss = torch.max(kl, torch.full((1,), float(c.free_nats))).mean((0, 1))
+        model_loss = obs_loss + reward_loss + kl_loss
+        self.model_opt.zero_grad()
+        model_loss.backward()
+        self.last["model_grads"] = [None if q.grad is None else q.grad.detach().clone() for q in self.model_params]
+        self.last["model_total_norm"] = float(clip_grad_norm(self.model_params, c.grad_clip_norm))
+        if apply:
+            self.model_opt.step()
+        out.update({"train/obs_loss": obs_loss, "train/reward_loss": reward_loss, "train/kl_loss": kl_loss,
+                    "train/model_loss": model_loss})
+        if self.is_repo:
+            beta_loss = -(log_beta * kl_viol.detach()).mean()
+            self.beta_opt.zero_grad()
+            beta_loss.backward()
+            if apply:
+                self.beta_opt.step()
+            out["train/beta_loss"] = beta_loss
+            for i in range(self.C):
+                out[f"train/beta_{i}"] = self.log_beta[i].exp()
+        self.last["observe"] = [x.detach() for x in (beliefs, prior_s, pm, ps, post_s, qm, qs)]
+        return beliefs.detach(), post_s.detach(), {k: float(v.detach()) for k, v in out.items()}
+
+    def train_actor_critic(self, tasks, beliefs, post_states, eps_act, eps_prior, eps_ent, apply=True):
+        """tasks (N, C).  dreamer_mt.py:230-301."""
+        c, p = self.c, self.p
+        H = c.horizon
+        frozen = self.model_params + self.value_params
+        for q in frozen:
+            q.requires_grad_(False)
+        try:
+            ib, istate, im, isd = cond_imagine(p["transition_model"], p["actor_model"], beliefs, post_states, tasks, H,
+                                               eps_act, eps_prior)
+            Hm, N = ib.shape[:2]
+            tk = tasks[None].repeat(Hm, 1, 1).reshape(Hm * N, -1)
+            fb, fs = ib.reshape(Hm * N, -1), istate.reshape(Hm * N, -1)
+            fsc = torch.cat([fs, tk], 1)
+            r_pred = scalar_head(p["reward_model"], fb, fsc).reshape(Hm, N)
+            v_pred = scalar_head(p["value_model"], fb, fsc).reshape(Hm, N)
+        finally:
+            for q in frozen:
+                q.requires_grad_(True)
+        a_mean, a_std = actor_fwd(p["actor_model"], fb, fsc)
+        action_entropy = tanh_normal_entropy(a_mean, a_std, eps_ent).mean()
+        latent_entropy = isd.log().sum(-1).mean()   # dreamer_mt.py:258: WITHOUT the Normal entropy's constant
+        disc = c.gamma * torch.ones_like(r_pred)
+        returns = lambda_return(r_pred[:-1], v_pred[:-1], disc[:-1], v_pred[-1], c.gae_lambda)
+        actor_loss = -returns.mean() - c.action_ent_coef * action_entropy - c.latent_ent_coef * latent_entropy
+        self.actor_opt.zero_grad()
+        for q in self.model_params + self.value_params:
+            q.grad = None
+        actor_loss.backward()
+        self.last["actor_grads"] = [q.grad.detach().clone() for q in self.actor_params]
+        self.last["actor_total_norm"] = float(clip_grad_norm(self.actor_params, c.grad_clip_norm))
+        if apply:
+            self.actor_opt.step()
+        nv = (Hm - 1) * N
+        v = scalar_head(p["value_model"], fb[:nv].detach(), fsc[:nv].detach())
+        value_loss = (0.5 * (v - returns.detach().reshape(-1)) ** 2 + 0.5 * LOG_2PI).mean()
+        self.value_opt.zero_grad()
+        value_loss.backward()
+        self.last["value_grads"] = [q.grad.detach().clone() for q in self.value_params]
+        self.last["value_total_norm"] = float(clip_grad_norm(self.value_params, c.grad_clip_norm))
+        if apply:
+            self.value_opt.step()
+        self.last["imagine"] = [x.detach() for x in (ib, istate, im, isd)]
+        return {"train/actor_loss": float(actor_loss.detach()), "train/value_loss": float(value_loss.detach()),
+                "train/action_entropy": float(action_entropy.detach()),
+                "train/latent_entropy": float(latent_entropy.detach())}
+
+    def update(self, tasks, obs_u8, actions, rewards, dones, noise):
+        obs = torch.from_numpy(fx.preprocess_u8(np.asarray(obs_u8)))
+        tk = torch.as_tensor(tasks)
+        t = {k: torch.as_tensor(v) for k, v in noise.items()}
+        beliefs, post, scal = self.train_dynamics(tk, obs, torch.as_tensor(actions), torch.as_tensor(rewards),
+                                                  1 - torch.as_tensor(dones), t["obs_prior"], t["obs_post"])
+        scal.update(self.train_actor_critic(tk[1:].flatten(0, 1), beliefs.flatten(0, 1), post.flatten(0, 1),
+                                            t["img_act"], t["img_prior"], t["entropy"]))
+        return beliefs, post, scal

@@ -126,6 +126,11 @@ class Dreamer:
         action_size = int(np.prod(env.action_space.shape))
         self.action_size = action_size
         self._npix = int(np.prod(obs_size))  # 3*64*64 (the reference's frames) or 3*128*128 (build-defined)
+        self._build_modules(config, env, obs_size, action_size)
+        self._build_optimizers(config)
+
+    def _build_modules(self, config, env, obs_size, action_size):
+        """The six modules (the multitask agents build the task-conditioned ones instead: dreamer_mt.py)."""
         dev = self.device
         # same construction order as the reference (dreamer.py:57-114) => same default init under a seed
         self.encoder = Encoder(False, obs_size, config.embedding_size, config.cnn_activation_function).to(dev)
@@ -140,13 +145,6 @@ class Dreamer:
         self.reward_model = RewardModel(
             config.belief_size, config.state_size, config.hidden_size, config.dense_activation_function
         ).to(dev)
-        self.model_params = (
-            list(self.encoder.parameters())
-            + list(self.transition_model.parameters())
-            + list(self.obs_model.parameters())
-            + list(self.reward_model.parameters())
-        )
-        self.model_optimizer = FlatAdam(self.model_params, lr=config.model_lr)
         # quirk kept: dense_activation_function lands in ActorModel's `dist` slot (dreamer.py:99-105)
         self.actor_model = ActorModel(
             config.belief_size, config.state_size, config.hidden_size, action_size, config.dense_activation_function
@@ -154,6 +152,16 @@ class Dreamer:
         self.value_model = ValueModel(
             config.belief_size, config.state_size, config.hidden_size, config.dense_activation_function
         ).to(dev)
+
+    def _build_optimizers(self, config):
+        dev = self.device
+        self.model_params = (
+            list(self.encoder.parameters())
+            + list(self.transition_model.parameters())
+            + list(self.obs_model.parameters())
+            + list(self.reward_model.parameters())
+        )
+        self.model_optimizer = FlatAdam(self.model_params, lr=config.model_lr)
         # the actor's and the critic's flat gradients are the two halves of ONE buffer: a data-parallel job
         # exchanges them as a single 1.18 MB bucket
         na = FlatAdam.padded_numel(list(self.actor_model.parameters()))
@@ -192,6 +200,9 @@ class Dreamer:
         return torch.randn(*shape, device=self.device)
 
     _N_SCANS = 1   # observe scans per update (TIA: 2)
+    # added per state dimension to the logged latent entropy: the multitask agents log sum(log std) WITHOUT the Normal
+    # entropy's constant 0.5 + 0.5 ln(2 pi) (reference dreamer_mt.py:258 against dreamer.py:327-328)
+    _LATENT_ENTROPY_SHIFT = 0.0
 
     def _noise_stride(self):
         """Upper bound (a power of two) of the normals ONE update draws at this configuration:
@@ -364,9 +375,11 @@ class Dreamer:
         return sv.featx[1:, :, :D], sv.featx[1:, :, D:]
 
     # ------------------------------------------------------------------ actor critic
-    def train_actor_critic(self, beliefs, posterior_states):
+    def train_actor_critic(self, beliefs, posterior_states, cond=None):
         """Imagination + actor and critic steps (reference dreamer.py:304-381).
-        beliefs (N, D), posterior_states (N, S): detached start states."""
+        beliefs (N, D), posterior_states (N, S): detached start states.
+        cond (N, C): the multitask agents' task one-hot (dreamer_mt.py:230-301 of the reference) -- every head then
+        reads [belief | state | cond] rows and the rollout runs conditioned (repo_rssm_imagine_fwd, cond)."""
         c = self.c
         dev = self.device
         N = beliefs.shape[0]
@@ -384,9 +397,18 @@ class Dreamer:
         sv = ops.rssm_imagine_fwd(
             pr, pa, beliefs.contiguous(), posterior_states.contiguous(), self._noise("img_act", (Hm, N, A)),
             self._noise("img_prior", (Hm, N, S)), self.transition_model.min_std_dev, *a_consts, spare_slot=True,
-            noise=self._draw(Hm * N * (A + S)), horizon=Hm,
+            noise=self._draw(Hm * N * (A + S)), horizon=Hm, cond=cond,
         )
-        feats = sv.featx[1:].reshape(Hm * N, F_)
+        # every row the heads read: all Hm + 1 slots of the rollout, widened by the condition columns if there is one
+        Fw = F_
+        x_all = sv.featx.reshape((Hm + 1) * N, F_)
+        if cond is not None:
+            Fw = F_ + cond.shape[1]
+            wide = torch.empty((Hm + 1) * N, Fw, device=dev)
+            wide[:, :F_] = x_all
+            wide.view(Hm + 1, N, Fw)[:, :, F_:] = cond
+            x_all = wide
+        feats = x_all[N:]
         r_pred, r_hid = ops.mlp_fwd(pw, feats)
         v_pred, v_hid = ops.mlp_fwd(pv, feats)
         # -- action entropy on the (attached) imagined states (dreamer.py:320-324).  The reference
@@ -395,7 +417,7 @@ class Dreamer:
         #    state is evaluated here, into the spare step slot of the rollout's saved activations.
         nl = sv.a_hidden.shape[0]
         tail = slice(Hm * N, (Hm + 1) * N)
-        ops.mlp_fwd(pa, sv.featx[Hm], out=sv.a_raw[tail], hid=[sv.a_hidden[l, tail] for l in range(nl)])
+        ops.mlp_fwd(pa, x_all[Hm * N:], out=sv.a_raw[tail], hid=[sv.a_hidden[l, tail] for l in range(nl)])
         ops.actor_head_fwd(sv.a_raw[tail], *a_consts, mean=sv.a_mean[tail], std=sv.a_std[tail])
         ent_rows = slice(N, (Hm + 1) * N)  # imagined steps 1..Hm
         mean2, std2 = sv.a_mean[ent_rows], sv.a_std[ent_rows]
@@ -409,7 +431,7 @@ class Dreamer:
         returns, dr, dv, ret_sum = ops.lambda_return(r_pred.view(Hm, N), v_pred.view(Hm, N), c.gamma, c.gae_lambda,
                                                      gret)
         # -- backward: heads -> entropy path (input gradient only) -> reverse rollout
-        dfeat = torch.empty(Hm * N, F_, device=dev)
+        dfeat = torch.empty(Hm * N, Fw, device=dev)
         ops.mlp_bwd(pw, feats, r_hid, dr.view(Hm * N, 1), dparams=None, dx=dfeat)
         ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat, accumulate_dx=True)
         # -- critic on detached imag[:-1] against detached returns (dreamer.py:362-373), forked onto a
@@ -431,13 +453,14 @@ class Dreamer:
         draw2 = ops.actor_head_bwd(mean2, std2, dmean=dmean2, dstd=dstd2, min_std=a_consts[0], mean_scale=a_consts[2])
         ops.mlp_bwd(pa, feats, [sv.a_hidden[l, ent_rows] for l in range(nl)], draw2, dparams=None, dx=dfeat,
                     accumulate_dx=True)
+        if cond is not None:   # the condition columns take a gradient nobody reads
+            dfeat = dfeat[:, :F_].contiguous()
         ops.rssm_imagine_bwd(pr, sv, dfeat, dprior_std=dpstd, min_std=self.transition_model.min_std_dev,
                              a_min_std=a_consts[0], a_mean_scale=a_consts[2], d_araw=d_out)
         ops.actor_head_bwd(mean2, std2, dmean=dmean2, dstd=dstd2, min_std=a_consts[0], mean_scale=a_consts[2],
                            out=d_out[ent_rows], accumulate=True)
         # -- ONE actor-trunk backward over every row the actor saw: both gradient paths share the
         #    same forward activations, and the chain is linear in the output gradient
-        x_all = sv.featx.reshape((Hm + 1) * N, F_)
         ops.mlp_bwd(pa, x_all, [sv.a_hidden[l] for l in range(nl)], d_out, dparams=ga, accumulate_w=False, dx=None)
         if self.dp is not None:
             # ONE bucket for both optimisers (their gradients are the halves of self._ac_grad); the critic's
@@ -478,7 +501,15 @@ class Dreamer:
         self._log_host[:n].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(cur)
-        self._log_pending = (ev, n, dual is not None, grow, Hm, gN, xs.numel(), xn.numel())
+        self._log_pending = (ev, n, dual.numel() if dual is not None else 0, grow, Hm, gN, xs.numel(), xn.numel())
+
+    def _dual_scalars(self, out, dual):
+        """The dual step's scalars (RePo: repo.py:99-105; per-task betas: repo_mt.py:100-112)."""
+        kl_div, kl_loss, beta_loss, beta = dual
+        out["train/kl_loss"] = kl_loss
+        out["train/kl_div"] = kl_div
+        out["train/beta"] = beta
+        out["train/beta_loss"] = beta_loss
 
     def _extra_scalars(self, out, sums, norms, grow):
         """Hook of the sibling algorithms: rewrite / add logged scalars from their own sums (see _log_update)."""
@@ -486,7 +517,7 @@ class Dreamer:
     def _flush_log(self):
         if self._log_pending is None:
             return
-        ev, n, has_dual, grow, Hm, gN, nxs, nxn = self._log_pending
+        ev, n, n_dual, grow, Hm, gN, nxs, nxn = self._log_pending
         self._log_pending = None
         ev.synchronize()
         c = self.c
@@ -500,18 +531,14 @@ class Dreamer:
         out = {}
         out["train/obs_loss"] = nll / grow + 0.5 * LOG_2PI * npix
         out["train/reward_loss"] = (rsq + 0.5 * LOG_2PI * rmask) / grow
-        if has_dual:
-            kl_div, kl_loss, beta_loss, beta = h[12:16]
-            out["train/kl_loss"] = kl_loss
-            out["train/kl_div"] = kl_div
-            out["train/beta"] = beta
-            out["train/beta_loss"] = beta_loss
+        if n_dual:
+            self._dual_scalars(out, h[12 : 12 + n_dual])
         else:
             out["train/kl_loss"] = kl / grow
         out["train/model_loss"] = out["train/obs_loss"] + out["train/reward_loss"] + out["train/kl_loss"]
         self._extra_scalars(out, xsums, xnorms, grow)
         action_entropy = ent / (Hm * gN)
-        latent_entropy = lat / (Hm * gN)
+        latent_entropy = lat / (Hm * gN) + self._LATENT_ENTROPY_SHIFT * self.c.state_size
         out["train/actor_loss"] = (-ret / ((Hm - 1) * gN) - c.action_ent_coef * action_entropy
                                    - c.latent_ent_coef * latent_entropy)
         out["train/value_loss"] = vsq / ((Hm - 1) * gN) + 0.5 * LOG_2PI

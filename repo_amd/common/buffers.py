@@ -70,8 +70,16 @@ class SequenceReplayBuffer:
         self._pushed_total = 0  # monotonic count of stored transitions (device mirror bookkeeping)
         self._mirror = None
 
+    # the per-transition arrays, in the order sample() returns them (the multitask buffer prepends `tasks`)
+    _RING_FIELDS = _FIELDS
+
+    def _rings(self):
+        return tuple(getattr(self, f) for f in self._RING_FIELDS)
+
     # exactly the keys the reference's save() writes (its instance dict, common/buffers.py:193-194)
-    _DATA_KEYS = ("capacity",) + _FIELDS + ("pos", "full")
+    @property
+    def _DATA_KEYS(self):
+        return ("capacity",) + _FIELDS + ("pos", "full") + tuple(f for f in self._RING_FIELDS if f not in _FIELDS)
 
     def __len__(self):
         return self.capacity if self.full else self.pos
@@ -111,7 +119,7 @@ class SequenceReplayBuffer:
             yield [a.reshape(seq_len, batch_size, *a.shape[1:]) for a in self._get_samples(inds)]
 
     def _get_samples(self, batch_inds):
-        return tuple(getattr(self, f)[batch_inds] for f in _FIELDS)
+        return tuple(r[batch_inds] for r in self._rings())
 
     def save(self, path):
         np.savez(path, **{k: getattr(self, k) for k in self._DATA_KEYS})
@@ -169,7 +177,7 @@ class SequenceReplayBuffer:
 
     def _mirror_flush(self, stream):
         m = self._mirror
-        srcs = (self.observations, self.actions, self.rewards, self.dones)
+        srcs = self._rings()
         if m["bufs"] is None:
             m["bufs"] = tuple(torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype, device=m["device"]) for a in srcs)
             m["synced"] = self._pushed_total - self.capacity - 1
@@ -202,12 +210,9 @@ class SequenceReplayBuffer:
             n = seq_len * batch_size
             slots = []
             for _ in range(2):
-                h = (
-                    host((n,) + self.observations.shape[1:], torch.from_numpy(self.observations[:0]).dtype),
-                    host((n,) + self.actions.shape[1:], torch.float32),
-                    host((n, 1), torch.float32),
-                    host((n, 1), torch.float32),
-                )
+                # frames keep the ring's dtype (uint8 on the device); every other field is float32
+                h = tuple(host((n,) + r.shape[1:], torch.from_numpy(r[:0]).dtype if r is self.observations
+                               else torch.float32) for r in self._rings())
                 d = tuple(torch.empty(t.shape, dtype=t.dtype, device=device) for t in h)
                 slots.append({"host": h, "dev": d, "event": None,
                               "idx_host": host((n,), torch.int64),
@@ -238,8 +243,7 @@ class SequenceReplayBuffer:
             return idx
         if slot["event"] is not None:
             slot["event"].synchronize()  # previous copy out of this pinned slot has finished
-        srcs = (self.observations, self.actions, self.rewards, self.dones)
-        for h, src in zip(slot["host"], srcs):
+        for h, src in zip(slot["host"], self._rings()):
             _gather_rows(src, inds, h.numpy())
         if st["stream"] is not None:
             consumed = slot.get("consumed")
@@ -260,7 +264,8 @@ class SequenceReplayBuffer:
 
     def acquire(self, handle, batch_size, seq_len, device):
         """Make the current stream wait for the slot's copy; returns the device tensors
-        (obs uint8 (L,B,C,H,W), actions (L,B,A), rewards (L,B,1), dones (L,B,1))."""
+        (obs uint8 (L,B,C,H,W), actions (L,B,A), rewards (L,B,1), dones (L,B,1); the multitask buffer: tasks
+        (L,B,num_tasks) first)."""
         st = self._staging(batch_size, seq_len, device)
         slot = st["slots"][handle]
         if self._mirror_on(device):
@@ -304,3 +309,24 @@ class SequenceReplayBuffer:
         d = dict(self.__dict__)
         d.pop("_stage", None)
         return d
+
+
+class MultitaskSequenceReplayBuffer(SequenceReplayBuffer):
+    """The reference's multitask ring (/root/reference/common/buffers.py:205-225): a `tasks` array (capacity,
+    num_tasks) beside the four rings, `push(task, obs, act, rew, done)`, and every batch led by its task one-hots:
+    sample() -> (tasks (L,B,num_tasks), obs, act, rew, done).  The pinned staging path and the HBM mirror carry the
+    fifth field like the others."""
+
+    _RING_FIELDS = ("tasks",) + _FIELDS
+
+    def __init__(self, capacity, num_tasks, obs_shape, act_shape, obs_type=np.float32, act_type=np.float32):
+        super().__init__(capacity, obs_shape, act_shape, obs_type, act_type)
+        self.tasks = np.zeros((self.capacity, num_tasks), dtype=act_type)
+
+    def push(self, task, obs, act, rew, done):
+        self.tasks[self.pos] = np.asarray(task)
+        super().push(obs, act, rew, done)
+
+    def adopt_offline(self, paths, truncate_size):
+        raise NotImplementedError("offline datasets carry no task labels (the reference's load_offline_data is "
+                                  "single-task: algorithms/repo/dreamer.py:566-596)")

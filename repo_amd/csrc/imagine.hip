@@ -192,17 +192,17 @@ int philox_fill(float* out, long n, uint64_t seed, uint64_t offset, hipStream_t 
 }
 
 // persistent row-tiled rollout (imagine16.hip)
-bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers);
+bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers, int64_t C);
 size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
 size_t imagine_fused_bwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S);
 int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
-                      const float* const* ap, const float* belief0, const float* state0, NoiseSrc eps_act,
-                      NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std, float a_mean_scale,
+                      const float* const* ap, const float* belief0, const float* state0, const float* cond, int64_t C,
+                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std, float a_mean_scale,
                       float* featx, float* prior_mean, float* prior_std, float* a_hidden, int64_t a_layer_rows,
                       float* a_raw, float* a_mean, float* a_std, float* xsa, float* e, float* gates, float* hp, void* ws,
                       hipStream_t stream);
 int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
-                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std,
+                      int64_t C, NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std,
                       float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
                       const float* a_std, const float* xsa, const float* e, const float* gates, const float* hp,
                       const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
@@ -400,6 +400,7 @@ extern "C" size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, i
 extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                                      int n_actor_layers, const float* const* rssm_params,
                                      const float* const* actor_params, const float* belief0, const float* state0,
+                                     const float* cond, int64_t C,
                                      const float* eps_act, const float* eps_prior, uint64_t noise_seed,
                                      uint64_t noise_offset, float min_std, float a_min_std,
                                      float a_init_std, float a_mean_scale, float* featx, float* prior_mean,
@@ -413,8 +414,11 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                    prior_std && a_hidden && a_raw && a_mean && a_std && xsa && e && gates && hp,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_fwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
-  if (imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers))
-    return imagine_fused_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0,
+  REPO_REQUIRE(C >= 0 && (C == 0 || cond), REPO_E_BADARG);
+  // a conditioned rollout runs on the persistent engine only (the condition rides in the K padding of its tiles)
+  REPO_REQUIRE(C == 0 || imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers, C), REPO_E_SHAPE);
+  if (imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers, C))
+    return imagine_fused_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0, cond, C,
                              NoiseSrc{eps_act, noise_seed, noise_offset},
                              NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_init_std, a_mean_scale, featx, prior_mean, prior_std, a_hidden,
                              a_layer_rows, a_raw, a_mean, a_std, xsa, e, gates, hp, ws, stream);
@@ -472,7 +476,7 @@ extern "C" size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, i
   return unfused > fused ? unfused : fused;
 }
 
-extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
+extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int64_t C,
                                      const float* const* rssm_params, const float* eps_act, const float* eps_prior,
                                      uint64_t noise_seed, uint64_t noise_offset, float min_std, float a_min_std,
                                      float a_mean_scale, const float* featx,
@@ -486,8 +490,9 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                    hp && dfeat && d_araw,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_bwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
-  if (imagine_fused_ok(Hm, N, A, D, Hd, S, 5))
-    return imagine_fused_bwd(Hm, N, A, D, Hd, S, rssm_params, NoiseSrc{eps_act, noise_seed, noise_offset},
+  REPO_REQUIRE(C == 0 || imagine_fused_ok(Hm, N, A, D, Hd, S, 5, C), REPO_E_SHAPE);
+  if (imagine_fused_ok(Hm, N, A, D, Hd, S, 5, C))
+    return imagine_fused_bwd(Hm, N, A, D, Hd, S, rssm_params, C, NoiseSrc{eps_act, noise_seed, noise_offset},
                              NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_mean_scale,
                              featx, prior_std, a_mean, a_std, xsa, e, gates, hp, dfeat, dprior_mean, dprior_std,
                              d_araw, dfeat0, ws, stream);

@@ -36,6 +36,7 @@ namespace repo {
 
 struct ImgDims {
   int Hm, N, A, D, Hd, S;
+  int C;  // condition width (multitask: the task one-hot, ConditionalTransitionModel.imagine, models/rssm.py:221-249); 0 = none
 };
 
 struct ImgFwdArgs {
@@ -46,6 +47,7 @@ struct ImgFwdArgs {
   unsigned Wsa, Wih, Whh, Wbp, Wsp;
   unsigned Bsa, Bih, Bhh, Bbp, Bsp;
   const float *belief0, *state0;
+  const float* cond;  // (N, C): constant over the rollout; columns [F, F+C) of the actor's input, [X, X+C) of W_sa's
   NoiseSrc eps_act, eps_prior;
   float min_std, a_min_std, a_init_std, a_mean_scale;
   float *featx, *prior_mean, *prior_std, *a_hidden, *a_raw, *a_mean, *a_std, *xsa, *e, *gates, *hp;
@@ -56,10 +58,11 @@ struct ImgFwdArgs {
 template <int BF, int BW, int BX, int BS>
 __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int Hm = p.d.Hm, N = p.d.N, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S;
+  const int Hm = p.d.Hm, N = p.d.N, A = p.d.A, D = p.d.D, Hd = p.d.Hd, S = p.d.S, C = p.d.C;
   const int F = D + S, X = S + A;
-  const int FP = pad16(F), WP = pad16(max(D, Hd)), XP = pad16(X), SP = pad16(max(2 * A, 2 * S));
-  float* Fa = lds;               // [FP x 16]  current [belief|state]
+  const int XL = X + C;  // row length of the saved [state|action|condition] rows = K of W_sa
+  const int FP = pad16(F + C), WP = pad16(max(D, Hd)), XP = pad16(XL), SP = pad16(max(2 * A, 2 * S));
+  float* Fa = lds;               // [FP x 16]  current [belief|state] (| condition: columns F.., written once)
   float* Fb = Fa + FP * kR;      // next
   float* HA = Fb + FP * kR;      // [WP x 16]
   float* HB = HA + WP * kR;
@@ -90,6 +93,12 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
       p.featx[(size_t)(r0 + row) * F + f] = v;
       Fa[ai(f, row)] = v;
     }
+  }
+  // the condition: nothing below writes a column >= F of either feature tile (belief quads end at D, D % 4 == 0; the
+  // state is written element-wise), so it is placed once and meets the actor's fc1 columns F.. on every step
+  for (int i = tid; i < kR * C; i += 512) {
+    const int row = i / C, c = i % C;
+    if (row < nr) Fa[ai(F + c, row)] = Fb[ai(F + c, row)] = p.cond[(size_t)(r0 + row) * C + c];
   }
   __syncthreads();
 
@@ -135,11 +144,13 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
     });
     __syncthreads();
     // ---------------- tanh-Normal action sample; x = [state, action]
-    for (int i = tid; i < kR * X; i += 512) {
-      const int row = i / X, k = i % X;
+    for (int i = tid; i < kR * XL; i += 512) {
+      const int row = i / XL, k = i % XL;
       float v;
       if (k < S) {
         v = Fc[ai(D + k, row)];
+      } else if (k >= X) {
+        v = Fc[ai(F + k - X, row)];  // pseudo-action = [action | condition]
       } else {
         const int a = k - S;
         const float mu = p.a_mean_scale * tanh_fast(SM[ai(a, row)] / p.a_mean_scale);
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(512) void imagine_fwd_kernel(ImgFwdArgs p) {
         }
       }
       XS[ai(k, row)] = v;
-      if (row < nr) p.xsa[(rb + row) * X + k] = v;
+      if (row < nr) p.xsa[(rb + row) * XL + k] = v;
     }
     __syncthreads();
     // ---------------- e = elu(W_sa x + b); meanwhile the GRU's first stream and the prior head's are opened
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
       const int row = i / A, a = i % A;
       if (row < nr) {
         const size_t o = (rb + row) * A + a;
-        const float act = p.xsa[(rb + row) * X + S + a];
+        const float act = p.xsa[(rb + row) * (X + p.d.C) + S + a];
         const float du = SM[ai(S + a, row)] * (1.f - act * act);
         const float tm = p.a_mean[o] / p.a_mean_scale;
         p.d_araw[(rb + row) * 2 * A + a] = du * (1.f - tm * tm);
@@ -444,14 +455,16 @@ __global__ __launch_bounds__(512) void imagine_bwd_kernel(ImgBwdArgs p) {
 // 16 k), belief + state = 230 (15), state + action 33..48 (3: A = 6 and ManiSkill's A = 7), 2 * state = 60 (4);
 // any other size runs the per-step engine (imagine.hip).
 constexpr int kBF = 15, kBW = 13, kBX = 3, kBS = 4;
-bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers) {
+bool imagine_fused_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers, int64_t C) {
   auto blk = [](int64_t k) { return pad16((int)k) >> 4; };
+  // a condition of C columns rides in the K padding of the two layers it widens: 230 + C <= 240, S + A + C <= 48
   return n_actor_layers == 5 && D % 4 == 0 && Hd % 4 == 0 && blk(D) == kBW && blk(Hd) == kBW && blk(D + S) == kBF &&
-         blk(S + A) == kBX &&
+         blk(D + S + C) == kBF && blk(S + A) == kBX && blk(S + A + C) == kBX && C >= 0 &&
          blk(2 * S) == kBS && 2 * A <= 16 && (Hm + 1) * N * 4 * D < kMaxIdx;
 }
 
 size_t imagine_fused_fwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  // (K is padded to 16: a condition inside the padding -- imagine_fused_ok -- does not change these)
   return pack_floats(Hd, D + S) + 3 * pack_floats(Hd, Hd) + pack_floats(2 * A, Hd) + pack_floats(D, S + A) +
          2 * pack_floats(3 * D, D) + pack_floats(Hd, D) + pack_floats(2 * S, Hd) +
          // bias vectors: 4 actor hidden + head, fc_embed_state_action, the GRU's two, prior hidden, prior out
@@ -464,14 +477,16 @@ size_t imagine_fused_bwd_ws_floats(int64_t A, int64_t D, int64_t Hd, int64_t S) 
 
 int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S,
                       const float* const* rp, const float* const* ap, const float* belief0, const float* state0,
+                      const float* cond, int64_t C,
                       NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std,
                       float a_mean_scale, float* featx, float* prior_mean, float* prior_std, float* a_hidden,
                       int64_t a_layer_rows, float* a_raw, float* a_mean, float* a_std, float* xsa, float* e,
                       float* gates, float* hp, void* ws, hipStream_t stream) {
-  const int F = (int)(D + S), X = (int)(S + A);
+  const int F = (int)(D + S + C), X = (int)(S + A + C);  // K of the two widened layers (C = 0: the reference's)
   float* w = (float*)ws;
   ImgFwdArgs a;
-  a.d = ImgDims{(int)Hm, (int)N, (int)A, (int)D, (int)Hd, (int)S};
+  a.d = ImgDims{(int)Hm, (int)N, (int)A, (int)D, (int)Hd, (int)S, (int)C};
+  a.cond = cond;
   PackArgs pa;
   pa.njobs = 0;
   float* const w_begin = w;
@@ -517,7 +532,7 @@ int imagine_fused_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
 }
 
 int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
-                      NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std,
+                      int64_t C, NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std,
                       float a_mean_scale, const float* featx, const float* prior_std, const float* a_mean,
                       const float* a_std, const float* xsa, const float* e, const float* gates, const float* hp,
                       const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
@@ -525,7 +540,7 @@ int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
   const int X = (int)(S + A);
   float* w = (float*)ws;
   ImgBwdArgs a;
-  a.d = ImgDims{(int)Hm, (int)N, (int)A, (int)D, (int)Hd, (int)S};
+  a.d = ImgDims{(int)Hm, (int)N, (int)A, (int)D, (int)Hd, (int)S, (int)C};
   PackArgs pa;
   pa.njobs = 0;
   // W'(n = input index, k = output index) = native[k * ld + n]
@@ -542,7 +557,7 @@ int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
     a.Whh[g] = add(rp[3] + (size_t)g * D * D, (int)D, (int)D, (int)D);
     a.Wih[g] = add(rp[2] + (size_t)g * D * D, (int)D, (int)D, (int)D);
   }
-  a.Wsa = add(rp[0], X, (int)D, X);
+  a.Wsa = add(rp[0], X, (int)D, X + (int)C);  // the rows of d [state|action] only: the condition takes no gradient
   a.wpack = w_begin;
   a.wbytes = (unsigned)((w - w_begin) * sizeof(float));
   int rc = launch_pack(pa, stream);

@@ -1,0 +1,251 @@
+// Kernels of the multitask (task-conditioned) agents, SURVEY.md section 8 row f4:
+//   * FiLM modulation of a conv layer's output, h = relu((1 + gamma[n][c]) * y[n][c][p] + beta[n][c])
+//     (ConditionalVisualEncoder.mod / ConditionalVisualObservationModel.mod,
+//     /root/reference/algorithms/repo/models/encoder.py:75-88, models/decoder.py:108-123) and its backward;
+//   * the KL balance with a PER-ROW Lagrange multiplier beta_row = exp(tasks_row . log_beta) and the dual step on the
+//     per-task log_beta vector (MultitaskRePo, /root/reference/algorithms/repo/repo_mt.py:24-32,75-112).
+// All are HBM-bound streaming kernels (bytes read once, wave64 shuffle reductions, fixed-order partial sums: bitwise
+// reproducible, no float atomics).  The one-hot concatenations of the conditioned dense layers need no kernel: the
+// condition is K columns of the caller's feature rows (heads), of the pseudo-actions (observe scan) or of the K
+// padding of the rollout's tiles (repo_rssm_imagine_fwd, cond).
+#include "common.h"
+
+namespace repo {
+
+constexpr int kMtRedBlocks = 512;
+constexpr int kMtMaxTasks = 13;  // 3 + C partial-sum columns <= 16
+
+// ------------------------------------------------------------------ FiLM forward
+// One workgroup walks whole (image, channel) planes: the plane's two modulation scalars are wave-uniform loads.
+// film[n * ld + goff + c] = gamma, film[n * ld + boff + c] = beta (the reference's film(condition).chunk(2).split(...)).
+__global__ __launch_bounds__(256) void film_fwd_kernel(long planes, int C, int P, const float* __restrict__ y,
+                                                       const float* __restrict__ film, int ld, int goff, int boff,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  if (P >= 64) {
+    for (long pl = wave; pl < planes; pl += nwaves) {
+      const long n = pl / C;
+      const int c = (int)(pl % C);
+      const float g = 1.f + film[n * ld + goff + c], b = film[n * ld + boff + c];
+      const float* src = y + pl * P;
+      float* dst = out + pl * P;
+      for (int p = lane; p < P; p += 64) dst[p] = fmaxf(fmaf(g, src[p], b), 0.f);
+    }
+  } else {
+    // small planes (2x2, 5x5, 6x6): a lane per element over a run of consecutive planes
+    const long total = planes * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const long pl = i / P, n = pl / C;
+      const int c = (int)(pl % C);
+      out[i] = fmaxf(fmaf(1.f + film[n * ld + goff + c], y[i], film[n * ld + boff + c]), 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ FiLM backward
+// dh is the gradient at the ReLU's INPUT (the producer -- a data-gradient kernel with the MUL_DRELU epilogue, or
+// repo_relu_mask -- has applied the mask): dy = dh * (1 + gamma); d gamma[n][c] = sum_p dh * y; d beta[n][c] = sum_p dh.
+// One wave per plane, fixed summation order.  dfilm rows are written (each (n, c) slot is owned by one plane).
+__global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P, const float* __restrict__ dh,
+                                                       const float* __restrict__ y, const float* __restrict__ film,
+                                                       int ld, int goff, int boff, float* __restrict__ dy,
+                                                       float* __restrict__ dfilm) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long pl = wave; pl < planes; pl += nwaves) {
+    const long n = pl / C;
+    const int c = (int)(pl % C);
+    const float g = 1.f + film[n * ld + goff + c];
+    const float* d = dh + pl * P;
+    const float* src = y + pl * P;
+    float* dst = dy + pl * P;
+    float sg = 0.f, sb = 0.f;
+    for (int p = lane; p < P; p += 64) {
+      const float v = d[p];
+      sg = fmaf(v, src[p], sg);
+      sb += v;
+      dst[p] = v * g;
+    }
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if (lane == 0) {
+      dfilm[n * ld + goff + c] = sg;
+      dfilm[n * ld + boff + c] = sb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ KL balance with per-row beta
+// parts is [3 + C][gridDim.x]: sum KL, sum beta_row * viol_row, sum lb_row * viol_row, sum tasks[row][i] * viol_row.
+__global__ __launch_bounds__(256) void kl_tasks_kernel(int rows, int S, int C, const float* __restrict__ pm,
+                                                       const float* __restrict__ ps, const float* __restrict__ qm,
+                                                       const float* __restrict__ qs, float alpha,
+                                                       const float* __restrict__ log_beta,
+                                                       const float* __restrict__ tasks, float target_kl, float scale,
+                                                       float* __restrict__ dpm, float* __restrict__ dps,
+                                                       float* __restrict__ dqm, float* __restrict__ dqs,
+                                                       float* __restrict__ parts) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float acc[3 + kMtMaxTasks];
+#pragma unroll
+  for (int i = 0; i < 3 + kMtMaxTasks; ++i) acc[i] = 0.f;
+  for (int row = blockIdx.x * nw + wid; row < rows; row += gridDim.x * nw) {
+    float kl = 0.f, gpm = 0.f, gps = 0.f, gqm = 0.f, gqs = 0.f;
+    const size_t o = (size_t)row * S + lane;
+    if (lane < S) {
+      const float mp = pm[o], sp = ps[o], mq = qm[o], sq = qs[o];
+      const float ratio = sq / sp, vr = ratio * ratio;
+      const float dm = (mq - mp) / sp, t1 = dm * dm;
+      kl = 0.5f * (vr + t1 - 1.f - logf(vr));
+      const float isp2 = 1.f / (sp * sp);
+      gqm = (mq - mp) * isp2;
+      gpm = -gqm;
+      gqs = -1.f / sq + sq * isp2;
+      gps = 1.f / sp - (sq * sq + (mq - mp) * (mq - mp)) * isp2 / sp;
+    }
+    const float klrow = wave_sum(kl);
+    float lb = 0.f;  // log_beta of this row = tasks[row] @ log_beta (repo_mt.py:89)
+    for (int i = 0; i < C; ++i) lb = fmaf(tasks[(size_t)row * C + i], log_beta[i], lb);
+    const float beta = expf(lb), viol = klrow - target_kl;
+    const float wp = beta * alpha * scale, wq = beta * (1.f - alpha) * scale;
+    if (lane == 0) {
+      acc[0] += klrow;
+      acc[1] = fmaf(beta, viol, acc[1]);
+      acc[2] = fmaf(lb, viol, acc[2]);
+#pragma unroll
+      for (int i = 0; i < kMtMaxTasks; ++i)
+        if (i < C) acc[3 + i] = fmaf(tasks[(size_t)row * C + i], viol, acc[3 + i]);
+    }
+    if (lane < S) {
+      if (dpm) dpm[o] = gpm * wp;
+      if (dps) dps[o] = gps * wp;
+      if (dqm) dqm[o] = gqm * wq;
+      if (dqs) dqs[o] = gqs * wq;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3 + kMtMaxTasks; ++i) {
+    if (i < 3 + C) {  // (uniform)
+      const float s = block_sum(acc[i], red);
+      if (threadIdx.x == 0) parts[i * gridDim.x + blockIdx.x] = s;
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void mt_final_sum_kernel(const float* __restrict__ parts, int n, int nvals, float* __restrict__ out) {
+  __shared__ float red[16];
+  for (int v = 0; v < nvals; ++v) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += parts[v * n + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[v] = s;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ dual step on the per-task log_beta vector
+// sums = the (3 + C) sums above over the GLOBAL batch.  beta_loss = -mean(lb_row * viol_row)  =>
+// d / d log_beta[i] = -sum_rows tasks[row][i] * viol_row / rows; one torch.optim.Adam step on the C-vector.
+// scalars_out: [kl_div, kl_loss, beta_loss, beta_0 .. beta_{C-1} AFTER the step] (repo_mt.py:100-112).
+__global__ void dual_step_tasks_kernel(int C, float* __restrict__ log_beta, float* __restrict__ m,
+                                       float* __restrict__ v, const float* __restrict__ sums, float inv_rows, float lr,
+                                       float b1, float b2, float eps, float bc1, float bc2_sqrt, int apply,
+                                       float* __restrict__ scalars_out) {
+  const int i = threadIdx.x;
+  if (blockIdx.x != 0) return;
+  if (i == 0) {
+    scalars_out[0] = sums[0] * inv_rows;
+    scalars_out[1] = sums[1] * inv_rows;
+    scalars_out[2] = -sums[2] * inv_rows;
+  }
+  if (i < C) {
+    const float g = -sums[3 + i] * inv_rows;
+    float nlb = log_beta[i];
+    if (apply) {
+      const float mm = b1 * m[i] + (1.f - b1) * g;
+      const float vv = b2 * v[i] + (1.f - b2) * g * g;
+      m[i] = mm;
+      v[i] = vv;
+      nlb -= (lr / bc1) * mm / (sqrtf(vv) / bc2_sqrt + eps);
+      log_beta[i] = nlb;
+    }
+    scalars_out[3 + i] = expf(nlb);
+  }
+}
+
+}  // namespace repo
+
+using namespace repo;
+
+static bool film_args_ok(int64_t nimg, int64_t C, int64_t P, int64_t ld, int64_t goff, int64_t boff) {
+  return nimg > 0 && C > 0 && P > 0 && nimg * C * P < kMaxIdx * 4L && goff >= 0 && boff >= 0 && goff + C <= ld &&
+         boff + C <= ld && (goff + C <= boff || boff + C <= goff);
+}
+
+extern "C" int repo_film_fwd(int64_t nimg, int64_t C, int64_t P, const float* y, const float* film, int64_t ldfilm,
+                             int64_t gamma_off, int64_t beta_off, float* out, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(film_args_ok(nimg, C, P, ldfilm, gamma_off, beta_off), REPO_E_SHAPE);
+  REPO_REQUIRE(y && film && out, REPO_E_BADARG);
+  const long planes = nimg * C;
+  long blocks = P >= 64 ? (planes + 3) / 4 : (planes * P + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(film_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, y, film,
+                     (int)ldfilm, (int)gamma_off, (int)beta_off, out);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* y, const float* film,
+                             int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm,
+                             hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(film_args_ok(nimg, C, P, ldfilm, gamma_off, beta_off), REPO_E_SHAPE);
+  REPO_REQUIRE(dh && y && film && dy && dfilm, REPO_E_BADARG);
+  const long planes = nimg * C;
+  long blocks = (planes + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(film_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, y,
+                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" size_t repo_kl_balance_tasks_workspace_bytes(void) { return (3 + kMtMaxTasks) * kMtRedBlocks * sizeof(float); }
+
+extern "C" int repo_kl_balance_tasks(int64_t rows, int64_t S, int64_t C, const float* pm, const float* ps,
+                                     const float* qm, const float* qs, float alpha, const float* log_beta,
+                                     const float* tasks, float target_kl, float scale, float* dpm, float* dps,
+                                     float* dqm, float* dqs, float* sums, void* ws, size_t ws_bytes,
+                                     hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(rows > 0 && S > 0 && S <= 64 && rows * S < kMaxIdx && C >= 1 && C <= kMtMaxTasks, REPO_E_SHAPE);
+  REPO_REQUIRE(pm && ps && qm && qs && log_beta && tasks && sums, REPO_E_BADARG);
+  REPO_REQUIRE(ws && ws_bytes >= repo_kl_balance_tasks_workspace_bytes(), REPO_E_WS_TOO_SMALL);
+  long blocks = (rows + 3) / 4;
+  if (blocks > kMtRedBlocks) blocks = kMtRedBlocks;
+  hipLaunchKernelGGL(kl_tasks_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (int)rows, (int)S, (int)C, pm, ps, qm,
+                     qs, alpha, log_beta, tasks, target_kl, scale, dpm, dps, dqm, dqs, (float*)ws);
+  REPO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mt_final_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)blocks, (int)(3 + C),
+                     sums);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" int repo_dual_step_tasks(int64_t C, float* log_beta, float* exp_avg, float* exp_avg_sq, const float* sums,
+                                    int64_t rows, float lr, float beta1, float beta2, float eps, int64_t step,
+                                    int apply, float* scalars_out, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(C >= 1 && C <= kMtMaxTasks && rows > 0 && step >= 1, REPO_E_SHAPE);
+  REPO_REQUIRE(log_beta && exp_avg && exp_avg_sq && sums && scalars_out, REPO_E_BADARG);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(dual_step_tasks_kernel, dim3(1), dim3(64), 0, stream, (int)C, log_beta, exp_avg, exp_avg_sq, sums,
+                     (float)(1.0 / (double)rows), lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), apply, scalars_out);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}

@@ -1,0 +1,145 @@
+"""Multi-kernel passes of the FiLM-conditioned conv stacks (multitask agents).
+
+Reference: ConditionalVisualEncoder.forward (/root/reference/algorithms/repo/models/encoder.py:78-88) and
+ConditionalVisualObservationModel.forward (models/decoder.py:111-123):
+
+    gammas, betas = film(condition).chunk(2, dim=1)        # one Linear(C -> 2 * sum(channels))
+    h_l = relu((1 + gamma_l) * conv_l(h_{l-1}) + beta_l)   # per (frame, channel); the decoder's conv4 is not modulated
+
+Here a modulated layer is the conv kernel with its BIAS-ONLY epilogue (y_l, saved) followed by repo_film_fwd (h_l,
+saved); backwards the data-gradient kernel of layer l+1 delivers d h_l already masked by ReLU (its MUL_DRELU epilogue
+on h_l), repo_film_bwd turns it into d y_l and the (frame, channel) gradients of gamma / beta, and the conv's weight /
+data gradients consume d y_l.  Parameter lists are the unconditioned stack's (functional.py) followed by
+[film.weight, film.bias]; gradients are written in place into `g` (same order).
+"""
+import torch
+
+from . import ops
+from .algorithms.repo.models.conditional import DEC_CHANNELS, ENC_CHANNELS, film_offsets
+from .functional import _Fork
+
+_ENC_L = (ops.ENC1, ops.ENC2, ops.ENC3, ops.ENC4)
+_ENC_OFF = film_offsets(ENC_CHANNELS)
+_DEC_OFF = film_offsets(DEC_CHANNELS)
+
+
+def _film(p_w, p_b, cond):
+    """film(condition): (n, C) @ W^T + b -> (n, 2 * channels)."""
+    return ops.gemm(cond, p_w, transb=True, bias=p_b)
+
+
+def _film_grads(dfilm, cond, g_w, g_b, accumulate):
+    ops.gemm_wgrad(dfilm, cond, dW=g_w, db=g_b, accumulate=accumulate)
+
+
+# ----------------------------------------------------------------------------- encoder
+def cond_encoder_fwd(p, obs, cond):
+    """p = [conv1.w, conv1.b, ..., conv4.w, conv4.b, film.w, film.b]; obs (n,3,64,64) uint8 | float32 in [-1,1];
+    cond (n, C).  Returns (embeds (n, 1024), saved)."""
+    film = _film(p[8], p[9], cond)
+    x, ys, hs = obs, [], []
+    for l in range(4):
+        y = ops.conv_down(_ENC_L[l], x, p[2 * l], p[2 * l + 1], epi=ops.EPI_NONE)
+        x = ops.film_fwd(y, film, *_ENC_OFF[l])
+        ys.append(y)
+        hs.append(x)
+    return x.view(x.shape[0], -1), (film, ys, hs)
+
+
+def cond_encoder_bwd(p, obs, cond, saved, dembeds, g, accumulate=False, side=None):
+    """Gradients of the ten encoder tensors into g."""
+    film, ys, hs = saved
+    fk = _Fork(side)
+    dfilm = torch.empty_like(film)
+    packs = [None] + [ops.conv_up_pack(_ENC_L[l], p[2 * l]) for l in (1, 2, 3)]
+    dh = ops.relu_mask(dembeds.reshape(hs[3].shape).contiguous(), hs[3])
+    for l in (3, 2, 1, 0):
+        dy = ops.film_bwd(dh, ys[l], film, *_ENC_OFF[l], dfilm)
+        below = hs[l - 1] if l > 0 else obs
+        fk.run(lambda l=l, dy=dy, below=below: ops.conv_wgrad(_ENC_L[l], dy, below, dw=g[2 * l], db=g[2 * l + 1],
+                                                             accumulate=accumulate))
+        if l > 0:
+            dh = ops.conv_up(_ENC_L[l], dy, p[2 * l], None, epi=ops.EPI_MUL_DRELU, aux=hs[l - 1], pack=packs[l])
+    _film_grads(dfilm, cond, g[8], g[9], accumulate)
+    fk.join()
+
+
+# ----------------------------------------------------------------------------- decoder
+def _cond_decoder_trunk(p, feat, cond):
+    """feat (rows, D + S) = [belief | state]: the pixel decoder concatenates nothing (models/decoder.py:116), the
+    condition enters through FiLM on conv1..conv3 only;
+    p = [fc1.w, fc1.b, conv1.w, conv1.b, ..., conv4.w, conv4.b, film.w, film.b]."""
+    rows = feat.shape[0]
+    film = _film(p[10], p[11], cond)
+    pk2, pk3 = ops.conv_up_pack(ops.DEC2, p[4]), ops.conv_up_pack(ops.DEC3, p[6])
+    h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
+    w1 = p[2].view(p[2].shape[0], -1)
+    y1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_NONE).view(rows, 128, 5, 5)
+    h1 = ops.film_fwd(y1, film, *_DEC_OFF[0])
+    y2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_NONE, pack=pk2)
+    h2 = ops.film_fwd(y2, film, *_DEC_OFF[1])
+    y3 = ops.conv_up(ops.DEC3, h2, p[6], p[7], epi=ops.EPI_NONE, pack=pk3)
+    h3 = ops.film_fwd(y3, film, *_DEC_OFF[2])
+    return film, h0, (y1, y2, y3), (h1, h2, h3)
+
+
+def cond_decoder_fwd(p, feat, cond):
+    """Values only: feat (rows, D + S), cond (rows, C) -> (recon (rows,3,64,64), saved)."""
+    film, h0, ys, hs = _cond_decoder_trunk(p, feat, cond)
+    recon = ops.conv_up(ops.DEC4, hs[2], p[8], p[9], epi=ops.EPI_NONE)
+    return recon, (film, h0, ys, hs)
+
+
+def cond_decoder_fwd_nll(p, feat, cond, target, grad_scale):
+    """Decoder forward fused with the unit-variance pixel NLL (dreamer_mt.py:189-195).
+    Returns (sum 0.5*(recon-target)^2 (1,), saved incl. d loss / d recon * grad_scale)."""
+    film, h0, ys, hs = _cond_decoder_trunk(p, feat, cond)
+    loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(hs[2], p[8], p[9], target, grad_scale, want_mask=True)
+    return loss_sum, (film, h0, ys, hs, dpre4, mask3)
+
+
+def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None):
+    """From d recon (saved) to the twelve decoder tensors (into g) and, if dfeat (rows, ld >= D+S) is given (Dreamer's
+    attached decoder), to the [belief | state] input (written into its first D+S columns)."""
+    film, h0, (y1, y2, y3), (h1, h2, h3), d4, mask3 = saved
+    rows = feat.shape[0]
+    fk = _Fork(side)
+    dfilm = torch.empty_like(film)
+
+    def w4():
+        ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+
+    fk.run(w4)
+    dh3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_MASK4, aux=mask3)
+    dy3 = ops.film_bwd(dh3, y3, film, *_DEC_OFF[2], dfilm)
+
+    def w3():
+        ops.conv_wgrad(ops.DEC3, h2, dy3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(dy3, out=g[7], accumulate=accumulate)
+
+    fk.run(w3)
+    dh2 = ops.conv_down(ops.DEC3, dy3, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h2)
+    dy2 = ops.film_bwd(dh2, y2, film, *_DEC_OFF[1], dfilm)
+
+    def w2():
+        ops.conv_wgrad(ops.DEC2, h1, dy2, dw=g[4], db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(dy2, out=g[5], accumulate=accumulate)
+
+    fk.run(w2)
+    dh1 = ops.conv_down(ops.DEC2, dy2, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h1)
+    dy1 = ops.film_bwd(dh1, y1, film, *_DEC_OFF[0], dfilm)
+    d1f = dy1.view(rows, 128 * 25)
+    w1 = p[2].view(p[2].shape[0], -1)
+
+    def w1f():
+        ops.gemm_wgrad(h0, d1f, dW=g[2].view(w1.shape), db=None, accumulate=accumulate, want_bias=False)
+        ops.channel_sum(dy1.view(rows, 128, 25), out=g[3], accumulate=accumulate)
+
+    fk.run(w1f)
+    dh0 = ops.gemm(d1f, w1, transb=True)
+    ops.gemm_wgrad(dh0, feat, dW=g[0], db=g[1], accumulate=accumulate)
+    if dfeat is not None:
+        ops.gemm(dh0, p[0], out=dfeat, accumulate=accumulate_dfeat)
+    _film_grads(dfilm, cond, g[10], g[11], accumulate)
+    fk.join()

@@ -493,14 +493,17 @@ def actor_head_bwd(mean, std, dmean=None, dstd=None, daction=None, action=None, 
 # ----------------------------------------------------------------------------- imagination
 class ImagineSaved:
     __slots__ = ("Hm", "N", "A", "D", "Hd", "S", "featx", "prior_mean", "prior_std", "a_hidden", "a_raw", "a_mean",
-                 "a_std", "xsa", "e", "gates", "hp", "eps_act", "eps_prior", "noise")
+                 "a_std", "xsa", "e", "gates", "hp", "eps_act", "eps_prior", "noise", "C")
 
 
 def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_prior, min_std=0.1, a_min_std=0.1,
-                     a_init_std=0.0, a_mean_scale=5.0, spare_slot=False, noise=(0, 0), horizon=None):
+                     a_init_std=0.0, a_mean_scale=5.0, spare_slot=False, noise=(0, 0), horizon=None, cond=None):
     """spare_slot: allocate the saved actor tensors with one extra step slot ((Hm+1)*N rows) so the
     caller can evaluate the actor on the final imagined state into the same buffers.
-    eps_act = eps_prior = None (+ horizon = Hm): the kernel draws its noise from Philox stream noise = (seed, offset)."""
+    eps_act = eps_prior = None (+ horizon = Hm): the kernel draws its noise from Philox stream noise = (seed, offset).
+    cond (N, C): the multitask agents' conditioned rollout (include/repo_hip.h); the actor's fc1 and W_sa carry C more
+    input columns."""
+    C = 0 if cond is None else cond.shape[1]
     if eps_act is None:
         Hm, N, A = int(horizon), belief0.shape[0], actor_params[-1].shape[0] // 2
     else:
@@ -512,12 +515,13 @@ def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_pr
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
     sv = ImagineSaved()
     sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S = Hm, N, A, D, Hd, S
+    sv.C = C
     sv.featx = f(Hm + 1, N, D + S)
     sv.prior_mean, sv.prior_std = f(Hm, N, S), f(Hm, N, S)
     ar = (Hm + 1) * N if spare_slot else Hm * N
     sv.a_hidden = f(La - 1, ar, Hd)
     sv.a_raw, sv.a_mean, sv.a_std = f(ar, 2 * A), f(ar, A), f(ar, A)
-    sv.xsa, sv.e, sv.gates, sv.hp = f(Hm * N, S + A), f(Hm * N, D), f(Hm * N, 4 * D), f(Hm * N, Hd)
+    sv.xsa, sv.e, sv.gates, sv.hp = f(Hm * N, S + A + C), f(Hm * N, D), f(Hm * N, 4 * D), f(Hm * N, Hd)
     sv.eps_act = _f32c(eps_act) if eps_act is not None else None
     sv.eps_prior = _f32c(eps_prior) if eps_prior is not None else None
     sv.noise = (int(noise[0]), int(noise[1]))
@@ -526,7 +530,8 @@ def rssm_imagine_fwd(rssm_params, actor_params, belief0, state0, eps_act, eps_pr
     ra, aa = ptr_array(rssm_params), ptr_array(actor_params)
     check(
         lib().repo_rssm_imagine_fwd(
-            Hm, N, A, D, Hd, S, La, ra, aa, _ptr(_f32c(belief0)), _ptr(_f32c(state0)), _ptr(sv.eps_act),
+            Hm, N, A, D, Hd, S, La, ra, aa, _ptr(_f32c(belief0)), _ptr(_f32c(state0)),
+            _ptr(_f32c(cond)) if C else None, C, _ptr(sv.eps_act),
             _ptr(sv.eps_prior), sv.noise[0], sv.noise[1], min_std, a_min_std, a_init_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_mean),
             _ptr(sv.prior_std), _ptr(sv.a_hidden), ar, _ptr(sv.a_raw), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(ws), ws.numel(), _stream(),
@@ -547,8 +552,8 @@ def rssm_imagine_bwd(rssm_params, sv, dfeat, dprior_mean=None, dprior_std=None, 
     ra = ptr_array(rssm_params)
     check(
         lib().repo_rssm_imagine_bwd(
-            sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S, ra, _ptr(sv.eps_act), _ptr(sv.eps_prior), sv.noise[0], sv.noise[1],
-            min_std, a_min_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
+            sv.Hm, sv.N, sv.A, sv.D, sv.Hd, sv.S, getattr(sv, "C", 0), ra, _ptr(sv.eps_act), _ptr(sv.eps_prior),
+            sv.noise[0], sv.noise[1], min_std, a_min_std, a_mean_scale, _ptr(sv.featx), _ptr(sv.prior_std), _ptr(sv.a_mean), _ptr(sv.a_std), _ptr(sv.xsa),
             _ptr(sv.e), _ptr(sv.gates), _ptr(sv.hp), _ptr(_f32c(dfeat)), _ptr(dprior_mean), _ptr(dprior_std),
             _ptr(d_araw), _ptr(dfeat0), _ptr(ws), ws.numel(), _stream(),
         ),
@@ -709,4 +714,60 @@ def philox_normal(n, seed, offset, device):
     instead of a noise tensor draws for elements 0..n-1."""
     out = torch.empty(int(n), dtype=torch.float32, device=device)
     check(lib().repo_philox_normal(_ptr(out), int(n), int(seed), int(offset), _stream()), "repo_philox_normal")
+    return out
+
+
+# ----------------------------------------------------------------------------- multitask (task-conditioned) agents
+def film_fwd(y, film, gamma_off, beta_off, out=None):
+    """h = relu((1 + gamma) * y + beta) per (image, channel) plane; y (n, C, ...) NCHW, film (n, ld) the FiLM layer's
+    output, gamma / beta at column offsets gamma_off / beta_off (models/encoder.py:75-88 of the reference)."""
+    n, C = y.shape[:2]
+    P = y.numel() // (n * C)
+    if out is None:
+        out = torch.empty_like(y)
+    check(lib().repo_film_fwd(n, C, P, _ptr(y), _ptr(film), film.shape[1], gamma_off, beta_off, _ptr(out), _stream()),
+          "repo_film_fwd")
+    return out
+
+
+def film_bwd(dh, y, film, gamma_off, beta_off, dfilm, dy=None):
+    """dh: gradient at the ReLU's input (mask applied).  Returns dy = dh * (1 + gamma); writes the (n, C) gamma and
+    beta gradient blocks of dfilm (n, ld)."""
+    n, C = y.shape[:2]
+    P = y.numel() // (n * C)
+    if dy is None:
+        dy = torch.empty_like(y)
+    check(lib().repo_film_bwd(n, C, P, _ptr(dh), _ptr(y), _ptr(film), film.shape[1], gamma_off, beta_off, _ptr(dy),
+                              _ptr(dfilm), _stream()), "repo_film_bwd")
+    return dy
+
+
+def kl_balance_tasks(pm, ps, qm, qs, alpha, log_beta, tasks, target_kl, scale):
+    """MultitaskRePo's KL balance with the per-row multiplier exp(tasks_row . log_beta) (repo_mt.py:75-93).
+    Returns (sums (3 + C,), [dpm, dps, dqm, dqs])."""
+    S = pm.shape[-1]
+    rows = pm.numel() // S
+    C = log_beta.numel()
+    dev = pm.device
+    g = [torch.empty_like(pm) for _ in range(4)]
+    sums = torch.empty(3 + C, dtype=torch.float32, device=dev)
+    nb = lib().repo_kl_balance_tasks_workspace_bytes()
+    ws = workspace(nb, dev)
+    check(
+        lib().repo_kl_balance_tasks(rows, S, C, _ptr(_f32c(pm)), _ptr(_f32c(ps)), _ptr(_f32c(qm)), _ptr(_f32c(qs)),
+                                    float(alpha), _ptr(log_beta), _ptr(_f32c(tasks)), float(target_kl), float(scale),
+                                    _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(sums), _ptr(ws), ws.numel(),
+                                    _stream()),
+        "repo_kl_balance_tasks",
+    )
+    return sums, g
+
+
+def dual_step_tasks(log_beta, exp_avg, exp_avg_sq, sums, rows, lr, betas, eps, step, apply=True, out=None):
+    C = log_beta.numel()
+    if out is None:
+        out = torch.empty(3 + C, dtype=torch.float32, device=log_beta.device)
+    check(lib().repo_dual_step_tasks(C, _ptr(log_beta), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(sums), int(rows), float(lr),
+                                     float(betas[0]), float(betas[1]), float(eps), int(step), int(bool(apply)), _ptr(out),
+                                     _stream()), "repo_dual_step_tasks")
     return out

@@ -213,6 +213,63 @@ def run_case(Algo, algo_name, L, B, H, A, n_updates, full_latents, feeder, recor
     print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
 
 
+def run_mt_case(algo_name, L, B, H, A, C, n_updates, feeder, record, out_path, **over):
+    """MultitaskDreamer / MultitaskRePo (dreamer_mt.py, repo_mt.py; share_repr=False): tasks (L, B, C) lead every
+    batch.  Same stored quantities as run_case; log_beta is the per-task VECTOR."""
+    from algorithms.repo import MultitaskDreamer, MultitaskRePo
+
+    Algo = MultitaskRePo if algo_name == "repo_multitask" else MultitaskDreamer
+    cfg = fx.default_config(algo=algo_name, batch_size=B, chunk_size=L, horizon=H, share_repr=False, **over)
+    logger = RecLogger()
+    env = FakeEnv(A)
+    env.num_tasks = C
+    algo = Algo(cfg, env, env, logger)
+    load_params(algo, fx.make_params(A, seed=7, cond=C))
+    T = L - 1
+    g = OrderedDict()
+    g["meta"] = np.array([L, B, H, A, n_updates, C], dtype=np.int64)
+    g["cfg"] = np.array([cfg.init_beta, cfg.target_kl, cfg.beta_lr], dtype=np.float64)
+    scalar_keys = None
+    for u in range(n_updates):
+        obs_u8, actions, rewards, dones = fx.make_batch(L, B, A, seed=11 + u)
+        tasks = fx.make_tasks(L, B, C, seed=11 + u)
+        noise = fx.make_noise(L, B, H, A, seed=101 + u)
+        feeder.load(noise, T, H)
+        record["clip_calls"].clear()
+        record["total_norms"].clear()
+        logger.kv.clear()
+        tk = torch.from_numpy(tasks)
+        beliefs, post = algo.train_dynamics(tk, torch.from_numpy(fx.preprocess_u8(obs_u8)), torch.from_numpy(actions),
+                                            torch.from_numpy(rewards), torch.from_numpy(1 - dones))
+        algo.train_actor_critic(tk[1:].flatten(0, 1), beliefs.flatten(0, 1), post.flatten(0, 1))
+        assert not feeder.queue, "noise left over: draw order differs from SURVEY 8c"
+        keys = sorted(logger.kv.keys())
+        scalar_keys = scalar_keys or keys
+        assert keys == scalar_keys
+        g[f"u{u}/scalars"] = np.array([logger.kv[k] for k in keys], dtype=np.float64)
+        if hasattr(algo, "log_beta"):
+            g[f"u{u}/log_beta"] = algo.log_beta.detach().numpy().astype(np.float64)
+        g[f"u{u}/total_norms"] = np.array(record["total_norms"], dtype=np.float64)
+        mn = module_norms(algo, record["clip_calls"][0], "model")
+        mn.update(module_norms(algo, record["clip_calls"][1], "actor_model"))
+        mn.update(module_norms(algo, record["clip_calls"][2], "value_model"))
+        g[f"u{u}/module_grad_norms"] = np.array([mn[m] for m in fx.MODULES], dtype=np.float64)
+        g[f"u{u}/beliefs"] = beliefs.numpy().copy()
+        g[f"u{u}/posterior_states"] = post.numpy().copy()
+        print(f"  [{os.path.basename(out_path)}] update {u}: "
+              + " ".join(f"{k.split('/')[-1]}={logger.kv[k]:.6g}" for k in keys), flush=True)
+    g["scalar_keys"] = np.array(scalar_keys)
+    names, sums, abssums = [], [], []
+    for mod in fx.MODULES:
+        for k, v in getattr(algo, mod).state_dict().items():
+            names.append(f"{mod}.{k}")
+            sums.append(float(v.double().sum()))
+            abssums.append(float(v.double().abs().sum()))
+    g["param_names"], g["param_sums"], g["param_abssums"] = np.array(names), np.array(sums), np.array(abssums)
+    np.savez_compressed(out_path, **g)
+    print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
+
+
 def run_tia_case(TIA, L, B, H, A, n_updates, feeder, record, out_path, **cfg_over):
     """The reference's TIA (tia.py) on seeded parameters / batches / noise: logged scalars, the pre-clip total
     norms of its clip_grad_norm_ calls (model, distractor reward x tia_reward_train_steps, actor, value), the task
@@ -309,6 +366,14 @@ def run_finetune_case(L, B, A, n_updates, feeder, record, out_path):
     print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
 
 
+def run_mt_cases(feeder, record):
+    # multitask (f4): MultitaskDreamer at the defaults; MultitaskRePo with a beta large enough for the per-task
+    # multipliers to matter and a target below the KL, 3 tasks (every multitask environment of the reference has 3)
+    run_mt_case("dreamer_multitask", 8, 4, 5, 6, 3, 3, feeder, record, os.path.join(OUT, "mt_dreamer_tiny.npz"))
+    run_mt_case("repo_multitask", 8, 4, 5, 6, 3, 3, feeder, record, os.path.join(OUT, "mt_repo_tiny.npz"),
+                init_beta=0.05, target_kl=0.3, beta_lr=1e-2)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -319,6 +384,9 @@ def main():
 
     if "--finetune-only" in sys.argv:
         run_finetune_case(8, 4, 6, 3, feeder, record, os.path.join(OUT, "finetune_tiny.npz"))
+        return
+    if "--mt-only" in sys.argv:
+        run_mt_cases(feeder, record)
         return
     if "--tia-only" in sys.argv:
         run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(OUT, "tia_tiny.npz"))
@@ -340,6 +408,7 @@ def main():
     run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(OUT, "tia_tiny.npz"))
     run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(OUT, "tia_coefs.npz"), tia_obs_coef=0.5,
                  tia_adv_coef=2.0, tia_reward_train_steps=2)
+    run_mt_cases(feeder, record)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,352 @@
+"""Multitask agents (MultitaskDreamer / MultitaskRePo, /root/reference/algorithms/repo/
+dreamer_mt.py, repo_mt.py) on the GPU: the FiLM and per-task-dual kernels against plain PyTorch restatements, the
+conditioned rollout against the oracle, and whole updates against (a) the golden vectors the REFERENCE's classes
+produced (tests/golden/mt_*.npz) and (b) the CPU oracle's gradients on the same seeded batches and noise.
+Tolerances as in tests/test_update_gpu.py (north_star: per-step losses within 1e-3 relative)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import repo_oracle as ro
+from tests.test_update_gpu import Env, Logger, dev_batch, dev_noise
+from tests.util import l2err, log, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+class MtEnv(Env):
+    def __init__(self, A, C):
+        super().__init__(A)
+        self.num_tasks = C
+
+
+def make_mt(algo, L, B, H, A, C, seed=7, **over):
+    from repo_amd.algorithms.repo import MultitaskDreamer, MultitaskRePo
+    from repo_amd.common.utils import set_gpu_mode
+
+    set_gpu_mode(True)
+    cfg = fx.default_config(algo=algo, batch_size=B, chunk_size=L, horizon=H, share_repr=False, **over)
+    env = MtEnv(A, C)
+    agent = (MultitaskRePo if algo == "repo_multitask" else MultitaskDreamer)(cfg, env, env, Logger())
+    params = fx.make_params(A, seed, cond=C)
+    for mod in fx.MODULES:
+        agent._load_module(getattr(agent, mod), {k: torch.from_numpy(v) for k, v in params[mod].items()})
+    return agent, cfg
+
+
+def dev_tasks(L, B, C, seed):
+    t = fx.make_tasks(L, B, C, seed=seed)
+    return torch.from_numpy(t).cuda(), t
+
+
+@pytest.mark.parametrize("n,C,hw", [(5, 32, 31), (3, 64, 14), (7, 128, 6), (4, 256, 2), (6, 128, 5), (2, 64, 13), (3, 32, 30)])
+def test_film_fwd_bwd_match_torch(n, C, hw):
+    """repo_film_fwd / repo_film_bwd on every modulated plane size of the two conv stacks (encoder 31/14/6/2, decoder
+    5/13/30) against autograd, gamma / beta taken from the middle of a wider FiLM row as the stacks do."""
+    from repo_amd import ops
+
+    rs = np.random.RandomState(n * 1000 + C + hw)
+    ld, goff, boff = 2 * C + 24, 5, C + 19
+    y = torch.from_numpy(rs.standard_normal((n, C, hw, hw)).astype(np.float32)).cuda()
+    film = torch.from_numpy(rs.standard_normal((n, ld)).astype(np.float32) * 0.7).cuda()
+    up = torch.from_numpy(rs.standard_normal((n, C, hw, hw)).astype(np.float32)).cuda()
+    yd, fd = y.double().requires_grad_(True), film.double().requires_grad_(True)
+    g, b = fd[:, goff : goff + C], fd[:, boff : boff + C]
+    want = torch.relu((1 + g[..., None, None]) * yd + b[..., None, None])
+    want.backward(up.double())
+    h = ops.film_fwd(y, film, goff, boff)
+    assert relerr(h, want) < 1e-6
+    dfilm = torch.full_like(film, 7.0)   # only the two (n, C) blocks are written
+    dh = ops.relu_mask(up, h)
+    dy = ops.film_bwd(dh, y, film, goff, boff, dfilm)
+    assert relerr(dy, yd.grad) < 1e-6
+    assert relerr(dfilm[:, goff : goff + C], fd.grad[:, goff : goff + C]) < 2e-6
+    assert relerr(dfilm[:, boff : boff + C], fd.grad[:, boff : boff + C]) < 2e-6
+    mask = torch.ones_like(film, dtype=torch.bool)
+    mask[:, goff : goff + C] = False
+    mask[:, boff : boff + C] = False
+    assert bool((dfilm[mask] == 7.0).all())
+
+
+@pytest.mark.parametrize("rows,C", [(1, 1), (37, 3), (2450, 3), (500, 13)])
+def test_kl_balance_tasks_and_dual_step_match_torch(rows, C):
+    """repo_kl_balance_tasks + repo_dual_step_tasks against repo_mt.py:75-99 written with autograd + torch.optim.Adam."""
+    from repo_amd import ops
+
+    S = 30
+    rs = np.random.RandomState(rows + C)
+    f = lambda *s: torch.from_numpy(rs.standard_normal(s).astype(np.float32))  # noqa: E731
+    pm, qm = f(rows, S), f(rows, S)
+    ps, qs = f(rows, S).abs() + 0.2, f(rows, S).abs() + 0.2
+    tasks = torch.from_numpy(np.eye(C, dtype=np.float32)[rs.randint(0, C, rows)])
+    lb0 = torch.from_numpy(rs.uniform(-3, -1, C).astype(np.float32))
+    alpha, target, scale = 5 / 6, 0.7, 1.0 / rows
+    P = [t.double().requires_grad_(True) for t in (pm, ps, qm, qs)]
+    lb = lb0.double().requires_grad_(True)
+    kl_prior = ro.normal_kl(P[2].detach(), P[3].detach(), P[0], P[1]).sum(1)
+    kl_post = ro.normal_kl(P[2], P[3], P[0].detach(), P[1].detach()).sum(1)
+    kl_div = alpha * kl_prior + (1 - alpha) * kl_post
+    viol = kl_div - target
+    lbr = tasks.double() @ lb
+    kl_loss = (lbr.exp().detach() * viol).mean()
+    kl_loss.backward()
+    beta_loss = -(lbr * viol.detach()).mean()
+    opt = torch.optim.Adam([lb], lr=1e-2)
+    opt.zero_grad()
+    beta_loss.backward()
+    lb_grad = lb.grad.clone()
+    opt.step()
+    dlb = lb0.cuda().clone()
+    sums, g = ops.kl_balance_tasks(pm.cuda(), ps.cuda(), qm.cuda(), qs.cuda(), alpha, dlb, tasks.cuda(), target, scale)
+    for got, want in zip(g, P):
+        assert relerr(got, want.grad) < 2e-5
+    m, v = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    out = ops.dual_step_tasks(dlb, m, v, sums, rows, 1e-2, (0.9, 0.999), 1e-8, 1).cpu().double()
+    assert abs(out[0] - kl_div.mean().item()) < 1e-5 * abs(kl_div.mean().item()) + 1e-7
+    assert abs(out[1] - kl_loss.item()) < 2e-5 * abs(kl_loss.item()) + 1e-7
+    assert abs(out[2] - beta_loss.item()) < 2e-5 * abs(beta_loss.item()) + 1e-6
+    # tasks without a row in the batch take a zero gradient: Adam leaves them where they were
+    touched = lb_grad != 0
+    np.testing.assert_allclose(dlb.cpu().double().numpy(), lb.detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out[3:].numpy(), lb.detach().exp().numpy(), rtol=1e-5)
+    assert bool((dlb.cpu()[~touched] == lb0[~touched]).all())
+
+
+def test_conditioned_rollout_matches_oracle():
+    """repo_rssm_imagine_fwd / _bwd with cond (ConditionalTransitionModel.imagine + ConditionalActorModel,
+    models/rssm.py:221-249): every saved tensor against the oracle's conditioned rollout, the actor-output gradient and
+    the start-state gradient against autograd through it."""
+    from repo_amd import ops
+
+    A, C, D, S, Hm, N = 6, 3, 200, 30, 4, 37
+    P = fx.make_params(A, 7, cond=C)
+    rp = {k: torch.from_numpy(v).requires_grad_(False) for k, v in P["transition_model"].items()}
+    ap = {k: torch.from_numpy(v).requires_grad_(True) for k, v in P["actor_model"].items()}
+    rs = np.random.RandomState(0)
+    f = lambda *s: torch.from_numpy(rs.standard_normal(s).astype(np.float32))  # noqa: E731
+    b0, s0 = (f(N, D) * 0.3).requires_grad_(True), f(N, S).requires_grad_(True)
+    cond = torch.from_numpy(np.eye(C, dtype=np.float32)[rs.randint(0, C, N)])
+    ea, ep = f(Hm, N, A), f(Hm, N, S)
+    ib, ist, im, isd = ro.cond_imagine(rp, ap, b0, s0, cond, Hm + 1, ea, ep)
+    up_f, up_m, up_s = f(Hm, N, D + S), f(Hm, N, S), f(Hm, N, S)
+    loss = (torch.cat([ib, ist], 2) * up_f).sum() + (im * up_m).sum() + (isd * up_s).sum()
+    loss.backward()
+    cu = lambda d: [t.detach().cuda() for t in d.values()]  # noqa: E731
+    sv = ops.rssm_imagine_fwd(cu(rp), cu(ap), b0.detach().cuda(), s0.detach().cuda(), ea.cuda(), ep.cuda(),
+                              cond=cond.cuda())
+    assert sv.xsa.shape == (Hm * N, S + A + C)
+    assert relerr(sv.featx[1:, :, :D], ib) < 2e-5 and relerr(sv.featx[1:, :, D:], ist) < 2e-5
+    assert relerr(sv.prior_mean, im) < 2e-5 and relerr(sv.prior_std, isd) < 2e-5
+    assert torch.equal(sv.xsa.view(Hm, N, -1)[:, :, S + A :], cond.cuda().expand(Hm, N, C))
+    d_araw, dfeat0 = ops.rssm_imagine_bwd(cu(rp), sv, up_f.cuda(), dprior_mean=up_m.cuda(), dprior_std=up_s.cuda(),
+                                          want_dfeat0=True)
+    assert l2err(dfeat0[:, :D], b0.grad) < 2e-5 and l2err(dfeat0[:, D:], s0.grad) < 2e-5
+    # actor gradients: finish with the trunk backward over [belief | state | cond] rows
+    F_ = D + S
+    xw = torch.empty(Hm * N, F_ + C).cuda()
+    xw[:, :F_] = sv.featx[:Hm].reshape(Hm * N, F_)
+    xw.view(Hm, N, F_ + C)[:, :, F_:] = cond.cuda()
+    ga = [torch.zeros_like(t) for t in cu(ap)]
+    ops.mlp_bwd(cu(ap), xw, [sv.a_hidden[l] for l in range(sv.a_hidden.shape[0])], d_araw, dparams=ga, dx=None)
+    for got, (name, want) in zip(ga, ap.items()):
+        assert l2err(got, want.grad) < 5e-5, name
+
+
+@pytest.mark.parametrize("fname,algo", [("mt_dreamer_tiny.npz", "dreamer_multitask"), ("mt_repo_tiny.npz", "repo_multitask")])
+def test_mt_update_matches_reference_goldens(golden_dir, fname, algo):
+    g = np.load(os.path.join(golden_dir, fname))
+    L, B, H, A, n_updates, C = (int(x) for x in g["meta"])
+    init_beta, target_kl, beta_lr = (float(x) for x in g["cfg"])
+    agent, cfg = make_mt(algo, L, B, H, A, C, init_beta=init_beta, target_kl=target_kl, beta_lr=beta_lr)
+    keys = [str(k) for k in g["scalar_keys"]]
+    for u in range(n_updates):
+        batch, _ = dev_batch(L, B, A, 11 + u, u8=(u % 2 == 0))
+        tasks, _ = dev_tasks(L, B, C, 11 + u)
+        agent.noise_source, _ = dev_noise(L, B, H, A, 101 + u)
+        beliefs, post = agent.train_dynamics(tasks, batch[0], batch[1], batch[2], 1.0 - batch[3])
+        agent.train_actor_critic(tasks[1:].flatten(0, 1), beliefs.flatten(0, 1), post.flatten(0, 1))
+        scal = agent.last_scalars
+        assert sorted(scal) == keys, (sorted(scal), keys)
+        atol = 1e-4 if u == 0 else 2e-3
+        np.testing.assert_allclose(beliefs.cpu().numpy(), g[f"u{u}/beliefs"], rtol=1e-3, atol=atol)
+        np.testing.assert_allclose(post.cpu().numpy(), g[f"u{u}/posterior_states"], rtol=1e-3, atol=atol)
+        for k, w in zip(keys, g[f"u{u}/scalars"]):
+            r = abs(scal[k] - w) / (abs(w) + 1e-12)
+            log(f"[{fname}] update {u} {k}: got {scal[k]:.7g} ref {w:.7g} rel {r:.2e}")
+            assert r < 1e-3, (fname, u, k, scal[k], w)
+        if algo == "repo_multitask":
+            np.testing.assert_allclose(agent.log_beta.cpu().numpy(), g[f"u{u}/log_beta"], rtol=0, atol=1e-5)
+        gn = agent.last_grad_norms
+        for name, w in zip(("model", "actor", "value"), g[f"u{u}/total_norms"]):
+            assert abs(gn[name] - w) < 2e-3 * w, (name, gn[name], w)
+    torch.cuda.synchronize()
+    sums = {f"{m}.{k}": float(v.double().sum()) for m in fx.MODULES for k, v in getattr(agent, m).state_dict().items()}
+    abss = {f"{m}.{k}": float(v.double().abs().sum()) for m in fx.MODULES for k, v in getattr(agent, m).state_dict().items()}
+    for n, s_, a_ in zip((str(n) for n in g["param_names"]), g["param_sums"], g["param_abssums"]):
+        assert abs(abss[n] - a_) <= 1e-3 * abs(a_) + 1e-7, (n, abss[n], a_)
+        assert abs(sums[n] - s_) <= 1e-3 * abs(a_) + 1e-7, (n, sums[n], s_)
+
+
+@pytest.mark.parametrize("algo", ["dreamer_multitask", "repo_multitask"])
+def test_mt_update_matches_oracle_grads(algo):
+    """Flat pre-clip gradients of the three optimisers against the oracle's autograd, per module too (the FiLM layers'
+    and the condition columns' gradients vanish in the flat norm), with the KL term active."""
+    L, B, H, A, C = 9, 5, 5, 6, 3
+    over = dict(init_beta=0.05, target_kl=0.3, beta_lr=1e-2, free_nats=0.1)
+    agent, cfg = make_mt(algo, L, B, H, A, C, **over)
+    oracle = ro.OracleMultitask(cfg, A, C, seed=7)
+    for u in range(2):
+        batch, host = dev_batch(L, B, A, 60 + u, u8=(u == 0))
+        tasks, htasks = dev_tasks(L, B, C, 60 + u)
+        agent.noise_source, nz = dev_noise(L, B, H, A, 160 + u)
+        snap = {}
+        for name in ("model", "actor", "value"):
+            opt = getattr(agent, f"{name}_optimizer")
+            orig = opt.clip_and_step
+
+            def hooked(norm, opt=opt, orig=orig, name=name):
+                snap[name] = opt.grad.clone()
+                orig(norm)
+
+            opt.clip_and_step = hooked
+        agent.update((tasks, *batch))
+        for name in ("model", "actor", "value"):
+            del getattr(agent, f"{name}_optimizer").clip_and_step
+        got = dict(agent.last_scalars)
+        _, _, want = oracle.update(htasks, *host, nz)
+        for k, w in want.items():
+            assert abs(got[k] - w) <= 1e-3 * abs(w) + 1e-7, (u, k, got[k], w)
+        for name, oparams, ograds in (("model", oracle.model_params, oracle.last["model_grads"]),
+                                      ("actor", oracle.actor_params, oracle.last["actor_grads"]),
+                                      ("value", oracle.value_params, oracle.last["value_grads"])):
+            opt = getattr(agent, f"{name}_optimizer")
+            flat = torch.zeros(opt.numel)
+            for o, p, gr in zip(opt.offsets, opt.params, ograds):
+                assert tuple(gr.shape) == tuple(p.shape)
+                flat[o : o + p.numel()] = gr.reshape(-1)
+            e = ((snap[name].cpu() - flat).norm() / flat.norm()).item()
+            log(f"[oracle {algo}] update {u} flat grad {name}: l2 rel {e:.2e}")
+            assert e < 1e-3, (name, e)
+            for o, p, gr, q in zip(opt.offsets, opt.params, ograds, oparams):
+                a = snap[name][o : o + p.numel()].cpu()
+                em = ((a - gr.reshape(-1)).norm() / (gr.norm() + 1e-12)).item()
+                assert em < 5e-3, (name, tuple(p.shape), em)
+        if algo == "repo_multitask":
+            np.testing.assert_allclose(agent.log_beta.cpu().numpy(), oracle.log_beta.detach().numpy(), atol=1e-5)
+
+
+def test_mt_full_size_b50_matches_oracle_scalars():
+    """MultitaskRePo at the headline batch shape (B=50, L=50, H=15, A=6, 3 tasks; `bench.py --config mt`): one update
+    against the CPU oracle -- scalars within 1e-3, pre-clip gradient norms within 2e-3."""
+    L, B, H, A, C = 50, 50, 15, 6, 3
+    agent, cfg = make_mt("repo_multitask", L, B, H, A, C)
+    oracle = ro.OracleMultitask(cfg, A, C, seed=7)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    batch, host = dev_batch(L, B, A, 2468)
+    tasks, htasks = dev_tasks(L, B, C, 2468)
+    agent.noise_source, nz = dev_noise(L, B, H, A, 99)
+    agent.update((tasks, *batch))
+    got = dict(agent.last_scalars)
+    want = oracle.update(htasks, *host, nz)[2]
+    for k, w in want.items():
+        r = abs(got[k] - w) / (abs(w) + 1e-12)
+        log(f"[mt B=50] {k}: got {got[k]:.7g} oracle {w:.7g} rel {r:.2e}")
+        assert r < 1e-3, (k, got[k], w)
+    for name in ("model", "actor", "value"):
+        w = oracle.last[f"{name}_total_norm"]
+        assert abs(agent.last_grad_norms[name] - w) < 2e-3 * w, (name, agent.last_grad_norms[name], w)
+
+
+class FakeMtEnv:
+    """Three tasks, episodes of 7 steps, random frames; the reference's MultitaskEnv surface (environments/mt_env.py)."""
+
+    def __init__(self, A, seed=0):
+        self.observation_space = Env(A).observation_space
+        self.action_space = type("S", (), {"shape": (A,), "sample": lambda s: np.random.uniform(-1, 1, A).astype(np.float32)})()
+        self._tasks = ["walk", "run", "stand"]
+        self._ind, self._t, self.rs = None, 0, np.random.RandomState(seed)
+
+    num_tasks = 3
+
+    @property
+    def task(self):
+        return self._tasks[self._ind]
+
+    @property
+    def task_one_hot(self):
+        v = np.zeros(3, dtype=np.float32)
+        v[self._ind] = 1
+        return v
+
+    def sample_task(self, round_robin=False):
+        nxt = 0 if self._ind is None else (self._ind + 1) % 3
+        return self._tasks[nxt if round_robin else self.rs.randint(3)]
+
+    def reset(self, task=None):
+        self._ind = self._tasks.index(task if task is not None else self.sample_task())
+        self._t = 0
+        return self.rs.randint(0, 256, (3, 64, 64)).astype(np.uint8)
+
+    def step(self, action):
+        assert np.asarray(action).shape == (6,)
+        self._t += 1
+        return self.rs.randint(0, 256, (3, 64, 64)).astype(np.uint8), float(self._ind), self._t >= 7, {"success": self._ind == 1}
+
+
+def test_mt_train_eval_loops_buffer_and_checkpoint(tmp_path):
+    """train() / eval_agent() end to end on a fake multitask environment: seed data with task labels, batches from the
+    HBM mirror of the five-field ring equal to host sampling, per-task logging in the reference's keys, acting path
+    (HIP graph) equal to the eager modules, checkpoint round trip incl. the per-task log_beta vector."""
+    from repo_amd.algorithms.repo import MultitaskRePo
+    from repo_amd.common.utils import set_gpu_mode
+
+    set_gpu_mode(True)
+    A = 6
+    cfg = fx.default_config(algo="repo_multitask", batch_size=3, chunk_size=5, horizon=4, share_repr=False, prefill=30,
+                            num_steps=16, train_every=8, eval_every=16, checkpoint_every=16, log_every=8, train_steps=2,
+                            replay_size=200, action_noise=0.3)
+    logger = Logger()
+    logger.dir = str(tmp_path)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    agent = MultitaskRePo(cfg, FakeMtEnv(A, 1), FakeMtEnv(A, 2), logger)
+    agent.train()
+    assert len(agent.buffer) >= 30 + 16
+    assert set(np.unique(agent.buffer.tasks[: len(agent.buffer)].sum(1))) == {1.0}
+    for k in ("train/beta_0", "train/beta_2", "train/kl_div", "train/obs_loss", "train/actor_loss"):
+        assert k in logger.kv and math.isfinite(logger.kv[k]), k
+    assert any(k.startswith("test/return_") for k in logger.kv) and any(k.startswith("train/return_") for k in logger.kv)
+    assert sum(k.startswith("test/video_") for k in logger.kv) == 3
+    # device-mirror batches == host sampling, task labels included
+    np.random.seed(5)
+    want = agent.buffer.sample(3, 5)
+    np.random.seed(5)
+    got = agent.buffer.sample_to_device(3, 5, agent.device)
+    torch.cuda.synchronize()
+    assert len(got) == 5 and got[0].shape == (5, 3, 3)
+    for g_, w in zip(got, want):
+        assert np.array_equal(g_.cpu().numpy(), w.astype(g_.cpu().numpy().dtype))
+    # acting path: graph replay == eager modules
+    b, s, a = agent.init_latent_and_action()
+    frame = torch.rand(1, 3, 64, 64, device="cuda") * 2 - 1
+    task = torch.tensor([[0.0, 1.0, 0.0]], device="cuda")
+    out_g = agent.update_latent_and_select_action(b, s, a, frame, task, False)
+    with torch.no_grad():
+        emb = agent.encoder(frame, task)
+        outs = agent.transition_model.observe(b, s, a.unsqueeze(0), task.unsqueeze(0), emb.unsqueeze(0))
+    assert out_g[0].shape == (1, 200) and out_g[2].shape == (1, A)
+    assert torch.isfinite(out_g[2]).all() and outs[0].shape == (1, 1, 200)
+    # checkpoint round trip
+    sd = agent.get_param_dict()
+    assert sd["log_beta"].shape == (3,) and sd["log_beta"].requires_grad
+    assert "film.weight" in sd["encoder"] and sd["transition_model"]["fc_embed_state_action.weight"].shape == (200, 39)
+    torch.save(sd, os.path.join(tmp_path, "models.pt"))
+    other = MultitaskRePo(cfg, FakeMtEnv(A, 1), FakeMtEnv(A, 2), Logger())
+    other.load_param_dict(torch.load(os.path.join(tmp_path, "models.pt"), map_location="cuda", weights_only=False))
+    assert torch.equal(other.log_beta, agent.log_beta) and other.beta_optimizer.step_count == agent.beta_optimizer.step_count
+    assert torch.equal(other.model_optimizer.flat, agent.model_optimizer.flat)
+    assert torch.equal(other.model_optimizer.exp_avg_sq, agent.model_optimizer.exp_avg_sq)
