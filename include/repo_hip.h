@@ -67,6 +67,10 @@ int repo_debug_poison_lds(hipStream_t stream);
  * restores it).  Process-wide and meant for tests only (tests/test_rssm_gpu.py::test_scan_timeout_reaches_the_host
  * sets 0 to see the status word of repo_rssm_observe_fwd / _bwd raised); returns the previous value. */
 int repo_debug_scan_spin_limit(int polls);
+/* Test aid: enable (default) / disable the bf16x6 dense engine (csrc/bgemm.h: big products of repo_gemm /
+ * repo_gemm_wgrad formed as six exact bf16 partial products per fp32 multiply on the bf16 matrix pipe -- same inputs,
+ * outputs and accuracy as the fp32-MFMA engines); process-wide, for A/B runs; returns the previous setting. */
+int repo_debug_bgemm(int enable);
 
 /* ------------------------------------------------------------------ reparameterisation noise
  * The reference draws its noise from torch's global generator (torch.randn_like in models/rssm.py:49,61-63;

@@ -2,10 +2,16 @@
 // split-K weight gradient (repo_gemm_wgrad).
 #include <stdlib.h>
 
+#include <atomic>
+
+#include "bgemm.h"
 #include "igemm.h"
 #include "vgemm.h"
 
 namespace repo {
+
+// Test aid (repo_debug_bgemm): 0 keeps every product on the fp32-MFMA tile engines, for A/B runs in one process.
+static std::atomic<int> g_bgemm_enabled{1};
 
 template <bool TA, bool TB>
 struct GemmOp {
@@ -456,6 +462,16 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
     REPO_CHECK_LAUNCH();
     return REPO_OK;
   }
+  // big products: the bf16x6 engine (bgemm.h): fp32-accurate at 6/16 of the fp32 MFMA's time per k
+  if (g_bgemm_enabled.load(std::memory_order_relaxed) && bgemm_ok(M, N, K, !transa, lda, transb != 0, ldb, A, B)) {
+    BgArgs a{Dense2D{A, 4u * (unsigned)(transa ? (K - 1) * lda + M : (M - 1) * lda + K), (int)lda},
+             Dense2D{B, 4u * (unsigned)(transb ? (N - 1) * ldb + K : (K - 1) * ldb + N), (int)ldb},
+             bias, aux, C, (int)ldc, (int)ldaux, (int)bias_div, (int)M, (int)N, (int)K, epi, accumulate};
+    if (!transa && transb) return bgemm_dispatch<true, true>(a, stream);
+    if (!transa && !transb) return bgemm_dispatch<true, false>(a, stream);
+    if (transa && !transb) return bgemm_dispatch<false, false>(a, stream);
+    return bgemm_dispatch<false, true>(a, stream);
+  }
   // vector-load engine whenever the k-contiguous operands (A if !transa, B if transb) have K % VW == 0
   const bool kvec = !transa || transb;
   const int vw = (!kvec || K % 4 == 0) ? 4 : (K % 2 == 0 ? 2 : 0);
@@ -494,6 +510,8 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
 #undef REPO_GEMM_CASE
 }
 
+extern "C" int repo_debug_bgemm(int enable) { return g_bgemm_enabled.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
+
 extern "C" size_t repo_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int splits = wgrad_splits(M, N, K);
@@ -519,6 +537,13 @@ extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY,
       if (db) (void)hipMemsetAsync(db, 0, N * sizeof(float), stream);
     }
     return REPO_OK;
+  }
+  // a big weight gradient without a bias column (the decoder's 1024 x 3200 first transposed conv): ONE product on the
+  // bf16x6 engine, dW[n][k] = sum_rows dY[row][n] X[row][k] with both operands row-contiguous -- no split-K slabs
+  if (!db && g_bgemm_enabled.load(std::memory_order_relaxed) && bgemm_ok(N, K, M, false, lddy, false, ldx, dY, X)) {
+    BgArgs a{Dense2D{dY, 4u * (unsigned)((M - 1) * lddy + N), (int)lddy}, Dense2D{X, 4u * (unsigned)((M - 1) * ldx + K), (int)ldx},
+             nullptr, nullptr, dW, (int)lddw, 0, 1, (int)N, (int)K, (int)M, REPO_EPI_NONE, accumulate};
+    return bgemm_dispatch<false, false>(a, stream);
   }
   const int splits = wgrad_splits(M, N, K);
   REPO_REQUIRE(ws && ws_bytes >= repo_gemm_wgrad_workspace_bytes(M, N, K), REPO_E_WS_TOO_SMALL);

@@ -76,6 +76,77 @@ def test_gemm_strided_and_epilogues(ops):
     assert relerr(got, want) < TOL
 
 
+BG_SHAPES = [
+    # (ta, tb, M, N, K): the decoder's three big products and ragged variants of each operand layout
+    (False, False, 2450, 3200, 1024),   # conv1 forward: h1 = h0 @ W1            (256 x 128 tiles)
+    (False, True, 2450, 1024, 3200),    # conv1 data gradient: dh0 = d1 @ W1^T   (128 x 128 tiles, K 32 per stage)
+    (True, False, 1024, 3200, 2450),    # conv1 weight gradient through repo_gemm's layout: A[k][m], B[k][n]
+    (False, True, 1301, 1932, 1001),    # nothing divides anything: M, N ragged in the last tiles, K % 16 = 9, K % 4 = 1
+    (False, False, 1300, 1940, 130),     # shortest K the engine takes (two register sets, 5 stages of 32)
+    (True, True, 1284, 1937, 777),       # A[k][m] with B[n][k]
+    (True, False, 1280, 2048, 16),      # below the engine's K: stays on the fp32 tiles (dispatch boundary)
+]
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", BG_SHAPES)
+def test_bgemm_matches_fp64_and_the_fp32_engine(ops, ta, tb, M, N, K):
+    """The bf16x6 dense engine (csrc/bgemm.h: six exact bf16 partial products per fp32 multiply, fp32 accumulation) on
+    every operand layout, ragged tiles and K tails, with bias / bias_div / ReLU / accumulate, against fp64 -- and against
+    the fp32-MFMA tile engine on the SAME operands (repo_debug_bgemm(0)): its error is not allowed to exceed that
+    engine's by more than 25 % (measured: equal or smaller; both are set by the fp32 accumulation over K)."""
+    from repo_amd._lib import lib
+
+    rs = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rnd(rs, K, M) if ta else rnd(rs, M, K)
+    B = rnd(rs, N, K) if tb else rnd(rs, K, N)
+    A[::7] *= 40.0      # a wide dynamic range inside every dot product
+    bias = rnd(rs, (N + 24) // 25)
+    opA, opB = (A.double().t() if ta else A.double()), (B.double().t() if tb else B.double())
+    pre = opA @ opB + bias.double().repeat_interleave(25)[:N]
+    mag = opA.abs() @ opB.abs()
+    # k-contiguous operands as column slices of wider buffers: the leading dimension stays a multiple of 4 (what the
+    # engine asks for) while K itself is ragged
+    def widen(t):
+        wide = torch.zeros(t.shape[0], (t.shape[1] + 7) // 4 * 4)
+        wide[:, : t.shape[1]] = t
+        return dev(wide)[:, : t.shape[1]]
+
+    dA = dev(A) if ta else widen(A)
+    dB = widen(B) if tb else dev(B)
+    dbias = dev(bias)
+    errs = {}
+    for engine in (1, 0):
+        prev = lib().repo_debug_bgemm(engine)
+        try:
+            got = ops.gemm(dA, dB, ta, tb, bias=dbias, bias_div=25, epi=ops.EPI_RELU)
+            acc = torch.full((M, N), 0.5).cuda()
+            ops.gemm(dA, dB, ta, tb, out=acc, accumulate=True)
+        finally:
+            lib().repo_debug_bgemm(prev)
+        assert relerr(got, F.relu(pre)) < TOL
+        assert relerr(acc, opA @ opB + 0.5) < TOL
+        errs[engine] = float(((acc.double().cpu() - (opA @ opB + 0.5)).abs() / mag).max())
+    log(f"bgemm ta={ta} tb={tb} {M}x{N}x{K}: max |err| / sum|a||b|  bf16x6 {errs[1]:.2e}  fp32 MFMA {errs[0]:.2e}")
+    assert errs[1] <= 1.25 * errs[0] + 1e-9, errs
+
+
+def test_bgemm_weight_gradient_without_slabs(ops):
+    """repo_gemm_wgrad without a bias column at the decoder conv1's size takes the bf16x6 engine (one product, no
+    split-K slabs): value, accumulate into a strided destination, and bit-reproducibility."""
+    rs = np.random.RandomState(9)
+    M, N, K = 2450, 1024, 3200
+    dY, X = rnd(rs, M, N), rnd(rs, M, K)
+    want = dY.double().t() @ X.double()
+    dW, _ = ops.gemm_wgrad(dev(dY), dev(X), want_bias=False)
+    assert relerr(dW, want) < TOL
+    wide = torch.full((N, K + 8), 2.0).cuda()
+    ops.gemm_wgrad(dev(dY), dev(X), dW=wide[:, 4 : 4 + K], db=None, accumulate=True, want_bias=False)
+    assert relerr(wide[:, 4 : 4 + K], want + 2) < TOL
+    assert float((wide[:, :4] - 2).abs().max()) == 0 and float((wide[:, 4 + K :] - 2).abs().max()) == 0
+    again, _ = ops.gemm_wgrad(dev(dY), dev(X), want_bias=False)
+    assert torch.equal(again, dW)
+
+
 @pytest.mark.parametrize("M,N,K", [(2450, 200, 230), (50, 60, 200), (3000, 200, 1024), (7, 12, 200), (343, 1, 200)])
 def test_gemm_wgrad(ops, M, N, K):
     rs = np.random.RandomState(M + N + K)

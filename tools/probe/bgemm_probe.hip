@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #define CK(x)                                                                   \
@@ -50,6 +51,9 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& p1, unsigne
   p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
 }
 
+#ifndef SCHED
+#define SCHED 4
+#endif
 constexpr int BM = 256, BN = 128, BK = 16, NT = 512;
 constexpr int ROWB = 48;                       // bytes per LDS row: 16 bf16 + 16 B pad (conflict-free ds_read_b128)
 constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;
@@ -92,16 +96,17 @@ __global__ __launch_bounds__(NT) void bgemm_nt_kernel(Args p) {
     blds = 3 * A_PLANE + row * ROWB + kq * 8;
   }
   f32x4 ga[2], gb;
-  auto gload = [&](int k0) __attribute__((always_inline)) {
-    // a k-quad past K reads zeros: the buffer's range check covers the LAST row only, so guard explicitly
+  // TAIL = false: k0 + BK <= K is known (the main loop): no masks, no branches -- the loop body stays ONE basic block
+  auto gload = [&](int k0, auto tail) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail)::value;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const bool ok = k0 + 4 * ((tid + j * NT) & 3) < p.K;
+      const bool ok = !TAIL || k0 + 4 * ((tid + j * NT) & 3) < p.K;
       ga[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? aoff[j] + 4u * k0 : 0x80000000u, 0, 0));
     }
-    const bool ok = k0 + 4 * (tid & 3) < p.K;
+    const bool ok = !TAIL || k0 + 4 * (tid & 3) < p.K;
     gb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? boff + 4u * k0 : 0x80000000u, 0, 0));
-    if (k0 + BK > p.K) {  // the last stage: elements of a quad that straddles K belong to the next row
+    if (TAIL) {  // elements of a quad that straddles K belong to the next row
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -138,13 +143,18 @@ __global__ __launch_bounds__(NT) void bgemm_nt_kernel(Args p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nst = (p.K + BK - 1) / BK;
-  gload(0);
+  const std::true_type TAILY{};
+  const std::false_type TAILN{};
+  gload(0, TAILY);
   stage(lds);
+  if (nst > 1) gload(BK, TAILY);
   __syncthreads();
   const int afrag = (wm * 64 + li) * ROWB + lh * 16, bfrag = 3 * A_PLANE + (wn * 64 + li) * ROWB + lh * 16;
-  for (int s = 0; s < nst; ++s) {
+  // one stage: fragments of `cur`, then -- BETWEEN its MFMAs (a wave issues in order: after its 24 MFMAs it would
+  // otherwise run ~100 vector instructions with the matrix pipe idle) -- the split + LDS stores of the next stage and
+  // the global loads of the one after
+  auto body = [&](int s, auto more1, auto more2, auto tail) __attribute__((always_inline)) {
     char* cur = lds + (s & 1) * BUF;
-    if (s + 1 < nst) gload((s + 1) * BK);
     bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -153,6 +163,8 @@ __global__ __launch_bounds__(NT) void bgemm_nt_kernel(Args p) {
         fa[i][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * A_PLANE + afrag + i * 32 * ROWB);
         fb[i][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * B_PLANE + bfrag + i * 32 * ROWB);
       }
+    if (decltype(more1)::value) stage(lds + ((s + 1) & 1) * BUF);
+    if (decltype(more2)::value) gload((s + 2) * BK, tail);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -168,8 +180,24 @@ __global__ __launch_bounds__(NT) void bgemm_nt_kernel(Args p) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
         acc[i][j] = c;
       }
-    if (s + 1 < nst) stage(lds + ((s + 1) & 1) * BUF);
+#if SCHED
+    if (decltype(more1)::value) {
+#pragma unroll
+      for (int g = 0; g < 4 * TERMS; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, SCHED, 0);   // a few vector ALU instructions of the split
+        if (g % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS store
+      }
+    }
+#endif
     __syncthreads();
+  };
+  int s = 0;
+  for (; s + 3 < nst; ++s) body(s, TAILY, TAILY, TAILN);   // stage s + 2 <= nst - 2: a full stage
+  for (; s < nst; ++s) {
+    if (s + 2 < nst) body(s, TAILY, TAILY, TAILY);
+    else if (s + 1 < nst) body(s, TAILY, TAILN, TAILN);
+    else body(s, TAILN, TAILN, TAILN);
   }
   // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
