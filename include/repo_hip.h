@@ -71,6 +71,8 @@ int repo_debug_scan_spin_limit(int polls);
  * repo_gemm_wgrad formed as six exact bf16 partial products per fp32 multiply on the bf16 matrix pipe -- same inputs,
  * outputs and accuracy as the fp32-MFMA engines); process-wide, for A/B runs; returns the previous setting. */
 int repo_debug_bgemm(int enable);
+/* The same switch for the bf16x6 stride-2 "down" convolution kernel (csrc/bconv.h). */
+int repo_debug_bconv(int enable);
 
 /* ------------------------------------------------------------------ reparameterisation noise
  * The reference draws its noise from torch's global generator (torch.randn_like in models/rssm.py:49,61-63;
@@ -132,7 +134,10 @@ int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t ld
  * `small` is the pre-activation gradient of the transposed-conv layer below (decoder backward), that is that layer's
  * bias gradient, taken while the values are in registers instead of by a second pass over the tensor
  * (repo_channel_sum).  Needs ws >= repo_conv_down_workspace_bytes(layer, nimg) then (per-workgroup partial sums,
- * reduced in a fixed order: bit-reproducible). */
+ * reduced in a fixed order: bit-reproducible).
+ * ws also holds the weight pack of the bf16x6 kernel (csrc/bconv.h: the MFMA-bound layers with an even row pitch --
+ * 2, 3, 5 -- form their products as six exact bf16 partial products per fp32 multiply on the bf16 matrix pipe, same
+ * accuracy); a call without ws (or with too little) runs the fp32-MFMA kernel. */
 size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg);
 int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
                    const float* bias, float* small, int epi, const void* aux, float* dbias_small,

@@ -23,6 +23,9 @@
 #include "dconv.h"
 #include "uconv.h"
 #include "dconv_up.h"
+#include "bconv.h"
+
+#include <atomic>
 
 namespace repo {
 
@@ -425,11 +428,35 @@ template <> struct DLatTile<GEnc2> { using type = DTile<32, 128, 4, 1, 4>; };
 template <> struct DLatTile<GEnc3> { using type = DTile<32, 128, 8, 1, 4>; };
 template <> struct DLatTile<GEnc4> { using type = DTile<32, 128, 8, 1, 4>; };
 
+// The bf16x6 down kernel (bconv.h: fp32-accurate, six bf16 MFMAs per 16 k) for the MFMA-bound geometries with an even
+// big-row pitch; NoTile = the layer stays on the fp32-MFMA kernel (3-channel layers: bandwidth / epilogue bound; odd
+// pitches: the tap pairs are not dword-aligned).  Test aid repo_debug_bconv(0) keeps every layer on the fp32 kernel.
+struct NoBTile {};
+template <class G> struct BDownFor { using type = NoBTile; };
+template <> struct BDownFor<GDec3> { using type = BTile<64, 256, 2, 1, 4>; };
+template <> struct BDownFor<GEnc3> { using type = BTile<64, 256, 4, 1, 4>; };
+template <> struct BDownFor<GEnc4> { using type = BTile<64, 128, 4, 1, 2>; };
+template <class G> constexpr bool kBDown = !std::is_same<typename BDownFor<G>::type, NoBTile>::value;
+static std::atomic<int> g_bconv_enabled{1};
+
+template <class G>
+static bool bconv_down_on(int64_t nimg) {
+  if constexpr (kBDown<G>) return g_bconv_enabled.load(std::memory_order_relaxed) && nimg * (int64_t)G::PS > 512;
+  return false;
+}
+template <class G>
+static size_t bconv_pack_bytes() {
+  if constexpr (kBDown<G>) return (BPack<G, typename BDownFor<G>::type>::BYTES + 255) & ~(size_t)255;
+  return 0;
+}
+
 // pixel tiles of the direct conv's grid = rows of the channel-sum partials (repo_conv_down's dbias)
 template <class G>
 static long conv_down_tiles(int64_t nimg) {
   const long px = nimg * (long)G::PS;
-  const long bn = px <= 512 ? DLatTile<G>::type::BN : DTileFor<G>::Down::BN;
+  long bn = px <= 512 ? DLatTile<G>::type::BN : DTileFor<G>::Down::BN;
+  if constexpr (kBDown<G>)
+    if (bconv_down_on<G>(nimg)) bn = BDownFor<G>::type::BN;
   return (px + bn - 1) / bn;
 }
 
@@ -437,14 +464,36 @@ template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
                        const float* aux, float* dbias, int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
-  const long tiles = conv_down_tiles<G>(nimg);
-  if (dbias && (!ws || ws_bytes < (size_t)tiles * G::CS * sizeof(float))) return REPO_E_WS_TOO_SMALL;
+  // workspace: [weight pack of the bf16x6 kernel | channel-sum partials]; without room for the pack the layer runs
+  // on the fp32-MFMA kernel (ws stays optional for callers that want no dbias)
+  bool bf = false;
+  size_t pack_bytes = 0;
+  if constexpr (kBDown<G> && std::is_same<BigT, float>::value) {
+    pack_bytes = bconv_pack_bytes<G>();
+    bf = bconv_down_on<G>(nimg) && ws && ws_bytes >= pack_bytes + (dbias ? (size_t)conv_down_tiles<G>(nimg) * G::CS * sizeof(float) : 0);
+    if (!bf) pack_bytes = 0;
+  }
+  long tiles = conv_down_tiles<G>(nimg);
+  if constexpr (kBDown<G>)
+    if (!bf && bconv_down_on<G>(nimg)) {   // the pack did not fit: the fp32 kernel's grid
+      const long px = nimg * (long)G::PS;
+      tiles = (px + DTileFor<G>::Down::BN - 1) / DTileFor<G>::Down::BN;
+    }
+  if (dbias && (!ws || ws_bytes < pack_bytes + (size_t)tiles * G::CS * sizeof(float))) return REPO_E_WS_TOO_SMALL;
+  float* parts = dbias ? (float*)((char*)ws + pack_bytes) : nullptr;
   DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
-             (unsigned)(G::CS * G::CB * G::KK * sizeof(float)), dbias ? (float*)ws : nullptr};
-  const int rc = (nimg * (int64_t)G::PS <= 512) ? launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s)
-                                                : launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
+             (unsigned)(G::CS * G::CB * G::KK * sizeof(float)), parts};
+  int rc;
+  if constexpr (kBDown<G> && std::is_same<BigT, float>::value) {
+    if (bf) rc = launch_bconv_down<G, typename BDownFor<G>::type>(a, w, (char*)ws, s);
+    else rc = (nimg * (int64_t)G::PS <= 512) ? launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s)
+                                            : launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
+  } else {
+    rc = (nimg * (int64_t)G::PS <= 512) ? launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s)
+                                        : launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
+  }
   if (rc || !dbias) return rc;
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(G::CS, 4)), dim3(256), 0, s, (const float*)ws, (int)tiles,
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(G::CS, 4)), dim3(256), 0, s, (const float*)parts, (int)tiles,
                      (int)G::CS, dbias, accumulate_dbias);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
@@ -645,8 +694,11 @@ extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_
 
 extern "C" size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg) {
   if (nimg <= 0) return 0;
-  REPO_LAYER_SWITCH(layer, return ((size_t)conv_down_tiles<G>(nimg) * G::CS * sizeof(float)))
+  REPO_LAYER_SWITCH(layer, return ((bconv_down_on<G>(nimg) ? bconv_pack_bytes<G>() : 0) +
+                                   (size_t)conv_down_tiles<G>(nimg) * G::CS * sizeof(float)))
 }
+
+extern "C" int repo_debug_bconv(int enable) { return g_bconv_enabled.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" size_t repo_conv_up_workspace_bytes(int layer) {
   REPO_LAYER_SWITCH(layer, return (conv_up_ws_bytes<G>()))

@@ -97,6 +97,123 @@ struct DownArgs {
   float* chan_part;  // nullable: [pixel tiles][CS] sums of the written values per output channel (bias gradients)
 };
 
+// The epilogue of the stride-2 "down" kernels (dconv_down_kernel here, bconv_down_kernel in bconv.h): `acc` holds the
+// workgroup's BM x BN tile in the 32 x 32 MFMA layout (T::TM x T::TN tiles per wave, waves as T::WM x T::WN), `lds` is the
+// kernel's LDS (free by now; >= (NT / 64) * 32 * 36 + (NT / 64) * TM * 32 floats).
+template <class G, class T>
+__device__ __forceinline__ void dconv_down_epilogue(const DownArgs& p, float* lds, f32x16 (&acc)[T::TM][T::TN], int n0,
+                                                    int m0, int Ntot) {
+  constexpr int BM = T::BM, NT = T::NT, TM = T::TM, TN = T::TN;
+  constexpr int EP = 36;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / T::WN, wn = wid % T::WN;
+  const int li = lane & 31, lh = lane >> 5;
+  // ---- epilogue.  An accumulator tile has its pixel on the lane and 16 channel rows in registers: stored as it
+  // stands, that is 16 dword stores (+ 16 dword loads of the ReLU operand) of 128 contiguous bytes per half-wave,
+  // and the store ISSUE, not the bytes, set the pace (ablation on one box, round 3: the epilogue was 11 % of decoder
+  // conv3's data gradient, 40 % of the 3-channel layers').  Each wave therefore turns its tile through a private
+  // LDS strip (the K loop's buffers are free by now) so that a lane owns ONE channel and FOUR consecutive pixels:
+  // one 16-byte load of the ReLU operand, one 16-byte store (raw-buffer accesses need dword alignment only); a quad
+  // that runs over the end of an image or of the tensor falls back to dwords.
+  // (strip pitch EP = 36: 16-byte aligned rows, the quads of 8 consecutive channels on distinct banks)
+  __syncthreads();  // every wave is done with the last chunk's operands
+  float* strip = lds + wid * 32 * EP;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 4u * (unsigned)Ntot * G::CS);
+  // channel sums of what this workgroup writes (the bias gradient of the layer whose pre-activation gradient this
+  // is): a lane's quad, then the 8 lanes of a channel by shuffles, summed over the wave's pixel tiles in registers;
+  // the waves' rows meet in LDS and ONE thread per channel adds them in a fixed order -- no atomics, reproducible
+  float csum[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) csum[i][q4] = 0.f;
+  const __amdgpu_buffer_rsrc_t raux =
+      make_rsrc(p.aux ? p.aux : p.out, (p.epi == REPO_EPI_MUL_MASK4 ? 1u : 4u) * (unsigned)Ntot * G::CS);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + li] = acc[i][j][r];
+      __builtin_amdgcn_wave_barrier();
+      const int nb = n0 + (wn * TN + j) * 32, mt = m0 + (wm * TM + i) * 32;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int ml = pass * 8 + (lane >> 3), q = lane & 7;
+        const int m = mt + ml, n = nb + 4 * q;
+        f32x4 v = *reinterpret_cast<const f32x4*>(strip + ml * EP + 4 * q);
+        float qs = 0.f;  // this lane's contribution to its channel's sum
+        if (m < G::CS && n < Ntot) {
+          const float bv = p.bias ? p.bias[m] : 0.f;
+          const int img = n / G::PS, pix = n % G::PS;
+          const unsigned o = (unsigned)((img * G::CS + m) * G::PS + pix);
+          if (pix + 3 < G::PS && n + 3 < Ntot) {
+            f32x4 a4 = {1.f, 1.f, 1.f, 1.f};
+            if (p.epi == REPO_EPI_MUL_DRELU) {
+              a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, 4u * o, 0, 0));
+            } else if (p.epi == REPO_EPI_MUL_MASK4) {
+              // bits o .. o+3 of the quad mask: one byte when the quad is aligned (always, for PS % 4 == 0), else two
+              unsigned bits = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(raux, o >> 2, 0, 0) >> (o & 3);
+              if (o & 3) bits |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(raux, (o >> 2) + 1, 0, 0) << (4 - (o & 3));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) a4[e] = (bits >> e) & 1u ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = v[e] + bv;
+              if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
+              else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_MASK4) x = a4[e] > 0.f ? x : 0.f;
+              v[e] = x;
+            }
+            qs = (v[0] + v[1]) + (v[2] + v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rout, 4u * o, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ne = n + e;
+              if (ne < Ntot) {
+                const int oe = ((ne / G::PS) * G::CS + m) * G::PS + ne % G::PS;
+                float x = v[e] + bv;
+                if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
+                else if (p.epi == REPO_EPI_MUL_DRELU) x = p.aux[oe] > 0.f ? x : 0.f;
+                else if (p.epi == REPO_EPI_MUL_MASK4)
+                  x = (reinterpret_cast<const unsigned char*>(p.aux)[oe >> 2] >> (oe & 3)) & 1 ? x : 0.f;
+                p.out[oe] = x;
+                qs += x;
+              }
+            }
+          }
+        }
+        if (p.chan_part) {  // wave-uniform
+          qs += __shfl_xor(qs, 1, 64);
+          qs += __shfl_xor(qs, 2, 64);
+          qs += __shfl_xor(qs, 4, 64);
+          csum[i][pass] += qs;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  if (p.chan_part) {
+    float* red = lds + (NT / 64) * 32 * EP;  // [wave][TM * 32]
+    if ((lane & 7) == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) red[wid * (TM * 32) + i * 32 + pass * 8 + (lane >> 3)] = csum[i][pass];
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < G::CS) {
+      const int wmc = tid / (TM * 32), c = tid % (TM * 32);
+      float t = 0.f;
+#pragma unroll
+      for (int x = 0; x < T::WN; ++x) t += red[(wmc * T::WN + x) * (TM * 32) + c];
+      p.chan_part[(size_t)blockIdx.x * G::CS + m0 + tid] = t;
+    }
+  }
+}
+
 template <class G, class BigT, class T>
 __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
   constexpr int BM = T::BM, BN = T::BN, CK = T::CK, NT = T::NT, TM = T::TM, TN = T::TN;
@@ -260,108 +377,7 @@ __global__ __launch_bounds__(T::NT) void dconv_down_kernel(DownArgs p) {
     }
   }
 
-  // ---- epilogue.  An accumulator tile has its pixel on the lane and 16 channel rows in registers: stored as it
-  // stands, that is 16 dword stores (+ 16 dword loads of the ReLU operand) of 128 contiguous bytes per half-wave,
-  // and the store ISSUE, not the bytes, set the pace (ablation on one box, round 3: the epilogue was 11 % of decoder
-  // conv3's data gradient, 40 % of the 3-channel layers').  Each wave therefore turns its tile through a private
-  // LDS strip (the K loop's buffers are free by now) so that a lane owns ONE channel and FOUR consecutive pixels:
-  // one 16-byte load of the ReLU operand, one 16-byte store (raw-buffer accesses need dword alignment only); a quad
-  // that runs over the end of an image or of the tensor falls back to dwords.
-  // (strip pitch EP = 36: 16-byte aligned rows, the quads of 8 consecutive channels on distinct banks)
-  __syncthreads();  // every wave is done with the last chunk's operands
-  float* strip = lds + wid * 32 * EP;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 4u * (unsigned)Ntot * G::CS);
-  // channel sums of what this workgroup writes (the bias gradient of the layer whose pre-activation gradient this
-  // is): a lane's quad, then the 8 lanes of a channel by shuffles, summed over the wave's pixel tiles in registers;
-  // the waves' rows meet in LDS and ONE thread per channel adds them in a fixed order -- no atomics, reproducible
-  float csum[TM][4];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) csum[i][q4] = 0.f;
-  const __amdgpu_buffer_rsrc_t raux =
-      make_rsrc(p.aux ? p.aux : p.out, (p.epi == REPO_EPI_MUL_MASK4 ? 1u : 4u) * (unsigned)Ntot * G::CS);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + li] = acc[i][j][r];
-      __builtin_amdgcn_wave_barrier();
-      const int nb = n0 + (wn * TN + j) * 32, mt = m0 + (wm * TM + i) * 32;
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int ml = pass * 8 + (lane >> 3), q = lane & 7;
-        const int m = mt + ml, n = nb + 4 * q;
-        f32x4 v = *reinterpret_cast<const f32x4*>(strip + ml * EP + 4 * q);
-        float qs = 0.f;  // this lane's contribution to its channel's sum
-        if (m < G::CS && n < Ntot) {
-          const float bv = p.bias ? p.bias[m] : 0.f;
-          const int img = n / G::PS, pix = n % G::PS;
-          const unsigned o = (unsigned)((img * G::CS + m) * G::PS + pix);
-          if (pix + 3 < G::PS && n + 3 < Ntot) {
-            f32x4 a4 = {1.f, 1.f, 1.f, 1.f};
-            if (p.epi == REPO_EPI_MUL_DRELU) {
-              a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, 4u * o, 0, 0));
-            } else if (p.epi == REPO_EPI_MUL_MASK4) {
-              // bits o .. o+3 of the quad mask: one byte when the quad is aligned (always, for PS % 4 == 0), else two
-              unsigned bits = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(raux, o >> 2, 0, 0) >> (o & 3);
-              if (o & 3) bits |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(raux, (o >> 2) + 1, 0, 0) << (4 - (o & 3));
-#pragma unroll
-              for (int e = 0; e < 4; ++e) a4[e] = (bits >> e) & 1u ? 1.f : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float x = v[e] + bv;
-              if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
-              else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_MASK4) x = a4[e] > 0.f ? x : 0.f;
-              v[e] = x;
-            }
-            qs = (v[0] + v[1]) + (v[2] + v[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rout, 4u * o, 0, 0);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int ne = n + e;
-              if (ne < Ntot) {
-                const int oe = ((ne / G::PS) * G::CS + m) * G::PS + ne % G::PS;
-                float x = v[e] + bv;
-                if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
-                else if (p.epi == REPO_EPI_MUL_DRELU) x = p.aux[oe] > 0.f ? x : 0.f;
-                else if (p.epi == REPO_EPI_MUL_MASK4)
-                  x = (reinterpret_cast<const unsigned char*>(p.aux)[oe >> 2] >> (oe & 3)) & 1 ? x : 0.f;
-                p.out[oe] = x;
-                qs += x;
-              }
-            }
-          }
-        }
-        if (p.chan_part) {  // wave-uniform
-          qs += __shfl_xor(qs, 1, 64);
-          qs += __shfl_xor(qs, 2, 64);
-          qs += __shfl_xor(qs, 4, 64);
-          csum[i][pass] += qs;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  if (p.chan_part) {
-    float* red = lds + (NT / 64) * 32 * EP;  // [wave][TM * 32]
-    if ((lane & 7) == 0) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) red[wid * (TM * 32) + i * 32 + pass * 8 + (lane >> 3)] = csum[i][pass];
-    }
-    __syncthreads();
-    if (tid < BM && m0 + tid < G::CS) {
-      const int wmc = tid / (TM * 32), c = tid % (TM * 32);
-      float t = 0.f;
-#pragma unroll
-      for (int x = 0; x < T::WN; ++x) t += red[(wmc * T::WN + x) * (TM * 32) + c];
-      p.chan_part[(size_t)blockIdx.x * G::CS + m0 + tid] = t;
-    }
-  }
+  dconv_down_epilogue<G, T>(p, lds, acc, n0, m0, Ntot);
   REPO_STAMP_FLUSH(NSL);
 }
 

@@ -137,10 +137,9 @@ def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None, dbias=
     assert is_u8 or big.dtype == torch.float32
     if out is None:
         out = torch.empty(nimg, cs, hs, hs, dtype=torch.float32, device=big.device)
-    ws, nb = None, 0
-    if dbias is not None:
-        nb = lib().repo_conv_down_workspace_bytes(layer, nimg)
-        ws = workspace(nb, big.device)
+    # workspace: the channel-sum partials (dbias) and the bf16x6 kernel's weight pack (include/repo_hip.h)
+    nb = lib().repo_conv_down_workspace_bytes(layer, nimg)
+    ws = workspace(nb, big.device) if nb else None
     check(
         lib().repo_conv_down(layer, nimg, _ptr(big), int(is_u8), _ptr(_f32c(w)), _ptr(bias), _ptr(out), epi,
                              _ptr(aux), _ptr(dbias), int(accumulate_dbias), _ptr(ws), nb, _stream()),
