@@ -30,7 +30,12 @@ struct BGeo {
   static constexpr int TAPS = G::KS * KSE;          // slots per channel before padding
   static constexpr int KKE = (TAPS + 7) & ~7;       // padded to whole 8-k fragments
   static constexpr int BPG = KKE / 8;               // MFMA k-blocks (16 k = 8 per lane half) per channel PAIR
-  static constexpr bool OK = G::WB % 2 == 0 && G::CB % 2 == 0;  // dword-aligned tap pairs need an even row pitch
+  // dword-aligned tap pairs need an even row pitch: an odd-width plane (31 x 31, 13 x 13) is stored in LDS with its
+  // rows padded by one element (WBE) -- its staging then places every element on its own (three 2-byte stores
+  // instead of one 8-byte store per plane for four elements)
+  static constexpr bool ODD = (G::WB & 1) != 0;
+  static constexpr int WBE = G::WB + (G::WB & 1);
+  static constexpr bool OK = G::CB % 2 == 0;
 };
 
 // BM x BN tile, CK channels per chunk (even), WM x WN waves
@@ -95,7 +100,9 @@ template <class G, class T>
 __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   typedef BGeo<G> BG;
   typedef BPack<G, T> P;
-  static_assert(BG::OK, "bf16x6 down kernel: even big-row pitch and channel count");
+  static_assert(BG::OK, "bf16x6 down kernel: even channel count");
+  constexpr bool ODD = BG::ODD;
+  constexpr int WBE = BG::WBE;
   constexpr int BM = T::BM, BN = T::BN, CK = T::CK, NT = T::NT, TM = T::TM, TN = T::TN;
   constexpr int NBLK = P::NBLK, NSL = P::NSL, WPLANE = P::WPLANE;
   // ---- patch geometry (dconv_down_kernel): a tile is BN consecutive pixels of (img, sy, sx); image i of the tile
@@ -106,7 +113,11 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   constexpr int PLMAX = cmin(NIMG_MAX * LENFULL,
                              ((2 * (BN / G::WS + 2) + NIMG_MAX * (G::KS - 2)) * G::WB + 4 * NIMG_MAX + 3) & ~3);
   constexpr int PLV = PLMAX / 4;
-  constexpr int PPLANE = CK * PLMAX * 2;                     // bytes of one patch plane
+  // the LDS image of a span (pitch WBE): its own lengths where the pitch is padded
+  constexpr int LENFULL_E = ODD ? ROWS_FULL * WBE : LENFULL;
+  constexpr int PLMAX_E = ODD ? cmin(NIMG_MAX * LENFULL_E, ((2 * (BN / G::WS + 2) + NIMG_MAX * (G::KS - 2)) * WBE + 3) & ~3)
+                              : PLMAX;
+  constexpr int PPLANE = (CK * PLMAX_E * 2 + 15) & ~15;      // bytes of one patch plane
   constexpr int W_NV = 3 * NBLK * 2 * BM;                    // 16-byte weight vectors per chunk
   constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * PLV + NT - 1) / NT;
   constexpr int EPI_FLOATS = (NT / 64) * 32 * 36 + (NT / 64) * TM * 32;
@@ -130,12 +141,17 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   const int lenA = ((2 * (la_ - fa) + G::KS) * G::WB + 3) & ~3;
   auto span_start = [&](int i) __attribute__((always_inline)) { return i == ia ? 0 : lenA + (i - ia - 1) * LENFULL; };
   const int PL = span_start(ib) + (ib == ia ? lenA : ((2 * lb + G::KS) * G::WB + 3) & ~3);
+  const int lenA_e = (2 * (la_ - fa) + G::KS) * WBE;
+  auto span_start_e = [&](int i) __attribute__((always_inline)) {
+    return ODD ? (i == ia ? 0 : lenA_e + (i - ia - 1) * LENFULL_E) : span_start(i);
+  };
 
   const __amdgpu_buffer_rsrc_t rbig = make_rsrc(p.big, p.big_bytes), rw = make_rsrc(p.w, p.w_bytes);
 
   // ---- staging roles
   unsigned poff[P_PER];
   int plds[P_PER];
+  int plde[ODD ? P_PER : 1][4];  // ODD: byte offset of each of the vector's four elements (or -1)
 #pragma unroll
   for (int j = 0; j < P_PER; ++j) {
     const int v = tid + j * NT, c = v / PLV, q = (v % PLV) * 4;
@@ -150,7 +166,16 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
     }
     const int f = (i == ia) ? fa : 0;
     poff[j] = act ? 4u * (unsigned)((i * G::CB + c) * G::PB + 2 * f * G::WB + rel) : kOobOffset;
-    plds[j] = act ? 2 * (c * PLMAX + q) : -1;   // bytes inside a plane
+    plds[j] = act ? 2 * (c * PLMAX_E + q) : -1;   // bytes inside a plane
+    if (ODD) {
+      // rows of the span in memory (its true length: the 16-byte vectors run up to 3 elements past it)
+      const int rows_i = (i == ia) ? 2 * (la_ - fa) + G::KS : (i == ib ? 2 * lb + G::KS : ROWS_FULL);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = (rel + e) / G::WB, col = (rel + e) % G::WB;
+        plde[j][e] = (act && r < rows_i) ? 2 * (c * PLMAX_E + span_start_e(i) + r * WBE + col) : -1;
+      }
+    }
   }
   constexpr unsigned P_STEP = 4u * CK * G::PB;
   const unsigned wbase = (unsigned)(blockIdx.y * NSL) * (unsigned)P::CHUNK_BYTES;
@@ -162,7 +187,7 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
     const int n = min(n0 + (wn * TN + j) * 32 + li, Ntot - 1);
     const int i = n / G::PS, pix = n % G::PS;
     const int f = (i == ia) ? fa : 0;
-    bbh[j] = 2 * (span_start(i) + 2 * (pix / G::WS - f) * G::WB + 2 * (pix % G::WS) + lh * PLMAX);
+    bbh[j] = 2 * (span_start_e(i) + 2 * (pix / G::WS - f) * WBE + 2 * (pix % G::WS) + lh * PLMAX_E);
   }
   const int abase = (lh * BM + wm * (TM * 32) + li) * 16;
 
@@ -197,15 +222,27 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
         unsigned a1, a2, a3, b1, b2, b3;
         bg_split3(rpv[j][0], rpv[j][1], a1, a2, a3);
         bg_split3(rpv[j][2], rpv[j][3], b1, b2, b3);
-        *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{a1, b1};
-        *reinterpret_cast<bg_u32x2*>(Pl + PPLANE + plds[j]) = bg_u32x2{a2, b2};
-        *reinterpret_cast<bg_u32x2*>(Pl + 2 * PPLANE + plds[j]) = bg_u32x2{a3, b3};
+        if (!ODD) {
+          *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{a1, b1};
+          *reinterpret_cast<bg_u32x2*>(Pl + PPLANE + plds[j]) = bg_u32x2{a2, b2};
+          *reinterpret_cast<bg_u32x2*>(Pl + 2 * PPLANE + plds[j]) = bg_u32x2{a3, b3};
+        } else {
+          const unsigned pk[3][2] = {{a1, b1}, {a2, b2}, {a3, b3}};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (plde[j][e] >= 0) {
+#pragma unroll
+              for (int q3 = 0; q3 < 3; ++q3)
+                *reinterpret_cast<unsigned short*>(Pl + q3 * PPLANE + plde[j][e]) =
+                    (unsigned short)(pk[q3][e >> 1] >> (16 * (e & 1)));
+            }
+        }
       }
   };
   // byte offset (inside a plane, from the half's base) of the dword that holds slots q, q + 1 of channel pair g
   auto qoff = [](int g, int q) constexpr {
     const int ky = q / BG::KSE, kx = q % BG::KSE;
-    return (q < BG::TAPS && kx < G::KS) ? 2 * (2 * g * PLMAX + ky * G::WB + kx) : 2 * (2 * g * PLMAX);
+    return (q < BG::TAPS && kx < G::KS) ? 2 * (2 * g * PLMAX_E + ky * WBE + kx) : 2 * (2 * g * PLMAX_E);
   };
   auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -243,6 +280,12 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   };
 
   gload(0);
+  if (ODD) {
+    // the pad column of every row is read (slot kx = KS of an odd kernel, against a zero weight): it must hold a
+    // finite value, and no store below ever touches it
+    for (int i = tid; i < 3 * PPLANE / 16; i += NT) reinterpret_cast<f32x4*>(Pl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+  }
   lstore();
   __syncthreads();
   for (int t = 0; t < NSL; ++t) {

@@ -24,10 +24,14 @@
 #include "uconv.h"
 #include "dconv_up.h"
 #include "bconv.h"
+#include "buconv.h"
 
 #include <atomic>
 
 namespace repo {
+
+// Test aid (repo_debug_bconv): 0 keeps every conv layer on the fp32-MFMA kernels
+static std::atomic<int> g_bconv_enabled{1};
 
 template <int CB_, int CS_, int HB_, int KS_>
 struct Geo {
@@ -429,15 +433,16 @@ template <> struct DLatTile<GEnc3> { using type = DTile<32, 128, 8, 1, 4>; };
 template <> struct DLatTile<GEnc4> { using type = DTile<32, 128, 8, 1, 4>; };
 
 // The bf16x6 down kernel (bconv.h: fp32-accurate, six bf16 MFMAs per 16 k) for the MFMA-bound geometries with an even
-// big-row pitch; NoTile = the layer stays on the fp32-MFMA kernel (3-channel layers: bandwidth / epilogue bound; odd
-// pitches: the tap pairs are not dword-aligned).  Test aid repo_debug_bconv(0) keeps every layer on the fp32 kernel.
+// big-row pitch; NoBTile = the layer stays on the fp32-MFMA kernel (3-channel layers: bandwidth / epilogue bound).  Test aid repo_debug_bconv(0) keeps every layer on the fp32 kernel.
 struct NoBTile {};
 template <class G> struct BDownFor { using type = NoBTile; };
 template <> struct BDownFor<GDec3> { using type = BTile<64, 256, 2, 1, 4>; };
 template <> struct BDownFor<GEnc3> { using type = BTile<64, 256, 4, 1, 4>; };
 template <> struct BDownFor<GEnc4> { using type = BTile<64, 128, 4, 1, 2>; };
+// (enc2 forward -- 31 x 31 planes, k4 -- measured equal on both kernels, 312 vs 309 us: with 4 taps per element the
+// element-wise staging of the padded pitch eats the gain; it stays on the fp32 kernel and saves the pack launch)
+template <> struct BDownFor<GDec2> { using type = BTile<64, 128, 2, 1, 4>; };   // 13 x 13 planes, k5 (32 slots for 25 taps)
 template <class G> constexpr bool kBDown = !std::is_same<typename BDownFor<G>::type, NoBTile>::value;
-static std::atomic<int> g_bconv_enabled{1};
 
 template <class G>
 static bool bconv_down_on(int64_t nimg) {
@@ -563,17 +568,34 @@ template <> struct UpDirect<GY4> { using type = REPO_UPD_Y4; };
 template <> struct UpDirect<GT4> { using type = REPO_UPD_T4; };
 template <class G> constexpr bool kUpDirect = !std::is_same<typename UpDirect<G>::type, NoTile>::value;
 
+// The bf16x6 scatter kernel (buconv.h) for the CS = 64 layers: the decoder's conv3 forward (the update's largest launch)
+// and the encoder's conv2 data gradient.  The weight pack's format follows the kernel: repo_debug_bconv toggles both, so
+// a pack written under one setting must not be used under the other (tests re-pack).
+template <class G> struct BUConf { using type = void; };
+template <> struct BUConf<GDec3> { using type = BSConf<GDec3, 1, 4>; };
+template <> struct BUConf<GEnc2> { using type = BSConf<GEnc2, 1, 4>; };
+template <class G>
+static bool buconv_on() {
+  if constexpr (!std::is_void<typename BUConf<G>::type>::value) return g_bconv_enabled.load(std::memory_order_relaxed) != 0;
+  return false;
+}
+
 template <class G>
 static size_t conv_up_ws_bytes() {
   using C = typename UConf<G>::type;
+  using BC = typename BUConf<G>::type;
   if constexpr (kUpDirect<G>) return UpGeo<G>::PACK_FLOATS * sizeof(float);
   else if constexpr (std::is_void<C>::value) return 0;
+  else if constexpr (!std::is_void<BC>::value) return BC::PACK_BYTES > C::PACK_FLOATS * sizeof(float) ? BC::PACK_BYTES : C::PACK_FLOATS * sizeof(float);
   else return C::PACK_FLOATS * sizeof(float);
 }
 
 template <class G>
 static int conv_up_pack_t(const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
   using UC = typename UConf<G>::type;
+  using BC = typename BUConf<G>::type;
+  if constexpr (!std::is_void<BC>::value)
+    if (buconv_on<G>()) return launch_buconv_pack<G, BC>(w, ws, ws_bytes, s);
   if constexpr (kUpDirect<G>) return launch_dconv_up_pack<G>(w, ws, ws_bytes, s);
   else if constexpr (!std::is_void<UC>::value) return launch_uconv_pack<G, UC>(w, ws, ws_bytes, s);
   else return REPO_OK;  // the 3-channel layers read the native weights
@@ -584,6 +606,9 @@ static int conv_up_t(int64_t nimg, const float* small, const float* w, const flo
                      const float* aux, int packed, void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   using UC = typename UConf<G>::type;
+  using BC = typename BUConf<G>::type;
+  if constexpr (!std::is_void<BC>::value)
+    if (buconv_on<G>()) return launch_buconv_scatter<G, BC>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   if constexpr (kUpDirect<G>) {
     return launch_dconv_up<G, typename UpDirect<G>::type>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   } else if constexpr (!std::is_void<UC>::value) {
