@@ -210,9 +210,18 @@ class Adam:
             denom = (v.sqrt() / math.sqrt(bc2)).add_(self.eps)
             p.addcdiv_(m, denom, value=-(self.lr / bc1))
 
+    # torch >= 2.0: zero_grad() sets gradients to None (set_to_none=True); torch 1.12.1 -- the version the reference
+    # pins (requirements.txt:17) -- ZEROES them, so a parameter whose gradient is not recomputed still takes an Adam
+    # step on a zero gradient (moments decay, the parameter moves, the step count advances).  Only TIA's update
+    # depends on the difference (OracleTIA, cfg.zero_grad_set_to_none).
+    set_to_none = True
+
     def zero_grad(self):
         for p in self.params:
-            p.grad = None
+            if self.set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad = torch.zeros_like(p.grad)
 
 
 @torch.no_grad()
@@ -344,8 +353,9 @@ class OracleAgent:
         actor_loss = -returns.mean() - c.action_ent_coef * action_entropy - c.latent_ent_coef * latent_entropy
 
         self.actor_opt.zero_grad()
-        for q in self.model_params + self.value_params:
-            q.grad = None
+        if getattr(self.model_opt, "set_to_none", True):   # (torch 1.12.1 semantics keep the stale gradients: they are
+            for q in self.model_params + self.value_params:  # what the next zero_grad() zeroes instead of dropping)
+                q.grad = None
         actor_loss.backward()
         self.last["actor_grads"] = [q.grad.detach().clone() for q in self.actor_params]
         total_a = clip_grad_norm(self.actor_params, c.grad_clip_norm)
@@ -420,6 +430,9 @@ class OracleTIA(OracleAgent):
             )
         self.model_params = [t for mod in fx.TIA_MODEL_MODULES for t in self.p[mod].values()]
         self.model_opt = PerParamAdam(self.model_params, cfg.model_lr)
+        # the reference pins torch==1.12.1 (zero_grad() zeroes); the goldens tia_tiny / tia_coefs were generated under
+        # torch 2.x (sets to None), tia_zeros.npz with zero_grad patched to the 1.12.1 behaviour
+        self.model_opt.set_to_none = bool(getattr(cfg, "zero_grad_set_to_none", True))
 
     def train_dynamics(self, obs, actions, rewards, nonterms, eps_prior, eps_post, d_eps_prior=None, d_eps_post=None,
                        apply=True):

@@ -16,6 +16,15 @@ Optimiser state: the reference holds every model parameter in ONE torch Adam who
 differ (the distractor reward head is skipped by the model step -- its gradients are None under FreezeParameters --
 and stepped `tia_reward_train_steps` times afterwards).  Here that is two FlatAdam groups; get_param_dict /
 load_param_dict merge / split them in the reference's parameter order (tia.py:71-82).
+
+zero_grad semantics: the description above is the reference run under torch >= 2.0, where
+`optimizer.zero_grad()` sets gradients to None -- what this container runs and what the goldens tia_tiny / tia_coefs
+pin.  The reference PINS torch==1.12.1 (requirements.txt:17), whose zero_grad() ZEROES gradients: there every
+world-model parameter also takes a zero-gradient Adam step in each fitting iteration (tia.py:184-196: moments decay,
+the parameter moves by lr * m_hat / (sqrt(v_hat) + eps), the step count advances), and from the second update on the
+distractor reward head takes one in the main step.  `config.zero_grad_set_to_none = False` reproduces that behaviour
+(two extra clip_adam launches on zeroed gradient buffers per update; golden tia_zeros.npz, generated from the reference
+with zero_grad patched to set_to_none=False); the default True matches torch >= 2.0.
 """
 import math
 import os
@@ -70,6 +79,8 @@ class TIA(Dreamer):
         self.d_reward_optimizer = FlatAdam(list(self.distractor_reward_model.parameters()), lr=c.model_lr)
         # data parallel: every gradient buffer is exchanged whole, in line (no bucket overlap for this algorithm)
         self._dp_two_buckets = False
+        self._d_reward_has_grad = False   # zero_grad_set_to_none=False: the head's gradient exists (is not None) from
+                                          # the first fitting step on
 
     def toggle_train(self, train=True):
         super().toggle_train(train)
@@ -192,9 +203,15 @@ class TIA(Dreamer):
         dembeds.add_(dembeds_d)
         Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=side)
         self._model_step()
+        opt = self.d_reward_optimizer
+        zeros_mode = not bool(getattr(c, "zero_grad_set_to_none", True))
+        if zeros_mode and self._d_reward_has_grad:
+            # torch 1.12.1: the head's gradient, zeroed by zero_grad() and untouched under FreezeParameters, takes a
+            # zero-gradient Adam step inside model_optimizer.step() (tia.py:182)
+            opt.grad.zero_()
+            opt.step()   # (no clip pass: it would overwrite the logged gradient norm, and scales zeros)
         # -- fit the distractor reward head on the detached latents (tia.py:184-196)
         last = rd_sums
-        opt = self.d_reward_optimizer
         for it in range(int(c.tia_reward_train_steps)):
             if it > 0:
                 rd_pred, rd_hid = ops.mlp_fwd(pw_d, feat_d)
@@ -202,6 +219,13 @@ class TIA(Dreamer):
             ops.mlp_bwd(pw_d, feat_d, rd_hid, drew.view(rows, 1), dparams=gw_d, dx=None)
             self._allreduce(opt.grad)
             opt.clip_and_step(c.grad_clip_norm)
+            self._d_reward_has_grad = True
+            if zeros_mode:
+                # ... and every OTHER model parameter a zero-gradient step in this model_optimizer.step() (tia.py:196)
+                if self._ev_ac_done is not None:   # the previous update's imagination may still read the parameters
+                    torch.cuda.current_stream(self.device).wait_event(self._ev_ac_done)
+                self.model_optimizer.grad.zero_()
+                self.model_optimizer.step()
         # -- logging: the base layout carries the task-side sums, the rest rides as extras
         self._pending_model = (torch.cat([sums8[0:1], rt_sums, kl_t, self.model_optimizer.sqnorm]), None, grow)
         self._pending_extra = (torch.cat([nll_o, rd_sums, kl_d, klraw_t, klraw_d, last]),

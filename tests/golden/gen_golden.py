@@ -270,6 +270,27 @@ def run_mt_case(algo_name, L, B, H, A, C, n_updates, feeder, record, out_path, *
     print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
 
 
+def zero_grad_like_torch_1_12():
+    """Context manager: torch.optim.Optimizer.zero_grad() defaults to set_to_none=False, as in the torch==1.12.1 the
+    reference pins (requirements.txt:17) -- gradients are ZEROED, not dropped."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        orig = torch.optim.Optimizer.zero_grad
+
+        def zero_grad(self, set_to_none=False):
+            return orig(self, set_to_none=set_to_none)
+
+        torch.optim.Optimizer.zero_grad = zero_grad
+        try:
+            yield
+        finally:
+            torch.optim.Optimizer.zero_grad = orig
+
+    return cm()
+
+
 def run_tia_case(TIA, L, B, H, A, n_updates, feeder, record, out_path, **cfg_over):
     """The reference's TIA (tia.py) on seeded parameters / batches / noise: logged scalars, the pre-clip total
     norms of its clip_grad_norm_ calls (model, distractor reward x tia_reward_train_steps, actor, value), the task
@@ -366,6 +387,14 @@ def run_finetune_case(L, B, A, n_updates, feeder, record, out_path):
     print(f"wrote {out_path} ({os.path.getsize(out_path)} bytes)")
 
 
+def run_tia_zeros(TIA, feeder, record):
+    # TIA under the zero_grad() of the torch==1.12.1 the reference pins (gradients zeroed, not set to None): every
+    # world-model parameter takes zero-gradient Adam steps in the fitting loop, the distractor reward head one in the
+    # main step from the second update on.  Two fitting steps, three updates.
+    with zero_grad_like_torch_1_12():
+        run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(OUT, "tia_zeros.npz"), tia_reward_train_steps=2)
+
+
 def run_mt_cases(feeder, record):
     # multitask (f4): MultitaskDreamer at the defaults; MultitaskRePo with a beta large enough for the per-task
     # multipliers to matter and a target below the KL, 3 tasks (every multitask environment of the reference has 3)
@@ -392,6 +421,7 @@ def main():
         run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(OUT, "tia_tiny.npz"))
         run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(OUT, "tia_coefs.npz"), tia_obs_coef=0.5,
                      tia_adv_coef=2.0, tia_reward_train_steps=2)
+        run_tia_zeros(TIA, feeder, record)
         return
     # tiny unit-test size, full latents
     run_case(RePo, "repo", 8, 4, 5, 6, 3, True, feeder, record, os.path.join(OUT, "repo_tiny.npz"))
@@ -408,6 +438,7 @@ def main():
     run_tia_case(TIA, 8, 4, 5, 6, 3, feeder, record, os.path.join(OUT, "tia_tiny.npz"))
     run_tia_case(TIA, 6, 3, 4, 7, 2, feeder, record, os.path.join(OUT, "tia_coefs.npz"), tia_obs_coef=0.5,
                  tia_adv_coef=2.0, tia_reward_train_steps=2)
+    run_tia_zeros(TIA, feeder, record)
     run_mt_cases(feeder, record)
 
 

@@ -44,6 +44,6 @@ def test_update_generator_reproduces_committed_fixtures(tmp_path):
     _run("gen_golden.py", tmp_path, "--skip-c1")
     made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
     assert made == ["dreamer_tiny.npz", "finetune_tiny.npz", "mt_dreamer_tiny.npz", "mt_repo_tiny.npz", "repo_odd.npz",
-                    "repo_tiny.npz", "tia_coefs.npz", "tia_tiny.npz"]
+                    "repo_tiny.npz", "tia_coefs.npz", "tia_tiny.npz", "tia_zeros.npz"]
     for f in made:
         _same_npz(tmp_path / f, os.path.join(GOLDEN, f))

@@ -236,6 +236,42 @@ def test_conv_up(ops, layer, nimg):
     assert relerr(got, want) < TOL
 
 
+@pytest.mark.parametrize("layer,kind", [(5, "down"), (2, "down"), (3, "down"), (4, "down"), (5, "up"), (1, "up")])
+def test_bf16x6_conv_kernels_match_fp64_and_the_fp32_kernels(ops, layer, kind):
+    """The bf16x6 conv kernels (csrc/bconv.h: decoder conv3 / conv2 data gradients, encoder conv3 / conv4 forward;
+    csrc/buconv.h: decoder conv3 forward, encoder conv2 data gradient) against fp64 at a batch that fills several
+    pixel tiles and straddles images -- and against the fp32-MFMA kernel of the same layer on the SAME operands
+    (repo_debug_bconv(0)): the error relative to sum |a||b| may not exceed that kernel's by more than 25 % (measured: at or
+    below it), i.e. the six-product split is an fp32-accurate way of feeding the bf16 pipe, not a reduced precision."""
+    from repo_amd._lib import lib
+
+    nimg = 41
+    big, small, w, rs = _layer_tensors(ops, layer, nimg, 900 + layer)
+    big[::3] *= 25.0
+    small[::3] *= 25.0
+    if kind == "down":
+        want = F.conv2d(big.double(), w.double(), None, stride=2)
+        mag = F.conv2d(big.double().abs(), w.double().abs(), None, stride=2)
+        run = lambda: ops.conv_down(layer, dev(big), dev(w), None, epi=ops.EPI_NONE)  # noqa: E731
+    else:
+        hb = big.shape[2]
+        pad = lambda r: F.pad(r, (0, hb - r.shape[3], 0, hb - r.shape[2]))  # noqa: E731
+        want = pad(F.conv_transpose2d(small.double(), w.double(), None, stride=2))
+        mag = pad(F.conv_transpose2d(small.double().abs(), w.double().abs(), None, stride=2)) + 1e-30
+        run = lambda: ops.conv_up(layer, dev(small), dev(w), None, epi=ops.EPI_NONE)  # noqa: E731
+    errs = {}
+    for engine in (1, 0):
+        prev = lib().repo_debug_bconv(engine)
+        try:
+            got = run()
+        finally:
+            lib().repo_debug_bconv(prev)
+        assert relerr(got, want) < TOL
+        errs[engine] = float(((got.double().cpu() - want).abs() / (mag + 1e-30)).max())
+    log(f"bf16x6 conv layer {layer} {kind}: max |err| / sum|a||b|  bf16x6 {errs[1]:.2e}  fp32 MFMA {errs[0]:.2e}")
+    assert errs[1] <= 1.25 * errs[0] + 1e-9, errs
+
+
 @pytest.mark.parametrize("layer", ALL_LAYERS)
 @pytest.mark.parametrize("nimg", [1, 9, 75])  # 75: several image groups per split, ragged last group and split
 def test_conv_wgrad(ops, layer, nimg):

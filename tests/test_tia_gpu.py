@@ -66,12 +66,14 @@ def test_tia_blend_nll_matches_torch(n, u8):
     assert dt2.data_ptr() == a.data_ptr() and torch.equal(dt2, dt) and torch.equal(dd2, dd)
 
 
-@pytest.mark.parametrize("fname", ["tia_tiny.npz", "tia_coefs.npz"])
+@pytest.mark.parametrize("fname", ["tia_tiny.npz", "tia_coefs.npz", "tia_zeros.npz"])
 def test_tia_update_matches_reference_goldens(golden_dir, fname):
     g = np.load(os.path.join(golden_dir, fname))
     L, B, H, A, n_updates, rsteps = (int(x) for x in g["meta"])
     obs_coef, adv_coef = (float(x) for x in g["coefs"])
-    agent, cfg = make_tia(L, B, H, A, tia_obs_coef=obs_coef, tia_adv_coef=adv_coef, tia_reward_train_steps=rsteps)
+    # tia_zeros.npz: the reference under the zero_grad() of the torch==1.12.1 it pins (gradients zeroed, not dropped)
+    agent, cfg = make_tia(L, B, H, A, tia_obs_coef=obs_coef, tia_adv_coef=adv_coef, tia_reward_train_steps=rsteps,
+                          zero_grad_set_to_none=fname != "tia_zeros.npz")
     keys = [str(k) for k in g["scalar_keys"]]
     for u in range(n_updates):
         batch, _ = dev_batch(L, B, A, 11 + u, u8=(u % 2 == 0))
@@ -79,14 +81,18 @@ def test_tia_update_matches_reference_goldens(golden_dir, fname):
         beliefs, post = agent.train_dynamics(batch[0], batch[1], batch[2], 1.0 - batch[3])
         agent.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
         scal = agent.last_scalars
-        atol = 1e-4 if u == 0 else 2e-3
+        atol = 1e-4 if u == 0 else (4e-3 if fname == "tia_zeros.npz" else 2e-3)
         np.testing.assert_allclose(beliefs.cpu().numpy(), g[f"u{u}/beliefs"], rtol=1e-3, atol=atol)
         np.testing.assert_allclose(post.cpu().numpy(), g[f"u{u}/posterior_states"], rtol=1e-3, atol=atol)
         for k, w in zip(keys, g[f"u{u}/scalars"]):
             got = scal[k]
             r = abs(got - w) / (abs(w) + 1e-12)
             log(f"[{fname}] update {u} {k}: got {got:.7g} ref {w:.7g} rel {r:.2e}")
-            assert r < 1e-3, (fname, u, k, got, w)
+            # (tia_zeros, raw KL values from the third update on: see tests/test_oracle_golden.py -- two fp32 CPU runs
+            # of the same arithmetic differ by 1.3e-3 there)
+            # (... and `reward_loss` = t_reward_loss - d_reward_loss is a difference of two 0.95s: -0.015)
+            loose = fname == "tia_zeros.npz" and (k.endswith("kl_div") or k == "train/reward_loss")
+            assert r < (4e-3 if loose else 1e-3), (fname, u, k, got, w)
         tn = g[f"u{u}/total_norms"]   # model, distractor reward x rsteps, actor, value
         gn = agent.last_grad_norms
         for name, w in (("model", tn[0]), ("actor", tn[-2]), ("value", tn[-1])):
