@@ -15,9 +15,11 @@
 //   * a tap of a tile is a chain of 6 * CS / 32 MFMAs of 16 cycles (fp32: CS / 4 of 32 cycles): 12 against 16 slots
 //     at CS = 64 -- the write-back of the previous pair and the request of the own old values sit in slots 1-2 / 4-5 as
 //     before.
-// Built for CS = 64 (decoder conv3 forward -- the update's largest launch -- and encoder conv2's data gradient, its most
-// contended one): with more input channels the fragments of one tile pair no longer fit the register file beside the
-// weights, and those layers stay on uconv.h's fp32 kernel.
+// The fragments of a tile are kept for 64 input channels at a time (more do not fit the register file beside the
+// weights): a layer with CS = 128 / 256 walks its channels in K-SLICES of 64 -- the accumulation is in the LDS class
+// planes anyway, so a slice is just another pass of chunks over the same tiles with the next slice's weights.
+// Odd kernels (k5): the tap set depends on the output parity class, so the tap loop is instantiated per class (the
+// wave's class is uniform; even kernels share one instantiation).
 #pragma once
 #include "bgemm.h"
 #include "uconv.h"
@@ -28,8 +30,9 @@ template <class G, int GI_, int NC_>
 struct BSConf {
   static constexpr int GI = GI_;                 // images per workgroup
   static constexpr int NC = NC_;                 // N tiles whose B fragments are resident at a time (even)
-  static constexpr int KB = G::CS / 32;          // k-blocks of v_mfma_f32_16x16x32_bf16
-  static constexpr int KST = G::CS / 4;          // dword loads of a B tile per lane (= 8 KB)
+  static constexpr int KSL = G::CS / 64;         // K-slices of 64 input channels
+  static constexpr int KB = 2;                   // k-blocks of v_mfma_f32_16x16x32_bf16 per slice
+  static constexpr int KST = 16;                 // dword loads of a B tile per lane and slice (= 8 KB)
   static constexpr int NGRP = G::CB / 16;
   static constexpr int NPX = GI * G::PS;
   static constexpr int NT = (NPX + 15) / 16;
@@ -40,11 +43,11 @@ struct BSConf {
   static constexpr int LDS_FLOATS = GI * IMG_LDS;
   static constexpr int DUMMY_FLOATS = 4 * (64 + (J - 1) * (NXM + 1) + 4);
   static constexpr int LDS_TOTAL_FLOATS = LDS_FLOATS + DUMMY_FLOATS;
-  // pack: [grp][cls][tap][kb][plane][lane][8 bf16]
+  // pack: [grp][cls][slice][tap][kb][plane][lane][8 bf16]
   static constexpr int TAP_BYTES = KB * 3 * 64 * 16;
-  static constexpr size_t PACK_BYTES = (size_t)NGRP * 4 * J * J * TAP_BYTES;
+  static constexpr size_t PACK_BYTES = (size_t)NGRP * 4 * KSL * J * J * TAP_BYTES;
   static constexpr size_t PACK_FLOATS = PACK_BYTES / 4;   // (the host code sizes workspaces in floats)
-  static_assert(G::CS % 32 == 0 && G::CB % 16 == 0 && NC % 2 == 0, "32-channel k-blocks, 16-channel groups, tile pairs");
+  static_assert(G::CS % 64 == 0 && G::CB % 16 == 0 && NC % 2 == 0, "64-channel slices, 16-channel groups, tile pairs");
   static_assert(6 * KB >= 8, "the pipelined write-back needs 8 slots per chain");
 };
 
@@ -52,11 +55,11 @@ struct BUPackArgs {
   const float* w;
   char* wp;
 };
-// one thread per (grp, cls, tap, kb, lane): the 8 k of one A fragment, three planes
+// one thread per (grp, cls, slice, tap, kb, lane): the 8 k of one A fragment, three planes
 template <class G, class C>
 __global__ __launch_bounds__(256) void buconv_pack_kernel(BUPackArgs p) {
   constexpr int J = C::J, KB = C::KB;
-  const int total = C::NGRP * 4 * J * J * KB * 64;
+  const int total = C::NGRP * 4 * C::KSL * J * J * KB * 64;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int lane = i & 63;
     int r = i >> 6;
@@ -64,34 +67,42 @@ __global__ __launch_bounds__(256) void buconv_pack_kernel(BUPackArgs p) {
     r /= KB;
     const int tap = r % (J * J);
     r /= J * J;
+    const int ks = r % C::KSL;
+    r /= C::KSL;
     const int cls = r & 3, grp = r >> 2;
     const int ky = (cls >> 1) + 2 * (tap / J), kx = (cls & 1) + 2 * (tap % J);
     const int cb = 16 * grp + (lane & 15);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int cs = 32 * kb + 8 * (lane >> 4) + j;
+      const int cs = 64 * ks + 32 * kb + 8 * (lane >> 4) + j;
       v[j] = (ky < G::KS && kx < G::KS) ? p.w[((size_t)cs * G::CB + cb) * G::KK + ky * G::KS + kx] : 0.f;
     }
     unsigned pl[3][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) bg_split3(v[2 * e], v[2 * e + 1], pl[0][e], pl[1][e], pl[2][e]);
-    char* dst = p.wp + ((size_t)((grp * 4 + cls) * J * J + tap) * KB + kb) * (3 * 64 * 16) + lane * 16;
+    char* dst = p.wp + ((size_t)(((grp * 4 + cls) * C::KSL + ks) * J * J + tap) * KB + kb) * (3 * 64 * 16) + lane * 16;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       *reinterpret_cast<u32x4s*>(dst + q * (64 * 16)) = u32x4s{pl[q][0], pl[q][1], pl[q][2], pl[q][3]};
   }
 }
 
-// raw fp32 values of N tile `j` of chunk d: lane (pixel lp, octet lq) loads small[img][32 kb + 8 lq + e][pixel]
+// A chunk = up to NC consecutive N tiles of one workgroup tile, over ONE K-slice; wave-uniform.
+struct BUChunk {
+  int img0, grp, tile0, ks;
+  bool valid;
+};
+
+// raw fp32 values of N tile `j` of chunk d: lane (pixel lp, octet lq) loads small[img][64 ks + 32 kb + 8 lq + e][pixel]
 template <class G, class C>
-__device__ __forceinline__ void buconv_load_raw(const UScatArgs& p, const UChunk& d, int j, int lane, float (&raw)[C::KST]) {
+__device__ __forceinline__ void buconv_load_raw(const UScatArgs& p, const BUChunk& d, int j, int lane, float (&raw)[C::KST]) {
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.small, p.small_bytes);
   const int lp = lane & 15, lq = lane >> 4;
   const int q = (d.tile0 + j) * 16 + lp;
   const int il = q / G::PS, pix = q % G::PS;
   const bool ok = q < C::NPX && d.img0 + il < p.nimg;
-  const unsigned base = ok ? 4u * (unsigned)(((d.img0 + il) * G::CS + 8 * lq) * G::PS + pix) : kOobOffset;
+  const unsigned base = ok ? 4u * (unsigned)(((d.img0 + il) * G::CS + 64 * d.ks + 8 * lq) * G::PS + pix) : kOobOffset;
 #pragma unroll
   for (int kb = 0; kb < C::KB; ++kb)
 #pragma unroll
@@ -117,27 +128,30 @@ __device__ __forceinline__ void buconv_split(const float (&raw)[C::KST], BFrag (
 }
 
 // All taps of one parity class over one chunk of NTL (compile-time) N tiles, for one compute wave: uconv_chunk with
-// the chain of a (tile, tap) being 6 KB MFMAs.  A0 = the weight buffer the chunk's FIRST tap sits in (the taps
-// alternate between the two buffers; a chunk of an odd number of taps hands the other parity to the next chunk).
-template <class G, class C, int NTL, int NEXT_NTL, int A0>
-__device__ __forceinline__ void buconv_chunk(const UScatArgs& p, char* pl, int cls, int lane, const UChunk& d,
-                                             const UChunk& nx, int dummy_ofs, BFrag (&bfr)[C::NC][C::KB],
+// the chain of a (tile, tap) being 6 KB MFMAs.  PY, PX: the class whose TAP SET this instantiation walks (ty < JY, tx <
+// JX; for even kernels every class has all J x J taps and (0, 0) serves them all -- the class itself, `cls`, only enters
+// addresses).  A0 = the weight buffer the chunk's FIRST tap sits in: the taps alternate between the two buffers, the
+// next chunk (same tiles' next K-slice, or the next tiles) starts where this one ends.
+template <class G, class C, int PY, int PX, int NTL, int NEXT_NTL, int A0>
+__device__ __forceinline__ void buconv_chunk(const UScatArgs& p, char* pl, int cls, int lane, const BUChunk& d,
+                                             const BUChunk& nx, int dummy_ofs, BFrag (&bfr)[C::NC][C::KB],
                                              float (&raw)[C::NC][C::KST], BFrag (&afr)[2][C::KB]) {
   constexpr int KB = C::KB, J = C::J, NXM = C::NXM, PLANE = C::PLANE;
-  static_assert(G::KS % 2 == 0, "every tap is valid for every class (even kernels)");
+  constexpr int JY = (G::KS - PY + 1) / 2, JX = (G::KS - PX + 1) / 2, NTAP = JY * JX;
   constexpr int NP = (NTL + 1) / 2;
   constexpr int SLOTS = 6 * KB;
   const int lp = lane & 15, lq = lane >> 4;
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, p.wp_bytes);
   const unsigned a_lane = 16u * (unsigned)lane;
-  auto a_sbase = [&](int grp) { return (unsigned)((grp * 4 + cls) * J * J) * (unsigned)C::TAP_BYTES; };
-  auto load_a = [&](BFrag (&a)[KB], unsigned sbase, int t) __attribute__((always_inline)) {
+  auto a_sbase = [&](const BUChunk& c) { return (unsigned)(((c.grp * 4 + cls) * C::KSL + c.ks) * J * J) * (unsigned)C::TAP_BYTES; };
+  // tn = tap number in the pack (ty * J + tx)
+  auto load_a = [&](BFrag (&a)[KB], unsigned sbase, int tn) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         a[kb][q] = __builtin_bit_cast(bg_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-            rw, a_lane + 1024u * (unsigned)q, sbase + (unsigned)t * C::TAP_BYTES + 3072u * (unsigned)kb, 0));
+            rw, a_lane + 1024u * (unsigned)q, sbase + (unsigned)tn * C::TAP_BYTES + 3072u * (unsigned)kb, 0));
   };
 
   int lbase[NTL];
@@ -157,14 +171,13 @@ __device__ __forceinline__ void buconv_chunk(const UScatArgs& p, char* pl, int c
   int pb0 = 0, pb1 = 0;
 
 #pragma unroll
-  for (int t = 0; t < J * J; ++t) {
-    const bool last = t == J * J - 1;
-    constexpr int dummy = 0;
-    (void)dummy;
+  for (int t = 0; t < NTAP; ++t) {
+    const int ty = t / JX, tx = t % JX;
+    const bool last = t == NTAP - 1;
     const int ab = (A0 + t) & 1;  // compile time after unrolling
-    if (!last) load_a(afr[ab ^ 1], a_sbase(d.grp), t + 1);
-    else if (nx.valid) load_a(afr[ab ^ 1], a_sbase(nx.grp), 0);
-    const int shift = 16 * ((t / J) * NXM + (t % J));
+    if (!last) load_a(afr[ab ^ 1], a_sbase(d), ((t + 1) / JX) * J + (t + 1) % JX);
+    else if (nx.valid) load_a(afr[ab ^ 1], a_sbase(nx), 0);
+    const int shift = 16 * (ty * NXM + tx);
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
       const int j0 = 2 * pr, j1 = (2 * pr + 1 < NTL) ? 2 * pr + 1 : 2 * pr;
@@ -211,11 +224,31 @@ __device__ __forceinline__ void buconv_chunk(const UScatArgs& p, char* pl, int c
   __builtin_amdgcn_wave_barrier();
 }
 
+// The chunks of one workgroup tile in order: for each K-slice, the tile chunks (NFULL of NC tiles + a tail).  Chunk c
+// is instantiated with its own tile count, its successor's, and the weight-buffer parity it starts in.
+template <class G, class C, int PY, int PX, int CI>
+__device__ __forceinline__ void buconv_run(const UScatArgs& p, char* buf, int cls, int lane, int img0, int grp,
+                                           BFrag (&bfr)[C::NC][C::KB], float (&raw)[C::NC][C::KST], BFrag (&afr)[2][C::KB]) {
+  constexpr int NC = C::NC, NT = C::NT;
+  constexpr int NFULL = NT / NC, NTAIL = NT % NC, NCHT = NFULL + (NTAIL > 0 ? 1 : 0), NCH = C::KSL * NCHT;
+  constexpr int NTAP = ((G::KS - PY + 1) / 2) * ((G::KS - PX + 1) / 2);
+  if constexpr (CI < NCH) {
+    constexpr int ct = CI % NCHT, ks = CI / NCHT;
+    constexpr int NTL = ct < NFULL ? NC : NTAIL;
+    constexpr bool more = CI + 1 < NCH;
+    constexpr int nct = (CI + 1) % NCHT, nks = (CI + 1) / NCHT;
+    constexpr int NEXT = more ? (nct < NFULL ? NC : NTAIL) : 1;
+    const BUChunk d{img0, grp, ct * NC, ks, true};
+    const BUChunk nx{img0, grp, nct * NC, nks, more};
+    buconv_chunk<G, C, PY, PX, NTL, NEXT, (CI * NTAP) & 1>(p, buf, cls, lane, d, nx, 4 * C::LDS_FLOATS, bfr, raw, afr);
+    buconv_run<G, C, PY, PX, CI + 1>(p, buf, cls, lane, img0, grp, bfr, raw, afr);
+  }
+}
+
 template <class G, class C>
 __global__ __launch_bounds__(256, 2) void buconv_scatter_kernel(UScatArgs p) {
   constexpr int GI = C::GI, NC = C::NC, NT = C::NT, JJ = C::J * C::J;
-  constexpr int NFULL = NT / NC, NTAIL = NT % NC;
-  constexpr int FIRST_NTL = NFULL > 0 ? NC : NTAIL;
+  constexpr int FIRST_NTL = NT / NC > 0 ? NC : NT % NC;
   extern __shared__ __attribute__((aligned(16))) float planes[];
 
   const int tid = threadIdx.x;
@@ -223,12 +256,11 @@ __global__ __launch_bounds__(256, 2) void buconv_scatter_kernel(UScatArgs p) {
   const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int grp = tile % C::NGRP, img0 = (tile / C::NGRP) * GI;
-  auto chunk_of = [&](int tile0, bool valid) { return UChunk{img0, grp, tile0, valid}; };
 
   BFrag bfr[NC][C::KB], afr[2][C::KB];
   float raw[NC][C::KST];
   {
-    const UChunk d0 = chunk_of(0, true);
+    const BUChunk d0{img0, grp, 0, 0, true};
 #pragma unroll
     for (int j = 0; j < FIRST_NTL; ++j) buconv_load_raw<G, C>(p, d0, j, lane, raw[j]);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wp, p.wp_bytes);
@@ -238,36 +270,19 @@ __global__ __launch_bounds__(256, 2) void buconv_scatter_kernel(UScatArgs p) {
       for (int q = 0; q < 3; ++q)
         afr[0][kb][q] = __builtin_bit_cast(bg_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
             rw, 16u * (unsigned)lane + 1024u * (unsigned)q,
-            (unsigned)((grp * 4 + cls) * JJ) * (unsigned)C::TAP_BYTES + 3072u * (unsigned)kb, 0));
+            (unsigned)(((grp * 4 + cls) * C::KSL) * JJ) * (unsigned)C::TAP_BYTES + 3072u * (unsigned)kb, 0));
   }
   for (int i = tid; i < C::LDS_TOTAL_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(planes)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  {
-    char* buf = reinterpret_cast<char*>(planes);
-    constexpr int dmy = 4 * C::LDS_FLOATS;
-    const UChunk none = chunk_of(0, false);
-    // chunk ch starts in weight buffer (ch * JJ) & 1
-#pragma unroll
-    for (int ch = 0; ch < NFULL; ++ch) {
-      const UChunk d = chunk_of(ch * NC, true);
-      constexpr int dummy = 0;
-      (void)dummy;
-      if (ch + 1 < NFULL) {
-        if ((ch * JJ) & 1) buconv_chunk<G, C, NC, NC, 1>(p, buf, cls, lane, d, chunk_of((ch + 1) * NC, true), dmy, bfr, raw, afr);
-        else buconv_chunk<G, C, NC, NC, 0>(p, buf, cls, lane, d, chunk_of((ch + 1) * NC, true), dmy, bfr, raw, afr);
-      } else if (NTAIL > 0) {
-        if ((ch * JJ) & 1) buconv_chunk<G, C, NC, (NTAIL > 0 ? NTAIL : 1), 1>(p, buf, cls, lane, d, chunk_of(NFULL * NC, true), dmy, bfr, raw, afr);
-        else buconv_chunk<G, C, NC, (NTAIL > 0 ? NTAIL : 1), 0>(p, buf, cls, lane, d, chunk_of(NFULL * NC, true), dmy, bfr, raw, afr);
-      } else {
-        if ((ch * JJ) & 1) buconv_chunk<G, C, NC, 1, 1>(p, buf, cls, lane, d, none, dmy, bfr, raw, afr);
-        else buconv_chunk<G, C, NC, 1, 0>(p, buf, cls, lane, d, none, dmy, bfr, raw, afr);
-      }
-    }
-    if (NTAIL > 0) {
-      if ((NFULL * JJ) & 1) buconv_chunk<G, C, (NTAIL > 0 ? NTAIL : 1), 1, 1>(p, buf, cls, lane, chunk_of(NFULL * NC, true), none, dmy, bfr, raw, afr);
-      else buconv_chunk<G, C, (NTAIL > 0 ? NTAIL : 1), 1, 0>(p, buf, cls, lane, chunk_of(NFULL * NC, true), none, dmy, bfr, raw, afr);
-    }
+  char* buf = reinterpret_cast<char*>(planes);
+  if constexpr (G::KS % 2 == 0) {
+    buconv_run<G, C, 0, 0, 0>(p, buf, cls, lane, img0, grp, bfr, raw, afr);
+  } else {  // odd kernels: the class's tap set is a compile-time property of its own instantiation
+    if (cls == 0) buconv_run<G, C, 0, 0, 0>(p, buf, cls, lane, img0, grp, bfr, raw, afr);
+    else if (cls == 1) buconv_run<G, C, 0, 1, 0>(p, buf, cls, lane, img0, grp, bfr, raw, afr);
+    else if (cls == 2) buconv_run<G, C, 1, 0, 0>(p, buf, cls, lane, img0, grp, bfr, raw, afr);
+    else buconv_run<G, C, 1, 1, 0>(p, buf, cls, lane, img0, grp, bfr, raw, afr);
   }
   __syncthreads();
   if (G::PB % 4 == 0) uconv_drain<G, C>(p, planes, grp, img0, cls, lane);
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void buconv_scatter_kernel(UScatArgs p) {
 template <class G, class C>
 inline int launch_buconv_pack(const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!ws || ws_bytes < C::PACK_BYTES) return REPO_E_WS_TOO_SMALL;
-  const int total = C::NGRP * 4 * C::J * C::J * C::KB * 64;
+  const int total = C::NGRP * 4 * C::KSL * C::J * C::J * C::KB * 64;
   hipLaunchKernelGGL((buconv_pack_kernel<G, C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, BUPackArgs{w, (char*)ws});
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? REPO_OK : (int)e;

@@ -568,12 +568,15 @@ template <> struct UpDirect<GY4> { using type = REPO_UPD_Y4; };
 template <> struct UpDirect<GT4> { using type = REPO_UPD_T4; };
 template <class G> constexpr bool kUpDirect = !std::is_same<typename UpDirect<G>::type, NoTile>::value;
 
-// The bf16x6 scatter kernel (buconv.h) for the CS = 64 layers: the decoder's conv3 forward (the update's largest launch)
-// and the encoder's conv2 data gradient.  The weight pack's format follows the kernel: repo_debug_bconv toggles both, so
+// The bf16x6 scatter kernel (buconv.h): the decoder's conv3 forward (the update's largest launch), conv2 forward, and the
+// encoder's conv2 / conv3 / conv4 data gradients.  The weight pack's format follows the kernel: repo_debug_bconv toggles both, so
 // a pack written under one setting must not be used under the other (tests re-pack).
 template <class G> struct BUConf { using type = void; };
 template <> struct BUConf<GDec3> { using type = BSConf<GDec3, 1, 4>; };
 template <> struct BUConf<GEnc2> { using type = BSConf<GEnc2, 1, 4>; };
+template <> struct BUConf<GEnc3> { using type = BSConf<GEnc3, 4, 4>; };   // CS = 128: two K-slices
+template <> struct BUConf<GEnc4> { using type = BSConf<GEnc4, 8, 2>; };   // CS = 256: four
+template <> struct BUConf<GDec2> { using type = BSConf<GDec2, 5, 4>; };   // CS = 128, k5: per-class tap sets
 template <class G>
 static bool buconv_on() {
   if constexpr (!std::is_void<typename BUConf<G>::type>::value) return g_bconv_enabled.load(std::memory_order_relaxed) != 0;
