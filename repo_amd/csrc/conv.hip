@@ -25,6 +25,7 @@
 #include "dconv_up.h"
 #include "bconv.h"
 #include "buconv.h"
+#include "bwgrad.h"
 
 #include <atomic>
 
@@ -660,6 +661,17 @@ static void launch_conv_slab_reduce(const float* ws, int splits, int cs, int nw,
   }
 }
 
+// The bf16x6 weight-gradient kernel (bwgrad.h) for the layers whose bands fill whole 16-k blocks reasonably (enc4's 2 x 2
+// planes would run 4 real k in a block of 16; the 3-channel layers are not MFMA-bound): tile BM x BN, waves, images per
+// chunk, small rows per band.  The split-K over image groups (slabs, reduce) is the fp32 kernel's.
+template <class G> struct BWgradFor { using type = NoBTile; };
+template <> struct BWgradFor<GDec3> { using type = WTile<64, 128, 1, 4, 1, 7>; };   // 531 -> 465 us (64 x 64 wave tiles: 551)
+template <> struct BWgradFor<GEnc3> { using type = WTile<64, 256, 1, 4, 1, 6>; };   // 215 -> 172-182 us
+// measured and left on the fp32 kernel: enc2 (31 x 31 planes: 343-445 us against 320) and dec2 (232-244 against 247) --
+// with one or two waves per SIMD the in-register split of the B fragments (44 dependent vector instructions per 8
+// elements) is not hidden behind 12 MFMAs
+template <class G> constexpr bool kBWgrad = !std::is_same<typename BWgradFor<G>::type, NoBTile>::value;
+
 template <class G, class BigT>
 static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float* dw, float* db, int accumulate,
                         void* ws, size_t ws_bytes, hipStream_t s) {
@@ -668,7 +680,14 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
   const int dips = dwgrad_ips<G>(nimg), dsplits = dwgrad_splits<G>(nimg);
   WgradArgs a{small, big, (float*)ws, (int)nimg, dips, db != nullptr,
               (unsigned)(nimg * G::CS * G::PS * sizeof(float)), (unsigned)(nimg * G::CB * G::PB * sizeof(BigT))};
-  int rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
+  int rc;
+  if constexpr (kBWgrad<G> && std::is_same<BigT, float>::value) {
+    static_assert(DTileFor<G>::Wgrad::GI % BWgradFor<G>::type::GI == 0, "images per split: a multiple of both kernels' chunks");
+    if (g_bconv_enabled.load(std::memory_order_relaxed)) rc = launch_bconv_wgrad<G, typename BWgradFor<G>::type>(a, dsplits, s);
+    else rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
+  } else {
+    rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
+  }
   if (rc) return rc;
   launch_conv_slab_reduce((const float*)ws, dsplits, G::CS, G::CB * G::KK, dw, db, accumulate, s);
   REPO_CHECK_LAUNCH();

@@ -236,10 +236,12 @@ def test_conv_up(ops, layer, nimg):
     assert relerr(got, want) < TOL
 
 
-@pytest.mark.parametrize("layer,kind", [(5, "down"), (2, "down"), (3, "down"), (4, "down"), (5, "up"), (1, "up")])
+@pytest.mark.parametrize("layer,kind", [(5, "down"), (2, "down"), (3, "down"), (4, "down"), (5, "up"), (1, "up"), (2, "up"),
+                                        (3, "up"), (4, "up"), (5, "wgrad"), (2, "wgrad")])
 def test_bf16x6_conv_kernels_match_fp64_and_the_fp32_kernels(ops, layer, kind):
     """The bf16x6 conv kernels (csrc/bconv.h: decoder conv3 / conv2 data gradients, encoder conv3 / conv4 forward;
-    csrc/buconv.h: decoder conv3 forward, encoder conv2 data gradient) against fp64 at a batch that fills several
+    csrc/buconv.h: decoder conv3 / conv2 forward, encoder conv2 / conv3 / conv4 data gradients; csrc/bwgrad.h: decoder conv3
+    and encoder conv3 weight gradients) against fp64 at a batch that fills several
     pixel tiles and straddles images -- and against the fp32-MFMA kernel of the same layer on the SAME operands
     (repo_debug_bconv(0)): the error relative to sum |a||b| may not exceed that kernel's by more than 25 % (measured: at or
     below it), i.e. the six-product split is an fp32-accurate way of feeding the bf16 pipe, not a reduced precision."""
@@ -253,6 +255,15 @@ def test_bf16x6_conv_kernels_match_fp64_and_the_fp32_kernels(ops, layer, kind):
         want = F.conv2d(big.double(), w.double(), None, stride=2)
         mag = F.conv2d(big.double().abs(), w.double().abs(), None, stride=2)
         run = lambda: ops.conv_down(layer, dev(big), dev(w), None, epi=ops.EPI_NONE)  # noqa: E731
+    elif kind == "wgrad":
+        def corr(a, b):   # dw[cs][cb][ky][kx] = sum_n corr(small, big)
+            ks = w.shape[-1]
+            cols = F.unfold(b, ks, stride=2).view(b.shape[0], b.shape[1], ks * ks, -1)       # (n, cb, kk, pix)
+            return torch.einsum("nsp,nckp->sck", a.flatten(2), cols).view(a.shape[1], b.shape[1], ks, ks)
+
+        want = corr(small.double(), big.double())
+        mag = corr(small.double().abs(), big.double().abs())
+        run = lambda: ops.conv_wgrad(layer, dev(small), dev(big), want_bias=False)[0]  # noqa: E731
     else:
         hb = big.shape[2]
         pad = lambda r: F.pad(r, (0, hb - r.shape[3], 0, hb - r.shape[2]))  # noqa: E731
