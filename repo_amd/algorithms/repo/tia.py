@@ -77,8 +77,11 @@ class TIA(Dreamer):
         main = [p for m in self._ref_model_modules if m is not self.distractor_reward_model for p in m.parameters()]
         self.model_optimizer = FlatAdam(main, lr=c.model_lr)
         self.d_reward_optimizer = FlatAdam(list(self.distractor_reward_model.parameters()), lr=c.model_lr)
-        # data parallel: every gradient buffer is exchanged whole, in line (no bucket overlap for this algorithm)
-        self._dp_two_buckets = False
+        # data parallel: the model gradient leaves as two buckets, cut behind the encoder (the first module of the flat
+        # buffer): [both filters, the three decoders, the task reward head, the mask head) is final when the two
+        # backward chains join and goes out beside the encoder backward; the encoder's share follows in line
+        self._model_cut = self.model_optimizer.offsets[len(list(self.encoder.parameters()))]
+        self._dp_two_buckets = os.environ.get("REPO_DP_BUCKETS", "2") != "1"
         self._d_reward_has_grad = False   # zero_grad_set_to_none=False: the head's gradient exists (is not None) from
                                           # the first fitting step on
 
@@ -200,6 +203,7 @@ class TIA(Dreamer):
         ops.rssm_observe_bwd(pr_d, sv_d, gr_d, dfeat=dfeat_d, dpm=klg_d[0], dps=klg_d[1], dqm=klg_d[2], dqs=klg_d[3],
                              dembeds=dembeds_d, min_std=self.distractor_transition_model.min_std_dev)
         main.wait_stream(rs)
+        self._model_bucket_begin(tail=True)   # everything but the encoder's gradients is final: 9/10 of the buffer
         dembeds.add_(dembeds_d)
         Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=side)
         self._model_step()

@@ -255,31 +255,47 @@ def test_tia_data_parallel_two_shards_equal_full_batch():
         out["entropy"] = nz["entropy"].view(100, H - 1, N, A)[:, :, rows].reshape(100, (H - 1) * T * nb, A).contiguous()
         return out
 
-    shared = {"slot": [None] * world, "barrier": threading.Barrier(world)}
-    agents, scal, errs = [], [None] * world, []
-    for r, (lo, hi) in enumerate(bounds):
-        ag, _ = make_tia(L, hi - lo, H, A, **over)
-        ag.dp = ThreadDP(r, world, shared, Fraction(B, hi - lo))
-        ag.noise_source = shard_noise(lo, hi)
-        agents.append(ag)
+    def run_shards(two_buckets):
+        shared = {"slot": [None] * world, "barrier": threading.Barrier(world)}
+        agents, scal, errs = [], [None] * world, []
+        for r, (lo, hi) in enumerate(bounds):
+            ag, _ = make_tia(L, hi - lo, H, A, **over)
+            ag.dp = ThreadDP(r, world, shared, Fraction(B, hi - lo))
+            ag._dp_two_buckets = two_buckets
+            ag.noise_source = shard_noise(lo, hi)
+            agents.append(ag)
 
-    def run(r):
-        try:
-            torch.cuda.set_device(0)
-            lo, hi = bounds[r]
-            agents[r].update(tuple(x[:, lo:hi].contiguous() for x in batch))
-            scal[r] = dict(agents[r].last_scalars)
-        except BaseException as e:  # noqa: BLE001
-            errs.append(e)
-            shared["barrier"].abort()
+        def run(r):
+            try:
+                torch.cuda.set_device(0)
+                lo, hi = bounds[r]
+                agents[r].update(tuple(x[:, lo:hi].contiguous() for x in batch))
+                scal[r] = dict(agents[r].last_scalars)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+                shared["barrier"].abort()
 
-    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join(600)
-    assert not errs, errs
-    torch.cuda.synchronize()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(600)
+        assert not errs, errs
+        torch.cuda.synchronize()
+        return agents, scal, shared.get("buckets")
+
+    agents, scal, buckets = run_shards(True)
+    # the bucketed exchange (everything behind the encoder begun beside the encoder backward, the encoder's share in
+    # line) moves the same sums as ONE all-reduce of the whole buffer: bit-identical parameters
+    one, scal1, none = run_shards(False)
+    opt = agents[0].model_optimizer
+    cut = agents[0]._model_cut
+    assert 0 < cut == opt.offsets[len(list(agents[0].encoder.parameters()))] < opt.numel
+    assert buckets[0] == [opt.numel - cut] == buckets[1] and none is None, (buckets, none)
+    assert scal == scal1
+    for r in range(world):
+        for name in ("model_optimizer", "d_reward_optimizer", "actor_optimizer", "value_optimizer"):
+            assert torch.equal(getattr(agents[r], name).flat, getattr(one[r], name).flat), (r, name)
     for k, w in s_full.items():
         assert abs(scal[0][k] - w) <= 2e-4 * abs(w) + 1e-6, (k, scal[0][k], w)
     assert scal[0] == scal[1]

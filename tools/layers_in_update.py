@@ -51,8 +51,8 @@ def main():
         tf = fl / (avg * 1e-6) / 1e12 if fl else None
         print(f"  {calls:9.1f} {avg:9.1f} {float(r['TotalDurationNs']) / nupd / 1e3:9.1f} "
               f"{(f'{tf:8.1f}' if tf else '       -')} {(f'{tf / PEAK:6.3f}' if tf else '     -')}  {name[:100]}")
-        if name.startswith("uconv_scatter_kernel<Geo<32, 64, 30, 6>"):
-            dom = {"kernel": "uconv_scatter_kernel<GDec3>", "nimg": NIMG, "avg_ms_in_update": round(avg / 1e3, 4),
+        if name.startswith("buconv_scatter_kernel<Geo<32, 64, 30, 6>") or name.startswith("uconv_scatter_kernel<Geo<32, 64, 30, 6>"):
+            dom = {"kernel": name.split("<")[0] + "<GDec3>", "nimg": NIMG, "avg_ms_in_update": round(avg / 1e3, 4),
                    "calls_per_update": round(calls, 2),
                    "frac_at_rocprof_duration": round(tf / PEAK, 4)}
     if "--json" in sys.argv and dom:
