@@ -303,7 +303,8 @@ def test_tia_data_parallel_two_shards_equal_full_batch():
         for name in ("model_optimizer", "d_reward_optimizer", "actor_optimizer", "value_optimizer"):
             e = (getattr(agents[r], name).flat - getattr(full, name).flat).abs().max().item()
             log(f"[tia dp 2 shards] rank {r} {name}: max |param diff| vs full batch {e:.2e}")
-            assert e < 2e-5, (name, e)
+            # (first Adam step: lr * g / (|g| + eps) amplifies summation-order noise on elements with |g| ~ eps; lr = 3e-4)
+            assert e < 5e-5, (name, e)
     assert torch.equal(agents[0].model_optimizer.flat, agents[1].model_optimizer.flat)
     assert torch.equal(agents[0].d_reward_optimizer.flat, agents[1].d_reward_optimizer.flat)
 
