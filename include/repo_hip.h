@@ -73,6 +73,9 @@ int repo_debug_scan_spin_limit(int polls);
 int repo_debug_bgemm(int enable);
 /* The same switch for the bf16x6 stride-2 "down" convolution kernel (csrc/bconv.h). */
 int repo_debug_bconv(int enable);
+/* The same switch for the bf16x6 32-row-tile engines (csrc/rowtile32.h: the imagination rollout and the dense heads);
+ * 0 = the 16-row fp32-MFMA engines of rowtile.h. */
+int repo_debug_rowtile32(int enable);
 
 /* ------------------------------------------------------------------ reparameterisation noise
  * The reference draws its noise from torch's global generator (torch.randn_like in models/rssm.py:49,61-63;

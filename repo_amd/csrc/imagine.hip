@@ -208,6 +208,16 @@ int imagine_fused_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, i
                       const float* dfeat, const float* dprior_mean, const float* dprior_std, float* d_araw,
                       float* dfeat0, void* ws, hipStream_t stream);
 
+// the same rollout on 32-row tiles and the bf16 matrix pipe (imagine32.hip)
+bool imagine32_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers, int64_t C);
+size_t imagine32_fwd_ws_bytes(int64_t A, int64_t D, int64_t Hd, int64_t S);
+int imagine32_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp,
+                  const float* const* ap, const float* belief0, const float* state0, const float* cond, int64_t C,
+                  NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std, float a_init_std,
+                  float a_mean_scale, float* featx, float* prior_mean, float* prior_std, float* a_hidden,
+                  int64_t a_layer_rows, float* a_raw, float* a_mean, float* a_std, float* xsa, float* e, float* gates,
+                  float* hp, void* ws, hipStream_t stream);
+
 // fused dense heads (mlp16.hip)
 bool mlp_fused_ok(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers);
 size_t mlp_fused_ws_floats(int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers);
@@ -393,7 +403,9 @@ extern "C" size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, i
                                                         int64_t S) {
   // per-step engine: gate / head scratch + room to materialise the two noise tensors when they are drawn in-library
   const size_t unfused = ((size_t)N * (6 * D + 2 * S) + (size_t)Hm * N * (A + S)) * sizeof(float);
-  const size_t fused = imagine_fused_fwd_ws_floats(A, D, Hd, S) * sizeof(float);
+  size_t fused = imagine_fused_fwd_ws_floats(A, D, Hd, S) * sizeof(float);
+  const size_t fused32 = imagine32_fwd_ws_bytes(A, D, Hd, S);
+  if (fused32 > fused) fused = fused32;
   return unfused > fused ? unfused : fused;
 }
 
@@ -417,6 +429,12 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
   REPO_REQUIRE(C >= 0 && (C == 0 || cond), REPO_E_BADARG);
   // a conditioned rollout runs on the persistent engine only (the condition rides in the K padding of its tiles)
   REPO_REQUIRE(C == 0 || imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers, C), REPO_E_SHAPE);
+  if (imagine32_ok(Hm, N, A, D, Hd, S, n_actor_layers, C))
+    return imagine32_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0, cond, C,
+                         NoiseSrc{eps_act, noise_seed, noise_offset},
+                         NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std,
+                         a_init_std, a_mean_scale, featx, prior_mean, prior_std, a_hidden, a_layer_rows, a_raw, a_mean,
+                         a_std, xsa, e, gates, hp, ws, stream);
   if (imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers, C))
     return imagine_fused_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0, cond, C,
                              NoiseSrc{eps_act, noise_seed, noise_offset},

@@ -142,6 +142,11 @@ __device__ __forceinline__ void dense_run(const float* A, WWin& w, __amdgpu_buff
   if (w.two) epi(c1 < N, c1, acc1);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): every global store of
+// saved activations still in flight (an acknowledgement from L2 takes a microsecond under load) would be waited for at
+// every layer boundary.  Nothing a workgroup stores to global memory in these kernels is read back by it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- quads.  Tile side: columns n0 .. n0+3 (n0 % 4 == 0) of tile row m are one 16-byte word.
 __device__ __forceinline__ f32x4v ldq(const float* T, int n0, int m) {
   return *reinterpret_cast<const f32x4v*>(T + ((n0 >> 2) * kR + m) * 4);
@@ -157,18 +162,24 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t arsrc(const float* p) {  // whole address space behind p
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xfffffffcu, 0x00020000);
 }
+#ifndef RT_STORE_AUX
+#define RT_STORE_AUX 0
+#endif
 __device__ __forceinline__ void bstq(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4v& v, int nv) {
+#ifdef RT_NO_STORE  // ablation build (tools/build_variant.sh): results wrong, time meaningful
+  if (v[0] != 123.456f) return;
+#endif
   // The elements of a ragged quad are copied out BEFORE the branch and pinned in registers of their own: with the
   // extraction inside the else-branch the compiler (ROCm 7.2) stored element 0 three times (the other side of the
   // branch ends the vector's live range).
   float e0 = v[0], e1 = v[1], e2 = v[2];
   asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2));
   if (nv >= 4) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, soff, RT_STORE_AUX);
   } else {
-    if (nv > 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e0), r, voff, soff, 0);
-    if (nv > 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e1), r, voff + 4u, soff, 0);
-    if (nv > 2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e2), r, voff + 8u, soff, 0);
+    if (nv > 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e0), r, voff, soff, RT_STORE_AUX);
+    if (nv > 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e1), r, voff + 4u, soff, RT_STORE_AUX);
+    if (nv > 2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e2), r, voff + 8u, soff, RT_STORE_AUX);
   }
 }
 __device__ __forceinline__ f32x4v bldq(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {  // a whole quad
