@@ -56,3 +56,4 @@ for name in ("featx", "prior_mean", "prior_std", "a_hidden", "a_raw", "a_mean", 
 for flag in (0, 1):
     lib().repo_debug_rowtile32(flag)
     print(f"imagine fwd, rowtile32={flag}: {timeit(lambda: ops.rssm_imagine_fwd(rp, ap, b0, s0, ea, ep)):.1f} us")
+
