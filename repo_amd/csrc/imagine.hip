@@ -218,6 +218,13 @@ int imagine32_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64
                   int64_t a_layer_rows, float* a_raw, float* a_mean, float* a_std, float* xsa, float* e, float* gates,
                   float* hp, void* ws, hipStream_t stream);
 
+size_t imagine32_bwd_ws_bytes(int64_t A, int64_t D, int64_t Hd, int64_t S);
+int imagine32_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp, int64_t C,
+                  NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std, float a_mean_scale,
+                  const float* featx, const float* prior_std, const float* a_mean, const float* a_std, const float* xsa,
+                  const float* e, const float* gates, const float* hp, const float* dfeat, const float* dprior_mean,
+                  const float* dprior_std, float* d_araw, float* dfeat0, void* ws, hipStream_t stream);
+
 // fused dense heads (mlp16.hip)
 bool mlp_fused_ok(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers);
 size_t mlp_fused_ws_floats(int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers);
@@ -490,7 +497,8 @@ extern "C" size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, i
                                                         int64_t S) {
   // g(F) carry(F) dpout(2S) dhp(Hd) dbel(D) dgi(3D) dgh(3D) de(D) dxsa(S+A) + the two noise tensors
   const size_t unfused = ((size_t)N * (2 * (D + S) + 2 * S + Hd + D + 6 * D + D + (S + A)) + (size_t)Hm * N * (A + S)) * sizeof(float);
-  const size_t fused = imagine_fused_bwd_ws_floats(A, D, Hd, S) * sizeof(float);
+  size_t fused = imagine_fused_bwd_ws_floats(A, D, Hd, S) * sizeof(float);
+  if (fused < imagine32_bwd_ws_bytes(A, D, Hd, S)) fused = imagine32_bwd_ws_bytes(A, D, Hd, S);
   return unfused > fused ? unfused : fused;
 }
 
@@ -509,6 +517,11 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_bwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
   REPO_REQUIRE(C == 0 || imagine_fused_ok(Hm, N, A, D, Hd, S, 5, C), REPO_E_SHAPE);
+  if (imagine32_ok(Hm, N, A, D, Hd, S, 5, C))
+    return imagine32_bwd(Hm, N, A, D, Hd, S, rssm_params, C, NoiseSrc{eps_act, noise_seed, noise_offset},
+                         NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std,
+                         a_mean_scale, featx, prior_std, a_mean, a_std, xsa, e, gates, hp, dfeat, dprior_mean,
+                         dprior_std, d_araw, dfeat0, ws, stream);
   if (imagine_fused_ok(Hm, N, A, D, Hd, S, 5, C))
     return imagine_fused_bwd(Hm, N, A, D, Hd, S, rssm_params, C, NoiseSrc{eps_act, noise_seed, noise_offset},
                              NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_mean_scale,

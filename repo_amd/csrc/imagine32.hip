@@ -292,6 +292,263 @@ __global__ __launch_bounds__(512) void imagine32_fwd_kernel(Img32FwdArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ reverse pass
+// The reverse rollout through the frozen world model (dreamer.py:357) for the same 32 rows per workgroup.  Gradient
+// CARRIES (d belief, d state) stay fp32 in LDS; what multiplies a weight matrix is written as bf16 planes by the phase
+// that produces it.  LDS holds two 208-column plane tiles: the four gate deltas pass through them in two rounds
+// (r, z; then n * r, n), the accumulators of the two products (into belief_t and into e) wait in registers in between.
+constexpr int kPDb = 3;   // (the epilogues' operands -- saved gates, belief_t -- are requested ahead too: registers)
+typedef WWin32<kPDb> WinB;
+struct Img32BwdArgs {
+  int Hm, N, A, D, Hd, S, C;
+  const char* wpack;   // transposed packs: W'(n = input index, k = output index)
+  unsigned wbytes;
+  unsigned Wsp, Wbp, Whh_rz, Wih_rz, Whh_n, Wih_n, Wsa;
+  NoiseSrc eps_act, eps_prior;
+  float min_std, a_min_std, a_mean_scale;
+  const float *featx, *prior_std, *a_mean, *a_std, *xsa, *e, *gates, *hp;
+  const float *dfeat, *dprior_mean, *dprior_std;
+  float *d_araw, *dfeat0;
+};
+
+template <int BW, int BS2>   // BS2: 16-k blocks of 2 S
+__global__ __launch_bounds__(512) void imagine32_bwd_kernel(Img32BwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds32[];
+  const int Hm = p.Hm, N = p.N, A = p.A, D = p.D, Hd = p.Hd, S = p.S;
+  const int F = D + S, X = S + A, XL = X + p.C;
+  constexpr int psH = 1024 * BW, psS = 1024 * BS2;
+  constexpr int WC = 16 * BW;                         // columns of a wide tile
+  char* XA = lds32;
+  char* XB = XA + 3 * psH;
+  char* SMp = XB + 3 * psH;                           // planes: d [prior mean | raw std]
+  float* Gb = reinterpret_cast<float*>(SMp + 3 * psS);  // fp32 quads [WC x 32]: d belief carry
+  float* Gs = Gb + WC * kR32;                         // [32 x 32]: d state
+  float* SMa = Gs + 32 * kR32;                        // [48 x 32]: d [state | action] of this step
+  constexpr int lds_bytes = 6 * psH + 3 * psS + (WC + 32 + 48) * kR32 * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int r0 = blockIdx.x * kR32;
+  const int nr = min(kR32, N - r0);
+  const __amdgpu_buffer_rsrc_t rw = wrsrc(reinterpret_cast<const float*>(p.wpack), p.wbytes);
+  const __amdgpu_buffer_rsrc_t q_hp = arsrc(p.hp), q_e = arsrc(p.e), q_gates = arsrc(p.gates), q_featx = arsrc(p.featx);
+  const __amdgpu_buffer_rsrc_t q_dfeat =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dfeat), 0, 0x7fffffff, 0x00020000);  // 2 GB window: 0x80000000 reads 0
+  const unsigned lrow = (unsigned)(r0 + min(li, nr - 1));
+  const int xf = xfrag32(lane);
+  const int c0 = wave * 32 + 4 * lh;
+
+  for (int i = tid; i < lds_bytes / 16; i += 512) reinterpret_cast<f32x4v*>(lds32)[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int ntD = (D + 31) >> 5, ntH = (Hd + 31) >> 5, ntX = (X + 31) >> 5;
+  // three windows: W_sp's (4 blocks) has one of its own, the other six streams of a step alternate between two
+  WinB wa, wb, wc;
+  wopen32<BS2, kPDb, false>(wc, rw, wave < ntH, p.Wsp, 0, Hd, min(wave, ntH - 1), lane);
+  for (int t = Hm - 1; t >= 0; --t) {
+    const size_t rb = (size_t)t * N + r0;
+    const unsigned tN = (unsigned)(t * N);
+    // ---- G += dfeat[t]; the prior head's sample / mean / std gradients -> d [mean | raw_std].  Everything the two
+    //      phases read from global memory is requested first (one exposed round trip instead of one per loop
+    //      iteration); a thread takes quads of dfeat with consecutive lanes on consecutive rows (LDS: contiguous)
+    {
+      constexpr int NQ = 4;  // quads of dfeat per thread: 32 rows x (F / 4 rounded up) <= 2048
+      f32x4v dq[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int u = tid + 512 * j, row = u & 31, qc = u >> 5;
+        const bool ok = 4 * qc < F && row < nr;
+        dq[j] = bldq(q_dfeat, ok ? 4u * ((unsigned)(r0 + row) * F + 4u * qc) : 0x80000000u, 4u * tN * F);
+      }
+      float pstd[2], pe[2], pdm[2], pds[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int u = tid + 512 * j, row = u & 31, sidx = u >> 5;
+        const bool ok = sidx < S && row < nr;
+        const size_t o = ok ? (rb + row) * S + sidx : 0;
+        pstd[j] = ok ? p.prior_std[o] : p.min_std;
+        pe[j] = ok ? p.eps_prior.at(o) : 0.f;
+        pdm[j] = (ok && p.dprior_mean) ? p.dprior_mean[o] : 0.f;
+        pds[j] = (ok && p.dprior_std) ? p.dprior_std[o] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int u = tid + 512 * j, row = u & 31, qc = u >> 5;
+        if (4 * qc < F) {
+          float* g = 4 * qc < D ? Gb + fq(4 * qc, row) : Gs + fq(4 * qc - D, row);
+          f32x4v v = *reinterpret_cast<f32x4v*>(g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (4 * qc + e < F) ? dq[j][e] : 0.f;  // (a quad straddling the row's end)
+          *reinterpret_cast<f32x4v*>(g) = v;
+        }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int u = tid + 512 * j, row = u & 31, sidx = u >> 5;
+        if (sidx < S) {
+          const float ds = row < nr ? Gs[fq(sidx, row)] : 0.f;
+          const float gm = ds + pdm[j];
+          const float gr = fmaf(ds, pe[j], pds[j]) * (-expm1f(-(pstd[j] - p.min_std)));
+          st1_32(SMp, psS, sidx, row, row < nr ? gm : 0.f);
+          st1_32(SMp, psS, S + sidx, row, row < nr ? gr : 0.f);
+        }
+      }
+    }
+    lds_barrier();
+    // ---- XB = (d out @ W_sp) * elu'(hp)
+    wopen32<BW, kPDb, false>(wa, rw, wave < ntD, p.Wbp, 0, D, min(wave, ntD - 1), lane);
+    if (wc.act) {
+      f32x4v h[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h[i] = bldq(q_hp, 4u * (lrow * Hd + (unsigned)min(c0 + 8 * i, Hd - 4)), 4u * tN * Hd);
+      f32x16v c = zero16();
+      wrun32<BS2, kPDb>(c, SMp + xf, psS, wc, rw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (wave * 32 + 8 * i < WC) {
+          const f32x4v a = quad(c, i);
+          f32x4v v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (c0 + 8 * i < Hd) ? a[r] * elu_grad_from_out(h[i][r]) : 0.f;
+          stq32(XB, psH, c0 + 8 * i, li, v);
+        }
+      }
+    }
+    lds_barrier();
+    // ---- d belief_{t+1} = Gb + XB @ W_bp, and the GRU's gate deltas from it in the same registers (a lane's quads:
+    //      4 columns of its row): g_r -> XA at once, g_z -> XB behind the barrier (XB is this product's operand);
+    //      g_n and g_n * r wait in registers for the second round; Gb <- d * z.  The saved gates and belief_t are
+    //      requested before the MFMA chain.
+    f32x16v gz16 = zero16(), gn16 = zero16(), gnr16 = zero16();
+    wopen32<2 * BW, kPDb, false>(wb, rw, wave < ntD, p.Whh_rz, 0, D, min(wave, ntD - 1), lane);
+    if (wa.act) {
+      f32x4v rq[4], zq[4], nq[4], hq[4], pq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned col = (unsigned)min(c0 + 8 * i, D - 4);
+        const unsigned gv = 4u * (lrow * 4 * D + col), gs = 4u * tN * 4 * D;
+        rq[i] = bldq(q_gates, gv, gs);
+        zq[i] = bldq(q_gates, gv + 4u * D, gs);
+        nq[i] = bldq(q_gates, gv + 8u * D, gs);
+        hq[i] = bldq(q_gates, gv + 12u * D, gs);
+        pq[i] = bldq(q_featx, 4u * (lrow * F + col), 4u * tN * F);
+      }
+      f32x16v c = zero16();
+      wrun32<BW, kPDb>(c, XB + xf, psH, wa, rw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (wave * 32 + 8 * i < WC) {
+          const int o = fq(c0 + 8 * i, li);
+          const bool in = c0 + 8 * i < D && li < nr;
+          const f32x4v d = quad(c, i) + *reinterpret_cast<const f32x4v*>(Gb + o);
+          f32x4v g_r, g_z, g_n, g_nr, dhp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float rg = rq[i][r], zg = zq[i][r], ng = nq[i][r];
+            g_n[r] = in ? d[r] * (1.f - zg) * (1.f - ng * ng) : 0.f;
+            g_z[r] = in ? d[r] * (pq[i][r] - ng) * zg * (1.f - zg) : 0.f;
+            g_r[r] = g_n[r] * hq[i][r] * rg * (1.f - rg);
+            g_nr[r] = g_n[r] * rg;
+            dhp[r] = in ? d[r] * zg : 0.f;
+          }
+          stq32(XA, psH, c0 + 8 * i, li, g_r);
+          *reinterpret_cast<f32x4v*>(Gb + o) = dhp;
+          set_quad(gz16, i, g_z);
+          set_quad(gn16, i, g_n);
+          set_quad(gnr16, i, g_nr);
+        }
+      }
+    }
+    lds_barrier();  // every wave has read XB
+    if (wa.act) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (wave * 32 + 8 * i < WC) stq32(XB, psH, c0 + 8 * i, li, quad(gz16, i));
+    }
+    lds_barrier();
+    // ---- through W_hh into belief_t (ah) and through W_ih into e (ae): [r | z] first ...
+    f32x16v ah = zero16(), ae = zero16();
+    wopen32<2 * BW, kPDb, false>(wa, rw, wave < ntD, p.Wih_rz, 0, D, min(wave, ntD - 1), lane);
+    if (wb.act) wrun32<2 * BW, kPDb, BW>(ah, XA + xf, psH, wb, rw, XB + xf, psH);
+    wopen32<BW, kPDb, false>(wb, rw, wave < ntD, p.Whh_n, 0, D, min(wave, ntD - 1), lane);
+    if (wa.act) wrun32<2 * BW, kPDb, BW>(ae, XA + xf, psH, wa, rw, XB + xf, psH);
+    wopen32<BW, kPDb, false>(wa, rw, wave < ntD, p.Wih_n, 0, D, min(wave, ntD - 1), lane);
+    lds_barrier();  // every wave has read g_r, g_z
+    // ---- ... second round: XA <- g_n * r, XB <- g_n
+    if (wa.act) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (wave * 32 + 8 * i < WC) {
+          stq32(XA, psH, c0 + 8 * i, li, quad(gnr16, i));
+          stq32(XB, psH, c0 + 8 * i, li, quad(gn16, i));
+        }
+      }
+    }
+    lds_barrier();
+    {
+      f32x4v ev[4];
+      if (wb.act) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ev[i] = bldq(q_e, 4u * (lrow * D + (unsigned)min(c0 + 8 * i, D - 4)), 4u * tN * D);
+        wrun32<BW, kPDb>(ah, XA + xf, psH, wb, rw);
+      }
+      wopen32<BW, kPDb, false>(wb, rw, wave < ntX, p.Wsa, 0, X, min(wave, ntX - 1), lane);
+      if (wa.act) wrun32<BW, kPDb>(ae, XB + xf, psH, wa, rw);
+      lds_barrier();  // every wave has read the gate tiles
+      if (wa.act) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (wave * 32 + 8 * i < WC) {
+            const int o = fq(c0 + 8 * i, li);
+            *reinterpret_cast<f32x4v*>(Gb + o) = *reinterpret_cast<const f32x4v*>(Gb + o) + quad(ah, i);  // new carry
+            const f32x4v a = quad(ae, i);
+            f32x4v v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (c0 + 8 * i < D) ? a[r] * elu_grad_from_out(ev[i][r]) : 0.f;
+            stq32(XA, psH, c0 + 8 * i, li, v);  // d pre-activation of fc_embed_state_action
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- d [state_t | action_t] = XA @ W_sa (the sample backward's operands are requested ahead of it)
+    wopen32<BS2, kPDb, false>(wc, rw, wave < ntH, p.Wsp, 0, Hd, min(wave, ntH - 1), lane);  // the next (earlier) step's first layer
+    const int prow = tid & 31, pa_ = tid >> 5;
+    const bool pok = pa_ < A && prow < nr;
+    const size_t po = pok ? (rb + prow) * A + pa_ : 0;
+    const float p_act = pok ? p.xsa[(rb + prow) * XL + S + pa_] : 0.f;
+    const float p_mean = pok ? p.a_mean[po] : 0.f, p_std = pok ? p.a_std[po] : p.a_min_std;
+    const float p_eps = pok ? p.eps_act.at(po) : 0.f;
+    if (wb.act) {
+      f32x16v c = zero16();
+      wrun32<BW, kPDb>(c, XA + xf, psH, wb, rw);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = c0 + 8 * (e >> 2) + (e & 3);
+        if (n < S) Gs[fq(n, li)] = c[e];
+        else if (n < X) SMa[fq(n, li)] = c[e];
+      }
+    }
+    lds_barrier();
+    // ---- tanh-Normal sample backward -> gradient at the actor trunk's output of step t
+    if (pok) {
+      const float du = SMa[fq(S + pa_, prow)] * (1.f - p_act * p_act);
+      const float tm = p_mean / p.a_mean_scale;
+      p.d_araw[(rb + prow) * 2 * A + pa_] = du * (1.f - tm * tm);
+      p.d_araw[(rb + prow) * 2 * A + A + pa_] = du * p_eps * (-expm1f(-(p_std - p.a_min_std)));
+    }
+    lds_barrier();
+  }
+  if (p.dfeat0) {
+    for (int i = tid; i < kR32 * F; i += 512) {
+      const int row = i / F, f = i % F;
+      if (row < nr) p.dfeat0[(size_t)(r0 + row) * F + f] = f < D ? Gb[fq(f, row)] : Gs[fq(f - D, row)];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 constexpr int kBF32 = 15, kBW32 = 13, kBX32 = 3;
 #ifndef RT32_DEFAULT
@@ -372,6 +629,57 @@ int imagine32_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64
   a.gates_bytes = (unsigned)((size_t)Hm * N * 4 * D * sizeof(float));
   constexpr int lds_b = 3 * 1024 * kBF32 + 6 * 1024 * kBW32 + 3 * 1024 * kBX32 + 64 * kR32 * 4;
   auto kern = imagine32_fwd_kernel<kBF32, kBW32, kBX32>;
+  hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+  if (he != hipSuccess) return (int)he;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((N + kR32 - 1) / kR32)), dim3(512), lds_b, stream, a);
+  he = hipGetLastError();
+  return he == hipSuccess ? REPO_OK : (int)he;
+}
+
+size_t imagine32_bwd_ws_bytes(int64_t A, int64_t D, int64_t Hd, int64_t S) {
+  return pack32_bytes(Hd, 2 * S) + pack32_bytes(D, Hd) + 6 * pack32_bytes(D, D) + pack32_bytes(S + A, D) + 256;
+}
+
+int imagine32_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, const float* const* rp, int64_t C,
+                  NoiseSrc eps_act, NoiseSrc eps_prior, float min_std, float a_min_std, float a_mean_scale,
+                  const float* featx, const float* prior_std, const float* a_mean, const float* a_std, const float* xsa,
+                  const float* e, const float* gates, const float* hp, const float* dfeat, const float* dprior_mean,
+                  const float* dprior_std, float* d_araw, float* dfeat0, void* ws, hipStream_t stream) {
+  const int X = (int)(S + A);
+  char* w = (char*)ws;
+  char* const w_begin = w;
+  Img32BwdArgs a;
+  a.Hm = (int)Hm, a.N = (int)N, a.A = (int)A, a.D = (int)D, a.Hd = (int)Hd, a.S = (int)S, a.C = (int)C;
+  Pack32Args pa;
+  pa.njobs = 0;
+  // W'(n = input index, k = output index) = native[k * ld + n]
+  auto mat = [&](const float* src, int Nin, int Kout, int ld) {
+    pa.job[pa.njobs++] = Pack32Job{src, w, Nin, Kout, 1, ld, 0, nullptr};
+    const unsigned r = (unsigned)(w - w_begin);
+    w += pack32_bytes(Nin, Kout);
+    return r;
+  };
+  a.Wsp = mat(rp[8], (int)Hd, (int)(2 * S), (int)Hd);
+  a.Wbp = mat(rp[6], (int)D, (int)Hd, (int)D);
+  a.Whh_rz = mat(rp[3], (int)D, (int)D, (int)D);                 // [r | z] along K: two packs back to back
+  mat(rp[3] + (size_t)D * D, (int)D, (int)D, (int)D);
+  a.Wih_rz = mat(rp[2], (int)D, (int)D, (int)D);
+  mat(rp[2] + (size_t)D * D, (int)D, (int)D, (int)D);
+  a.Whh_n = mat(rp[3] + (size_t)2 * D * D, (int)D, (int)D, (int)D);
+  a.Wih_n = mat(rp[2] + (size_t)2 * D * D, (int)D, (int)D, (int)D);
+  a.Wsa = mat(rp[0], X, (int)D, X + (int)C);  // the rows of d [state|action] only: the condition takes no gradient
+  a.wpack = w_begin;
+  a.wbytes = (unsigned)(w - w_begin);
+  int rc = launch_pack32(pa, stream);
+  if (rc) return rc;
+  a.eps_act = eps_act, a.eps_prior = eps_prior;
+  a.min_std = min_std, a.a_min_std = a_min_std, a.a_mean_scale = a_mean_scale;
+  a.featx = featx, a.prior_std = prior_std, a.a_mean = a_mean, a.a_std = a_std, a.xsa = xsa, a.e = e;
+  a.gates = gates, a.hp = hp, a.dfeat = dfeat, a.dprior_mean = dprior_mean, a.dprior_std = dprior_std;
+  a.d_araw = d_araw, a.dfeat0 = dfeat0;
+  constexpr int kBS2 = 4;
+  constexpr int lds_b = 6 * 1024 * kBW32 + 3 * 1024 * kBS2 + (16 * kBW32 + 32 + 48) * kR32 * 4;
+  auto kern = imagine32_bwd_kernel<kBW32, kBS2>;
   hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
   if (he != hipSuccess) return (int)he;
   hipLaunchKernelGGL(kern, dim3((unsigned)((N + kR32 - 1) / kR32)), dim3(512), lds_b, stream, a);

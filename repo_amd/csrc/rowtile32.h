@@ -166,7 +166,7 @@ __device__ __forceinline__ void wnext32(WWin32<PD>& w, __amdgpu_buffer_rsrc_t rw
 // The block addresses advance in a VECTOR register made opaque here: as scalar offsets derived from the loop-invariant
 // W the compiler hoists every one of them out of the step loop (several hundred scalars, spilled to vector lanes and
 // read back with v_readlane at each use).
-template <int NBLK, int PD>
+template <int NBLK, int PD, bool BIAS = true>
 __device__ __forceinline__ void wopen32(WWin32<PD>& w, __amdgpu_buffer_rsrc_t rw, bool act, unsigned W, unsigned B, int N,
                                         int tile, int lane) {
   const int NP = pad32(N);
@@ -178,12 +178,17 @@ __device__ __forceinline__ void wopen32(WWin32<PD>& w, __amdgpu_buffer_rsrc_t rw
   w.bstr = 96u * (unsigned)NP;
 #pragma unroll
   for (int b = 0; b < (NBLK < PD ? NBLK : PD); ++b) wnext32(w, rw, b);
-  unsigned bv = B + 4u * (unsigned)(tile * 32 + 4 * (lane >> 5));
-  asm volatile("" : "+v"(bv));
+  if (BIAS) {
+    unsigned bv = B + 4u * (unsigned)(tile * 32 + 4 * (lane >> 5));
+    asm volatile("" : "+v"(bv));
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    w.bias[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, bv + 32u * i, 0, 0));
+    for (int i = 0; i < 4; ++i)
+      w.bias[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rw, bv + 32u * i, 0, 0));
+  }
 }
+// fp32 quads in LDS (gradient carries, element-wise operands): columns c .. c+3 of one row are 16 bytes at
+// ((c / 4) * 32 + row) * 16 -- a lane's accumulator quad is one conflict-free ds_read / ds_write_b128
+__device__ __forceinline__ int fq(int c, int row) { return ((c >> 2) * kR32 + row) * 4 + (c & 3); }
 template <int PD>
 __device__ __forceinline__ f32x16v bias_acc(const WWin32<PD>& w) {
   f32x16v c;

@@ -57,3 +57,16 @@ for flag in (0, 1):
     lib().repo_debug_rowtile32(flag)
     print(f"imagine fwd, rowtile32={flag}: {timeit(lambda: ops.rssm_imagine_fwd(rp, ap, b0, s0, ea, ep)):.1f} us")
 
+# ---- reverse rollout
+dfeat = r(Hm, N, D + S, scale=0.01)
+dpm, dps = r(Hm, N, S, scale=0.01), r(Hm, N, S, scale=0.01)
+res = []
+for flag in (0, 1):
+    lib().repo_debug_rowtile32(flag)
+    sv = ops.rssm_imagine_fwd(rp, ap, b0, s0, ea, ep)
+    d_araw, dfeat0 = ops.rssm_imagine_bwd(rp, sv, dfeat, dpm, dps, want_dfeat0=True)
+    torch.cuda.synchronize()
+    res.append((d_araw.clone(), dfeat0.clone()))
+    print(f"imagine bwd, rowtile32={flag}: {timeit(lambda: ops.rssm_imagine_bwd(rp, sv, dfeat, dpm, dps, want_dfeat0=True)):.1f} us")
+for name, x, y in (("d_araw", res[0][0], res[1][0]), ("dfeat0", res[0][1], res[1][1])):
+    print(f"{name:8s} max|16-row - 32-row| = {(x - y).abs().max().item():.3e}  (max |x| = {x.abs().max().item():.3e})  finite: {bool(torch.isfinite(y).all())}")
