@@ -149,8 +149,19 @@ def test_mlp_layer_by_layer_path(ops, case):
     assert l2err(dx, x.grad) < GTOL
 
 
+@pytest.fixture(params=[1, 0], ids=["rowtile32", "rowtile16"])
+def rollout_engine(request):
+    """Both persistent rollout engines: 32-row tiles on the bf16 matrix pipe (csrc/imagine32.hip, the default) and
+    16-row tiles on the fp32 MFMA (csrc/imagine16.hip)."""
+    from repo_amd._lib import lib
+
+    prev = lib().repo_debug_rowtile32(request.param)
+    yield request.param
+    lib().repo_debug_rowtile32(prev)
+
+
 @pytest.mark.parametrize("Hm,N,A", [(4, 28, 6), (14, 300, 6), (2, 15, 7)])
-def test_imagine_fwd_bwd(ops, Hm, N, A):
+def test_imagine_fwd_bwd(ops, rollout_engine, Hm, N, A):
     rs = np.random.RandomState(Hm * 10 + N)
     D, S = 200, 30
     rp = tparams("transition_model", A, requires_grad=False)
@@ -190,6 +201,46 @@ def test_imagine_fwd_bwd(ops, Hm, N, A):
         e = l2err(g, v.grad)
         log(f"imagine bwd Hm={Hm} N={N} actor d{k}: {e:.2e}")
         assert e < GTOL
+
+
+def test_rollout_engines_agree_at_full_size_with_in_kernel_noise_and_condition(ops):
+    """The 32-row bf16x6 rollout (forward and reverse) against the 16-row fp32-MFMA one at the update's size (2450 start
+    states, a ragged last tile of 18 rows, 14 steps), noise drawn in the kernels from the same Philox stream, with and
+    without a condition: every saved tensor and both gradients agree to fp32 rounding."""
+    from repo_amd._lib import lib
+
+    rs = np.random.RandomState(5)
+    Hm, N, A, D, S = 14, 2450, 6, 200, 30
+    for C in (0, 3):
+        P = fx.make_params(A, 7, cond=C)
+        rp = [torch.tensor(v).cuda() for v in P["transition_model"].values()]
+        ap = [torch.tensor(v).cuda() for v in P["actor_model"].values()]
+        b0, s0 = rnd(rs, N, D, scale=0.3).cuda(), rnd(rs, N, S).cuda()
+        cond = None
+        if C:
+            cond = torch.zeros(N, C)
+            cond[torch.arange(N), torch.from_numpy(rs.randint(0, C, size=N))] = 1.0
+            cond = cond.cuda()
+        dfeat = rnd(rs, Hm, N, D + S, scale=0.01).cuda()
+        dpm, dps = rnd(rs, Hm, N, S, scale=0.01).cuda(), rnd(rs, Hm, N, S, scale=0.01).cuda()
+        got = {}
+        for engine in (0, 1):
+            prev = lib().repo_debug_rowtile32(engine)
+            try:
+                sv = ops.rssm_imagine_fwd(rp, ap, b0, s0, None, None, noise=(77, 1 << 20), horizon=Hm, cond=cond)
+                d_araw, dfeat0 = ops.rssm_imagine_bwd(rp, sv, dfeat, dpm, dps, want_dfeat0=True)
+                torch.cuda.synchronize()
+            finally:
+                lib().repo_debug_rowtile32(prev)
+            got[engine] = {n: getattr(sv, n).clone() for n in ("featx", "prior_mean", "prior_std", "a_hidden", "a_raw",
+                                                                "a_mean", "a_std", "xsa", "e", "gates", "hp")}
+            got[engine].update(d_araw=d_araw.clone(), dfeat0=dfeat0.clone())
+        for name, want in got[0].items():
+            x = got[1][name]
+            assert torch.isfinite(x).all(), (C, name)
+            e = (x - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+            log(f"rollout engines C={C} {name}: max |32-row - 16-row| / max |x| = {e:.2e}")
+            assert e < (2e-5 if name in ("d_araw", "dfeat0") else 1e-5), (C, name, e)
 
 
 def test_actor_head_and_entropy(ops):
