@@ -53,6 +53,13 @@ typedef struct ihipStream_t* hipStream_t;
                                 repo_decoder_out_nll for the decoder's last hidden activation, read by
                                 repo_conv_down (8.8 MB of mask instead of 282 MB of activations at 2450 frames)   */
 
+#define REPO_EPI_MUL_CMASK 6 /* multiply by relu'(x) given aux = the CHANNEL-QUAD MASK of relu(x) (bytes): for an NCHW
+                                activation x (n, C, P pixels), byte ((n * C/4 + c/4) * P + p) has bit (c & 3) set iff
+                                relu(x)[n][c][p] > 0.  Written by repo_conv_down (relu_cmask: the encoder's forward),
+                                read by repo_conv_up on the scatter kernels (layers 1-3: the encoder's data gradients,
+                                whose drain owns four channels of a pixel): 19 MB of mask instead of 301 MB of
+                                activations for the encoder's first layer at 2450 frames                           */
+
 int repo_abi_version(void);
 const char* repo_strerror(int code);
 /* REPO_OK if HIP device `device` is gfx950 (MI355X), REPO_E_ARCH if it is another architecture, REPO_E_BADARG
@@ -140,11 +147,13 @@ int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY, int64_t ld
  * reduced in a fixed order: bit-reproducible).
  * ws also holds the weight pack of the bf16x6 kernel (csrc/bconv.h: the MFMA-bound layers with an even row pitch --
  * 2, 3, 5 -- form their products as six exact bf16 partial products per fp32 multiply on the bf16 matrix pipe, same
- * accuracy); a call without ws (or with too little) runs the fp32-MFMA kernel. */
+ * accuracy); a call without ws (or with too little) runs the fp32-MFMA kernel.
+ * relu_cmask (nullable; epi = REPO_EPI_RELU, small_ch % 4 == 0): nimg * small_ch / 4 * small_pixels bytes, the
+ * output's channel-quad mask (REPO_EPI_MUL_CMASK) -- taken from the accumulators on their way out. */
 size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg);
 int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
                    const float* bias, float* small, int epi, const void* aux, float* dbias_small,
-                   int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t stream);
+                   int accumulate_dbias, unsigned char* relu_cmask, void* ws, size_t ws_bytes, hipStream_t stream);
 /* `up` works from a fragment-ready copy of the layer's weights in `ws` (layers 1..5; 0 bytes for the 3-channel
  * layers 0 and 6): at least repo_conv_up_workspace_bytes(layer).  repo_conv_up_pack writes that copy; repo_conv_up
  * writes it itself first unless ws_is_packed != 0 (the weights change once per optimiser step, not per call). */

@@ -468,7 +468,9 @@ static long conv_down_tiles(int64_t nimg) {
 
 template <class G, class BigT>
 static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const float* bias, float* small, int epi,
-                       const float* aux, float* dbias, int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+                       const float* aux, float* dbias, int accumulate_dbias, unsigned char* cmask, void* ws,
+                       size_t ws_bytes, hipStream_t s) {
+  if (cmask && G::CS % 4 != 0) return REPO_E_BADARG;
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   // workspace: [weight pack of the bf16x6 kernel | channel-sum partials]; without room for the pack the layer runs
   // on the fp32-MFMA kernel (ws stays optional for callers that want no dbias)
@@ -488,7 +490,7 @@ static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const floa
   if (dbias && (!ws || ws_bytes < pack_bytes + (size_t)tiles * G::CS * sizeof(float))) return REPO_E_WS_TOO_SMALL;
   float* parts = dbias ? (float*)((char*)ws + pack_bytes) : nullptr;
   DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
-             (unsigned)(G::CS * G::CB * G::KK * sizeof(float)), parts};
+             (unsigned)(G::CS * G::CB * G::KK * sizeof(float)), parts, cmask};
   int rc;
   if constexpr (kBDown<G> && std::is_same<BigT, float>::value) {
     if (bf) rc = launch_bconv_down<G, typename BDownFor<G>::type>(a, w, (char*)ws, s);
@@ -611,6 +613,8 @@ static int conv_up_t(int64_t nimg, const float* small, const float* w, const flo
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   using UC = typename UConf<G>::type;
   using BC = typename BUConf<G>::type;
+  // the channel-quad mask is what the scatter kernels' drain reads (a pixel's four channels per item)
+  if (epi == REPO_EPI_MUL_CMASK && (kUpDirect<G> || std::is_void<UC>::value || G::CB % 4 != 0)) return REPO_E_BADARG;
   if constexpr (!std::is_void<BC>::value)
     if (buconv_on<G>()) return launch_buconv_scatter<G, BC>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   if constexpr (kUpDirect<G>) {
@@ -719,24 +723,26 @@ using namespace repo;
 
 extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_is_u8, const float* w,
                               const float* bias, float* small, int epi, const void* aux_, float* dbias_small,
-                              int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t stream) {
+                              int accumulate_dbias, unsigned char* relu_cmask, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(big && w && small, REPO_E_BADARG);
   REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU ||
                    ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_MASK4) && aux_), REPO_E_BADARG);
+  REPO_REQUIRE(!relu_cmask || epi == REPO_EPI_RELU, REPO_E_BADARG);
   const float* aux = (const float*)aux_;  // fp32 activations, or the quad mask's bytes (REPO_EPI_MUL_MASK4)
   if (big_is_u8) {
     REPO_REQUIRE(layer == 0 || layer == 7, REPO_E_BADARG);
     if (layer == 7)
       return conv_down_t<GX1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, dbias_small,
-                                       accumulate_dbias, ws, ws_bytes, stream);
+                                       accumulate_dbias, relu_cmask, ws, ws_bytes, stream);
     return conv_down_t<GEnc1, uint8_t>(nimg, (const uint8_t*)big, w, bias, small, epi, aux, dbias_small,
-                                       accumulate_dbias, ws, ws_bytes, stream);
+                                       accumulate_dbias, relu_cmask, ws, ws_bytes, stream);
   }
   REPO_LAYER_SWITCH(layer, return (conv_down_t<G, float>(nimg, (const float*)big, w, bias, small, epi, aux, dbias_small,
-                                                         accumulate_dbias, ws, ws_bytes, stream)))
+                                                         accumulate_dbias, relu_cmask, ws, ws_bytes, stream)))
 }
 
 extern "C" size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg) {
@@ -764,7 +770,8 @@ extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const f
   REPO_REQUIRE(nimg >= 0, REPO_E_SHAPE);
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(small && w && big, REPO_E_BADARG);
-  REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU || (epi == REPO_EPI_MUL_DRELU && aux), REPO_E_BADARG);
+  REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU ||
+                   ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_CMASK) && aux), REPO_E_BADARG);
   REPO_LAYER_SWITCH(layer, return (conv_up_t<G>(nimg, small, w, bias, big, epi, aux, ws_is_packed, ws, ws_bytes, stream)))
 }
 

@@ -95,6 +95,7 @@ struct DownArgs {
   int nimg, epi;
   unsigned big_bytes, w_bytes;
   float* chan_part;  // nullable: [pixel tiles][CS] sums of the written values per output channel (bias gradients)
+  unsigned char* cmask;  // nullable (REPO_EPI_RELU): the output's CHANNEL-QUAD mask, repo_hip.h REPO_EPI_MUL_CMASK
 };
 
 // The epilogue of the stride-2 "down" kernels (dconv_down_kernel here, bconv_down_kernel in bconv.h): `acc` holds the
@@ -191,6 +192,31 @@ __device__ __forceinline__ void dconv_down_epilogue(const DownArgs& p, float* ld
           qs += __shfl_xor(qs, 2, 64);
           qs += __shfl_xor(qs, 4, 64);
           csum[i][pass] += qs;
+        }
+      }
+      if (p.cmask) {  // wave-uniform.  A lane: channel quad lane / 8 of the tile's 32 channels, pixels 4 (lane % 8) .. + 3:
+        // one byte per pixel, bit c = relu(channel 4 quad + c) > 0 -- what the layer's data gradient needs of the
+        // activation (its drain owns four channels of a pixel: one byte instead of four floats)
+        const int cq = lane >> 3, q = lane & 7;
+        const int m4 = mt + 4 * cq, n = nb + 4 * q;
+        if (m4 < G::CS && n < Ntot) {
+          f32x4 rws[4];
+          float bq[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            rws[c] = *reinterpret_cast<const f32x4*>(strip + (4 * cq + c) * EP + 4 * q);
+            bq[c] = p.bias ? p.bias[m4 + c] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ne = n + e;
+            if (ne < Ntot) {
+              unsigned bits = 0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) bits |= (rws[c][e] + bq[c] > 0.f ? 1u : 0u) << c;
+              p.cmask[((size_t)(ne / G::PS) * (G::CS / 4) + (m4 >> 2)) * G::PS + ne % G::PS] = (unsigned char)bits;
+            }
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();

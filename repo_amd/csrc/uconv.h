@@ -277,6 +277,21 @@ __device__ __forceinline__ void uconv_drain(const UScatArgs& p, float* planes, i
         w[u][e] = f32x4acc{0.f, 0.f, 0.f, 0.f};
         if (e < nv[u]) w[u][e] = ibase[(((y & 1) << 1) | (x & 1)) * 4 * PLANE + (y >> 1) * NXM + (x >> 1)];
       }
+      if (p.epi == REPO_EPI_MUL_CMASK) {
+        // channel-quad mask: one byte per pixel, bit i = channel cb + i; the quad's four bytes are one aligned dword
+        // (PB % 4 == 0 here); a ragged quad reads its bytes one by one
+        const unsigned char* cm = reinterpret_cast<const unsigned char*>(p.aux) +
+                                  ((size_t)(img0 + il) * (G::CB / 4) + (cb >> 2)) * PB + f0;
+        unsigned word = 0;
+        if (nv[u] == 4) word = *reinterpret_cast<const unsigned*>(cm);
+        else
+          for (int e = 0; e < 3; ++e)
+            if (e < nv[u]) word |= (unsigned)cm[e] << (8 * e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) msk[u][i][e] = (word >> (8 * e + i)) & 1u ? 1.f : 0.f;
+      }
       if (p.epi == REPO_EPI_MUL_DRELU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -301,7 +316,7 @@ __device__ __forceinline__ void uconv_drain(const UScatArgs& p, float* planes, i
         for (int e = 0; e < 4; ++e) {
           float x = w[u][e][i] + bv[i];
           if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
-          else if (p.epi == REPO_EPI_MUL_DRELU) x = msk[u][i][e] > 0.f ? x : 0.f;
+          else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_CMASK) x = msk[u][i][e] > 0.f ? x : 0.f;
           t[e] = x;
         }
         const unsigned o = gofs[u] + (unsigned)i * PB;
@@ -359,6 +374,11 @@ __device__ __forceinline__ void uconv_drain1(const UScatArgs& p, float* planes, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) msk[u][i] = p.aux[gofs[u] + (size_t)i * PB];
       }
+      if (p.epi == REPO_EPI_MUL_CMASK && act[u]) {  // one byte: the item's four channels (64 lanes: 64 contiguous bytes)
+        const unsigned b = reinterpret_cast<const unsigned char*>(p.aux)[((size_t)(img0 + il) * (G::CB / 4) + (cb >> 2)) * PB + f];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) msk[u][i] = (b >> i) & 1u ? 1.f : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -367,7 +387,7 @@ __device__ __forceinline__ void uconv_drain1(const UScatArgs& p, float* planes, 
       for (int i = 0; i < 4; ++i) {
         float t = val[u][i] + bv[i];
         if (p.epi == REPO_EPI_RELU) t = fmaxf(t, 0.f);
-        else if (p.epi == REPO_EPI_MUL_DRELU) t = msk[u][i] > 0.f ? t : 0.f;
+        else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_CMASK) t = msk[u][i] > 0.f ? t : 0.f;
         p.out[gofs[u] + (size_t)i * PB] = t;
       }
     }

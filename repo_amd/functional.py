@@ -19,14 +19,19 @@ def encoder_fwd(p, obs):
     """VisualEncoder.forward (models/encoder.py:34-41).  obs (n,3,64,64) [or (n,3,128,128)] uint8 or float32.
     p = [conv1.w, conv1.b, ..., conv4.w, conv4.b (, fc.w, fc.b)].  Returns (embeds (n,1024), saved)."""
     L = _ENC[obs.shape[-1]]
-    h1 = ops.conv_down(L[0], obs, p[0], p[1], epi=ops.EPI_RELU)
-    h2 = ops.conv_down(L[1], h1, p[2], p[3], epi=ops.EPI_RELU)
-    h3 = ops.conv_down(L[2], h2, p[4], p[5], epi=ops.EPI_RELU)
+    if len(p) > 8:   # the 128 x 128 stack (its data gradients take other engines: no masks)
+        h1 = ops.conv_down(L[0], obs, p[0], p[1], epi=ops.EPI_RELU)
+        h2 = ops.conv_down(L[1], h1, p[2], p[3], epi=ops.EPI_RELU)
+        h3 = ops.conv_down(L[2], h2, p[4], p[5], epi=ops.EPI_RELU)
+        h4 = ops.conv_down(L[3], h3, p[6], p[7], epi=ops.EPI_RELU)
+        return ops.gemm(h4.view(h4.shape[0], -1), p[8], transb=True, bias=p[9]), (h1, h2, h3, h4)
+    # each layer also writes the channel-quad mask of its ReLU (1/16 of the activation's bytes): all the data
+    # gradient of the layer above needs of it (19 MB instead of 301 MB for h1 at 2450 frames)
+    h1, m1 = ops.conv_down(L[0], obs, p[0], p[1], epi=ops.EPI_RELU, want_cmask=True)
+    h2, m2 = ops.conv_down(L[1], h1, p[2], p[3], epi=ops.EPI_RELU, want_cmask=True)
+    h3, m3 = ops.conv_down(L[2], h2, p[4], p[5], epi=ops.EPI_RELU, want_cmask=True)
     h4 = ops.conv_down(L[3], h3, p[6], p[7], epi=ops.EPI_RELU)
-    flat = h4.view(h4.shape[0], -1)
-    if len(p) > 8:
-        return ops.gemm(flat, p[8], transb=True, bias=p[9]), (h1, h2, h3, h4)
-    return flat, (h1, h2, h3, h4)
+    return h4.view(h4.shape[0], -1), (h1, h2, h3, h4, m1, m2, m3)
 
 
 class _Fork:
@@ -59,7 +64,8 @@ class _Fork:
 
 def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False, side=None):
     """Gradients of all eight encoder tensors into g (same order as p)."""
-    h1, h2, h3, h4 = saved
+    h1, h2, h3, h4 = saved[:4]
+    masks = saved[4:] if len(saved) > 4 else None
     n = h4.shape[0]
     L = _ENC[obs.shape[-1]]
     fk = _Fork(side)
@@ -73,11 +79,17 @@ def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False, side=None):
     fk.run(lambda: ops.conv_wgrad(L[3], d4, h3, dw=g[6], db=g[7], accumulate=accumulate))
     # the three weight packs first (independent of the gradients): their launches do not sit between the convs
     pk4, pk3, pk2 = ops.conv_up_pack(L[3], p[6]), ops.conv_up_pack(L[2], p[4]), ops.conv_up_pack(L[1], p[2])
-    d3 = ops.conv_up(L[3], d4, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h3, pack=pk4)
+    def up(layer, d, w, h, mask, pack):   # d of the layer below = conv_up(d) * relu'(h), from h or from its mask
+        if mask is not None:
+            return ops.conv_up(layer, d, w, None, epi=ops.EPI_MUL_CMASK, aux=mask, pack=pack)
+        return ops.conv_up(layer, d, w, None, epi=ops.EPI_MUL_DRELU, aux=h, pack=pack)
+
+    m1, m2, m3 = masks if masks else (None, None, None)
+    d3 = up(L[3], d4, p[6], h3, m3, pk4)
     fk.run(lambda: ops.conv_wgrad(L[2], d3, h2, dw=g[4], db=g[5], accumulate=accumulate))
-    d2 = ops.conv_up(L[2], d3, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h2, pack=pk3)
+    d2 = up(L[2], d3, p[4], h2, m2, pk3)
     fk.run(lambda: ops.conv_wgrad(L[1], d2, h1, dw=g[2], db=g[3], accumulate=accumulate))
-    d1 = ops.conv_up(L[1], d2, p[2], None, epi=ops.EPI_MUL_DRELU, aux=h1, pack=pk2)
+    d1 = up(L[1], d2, p[2], h1, m1, pk2)
     ops.conv_wgrad(L[0], d1, obs, dw=g[0], db=g[1], accumulate=accumulate)
     fk.join()
 

@@ -11,7 +11,7 @@ import torch
 
 from ._lib import check, lib
 
-EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU, EPI_MUL_MASK4 = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU, EPI_MUL_MASK4, EPI_MUL_CMASK = 0, 1, 2, 3, 4, 5, 6
 
 # layer ids of repo_conv_* (include/repo_hip.h): 0..6 the reference's 64 x 64 stack, 7..12 the build-defined 128 x 128 one
 ENC1, ENC2, ENC3, ENC4, DEC2, DEC3, DEC4 = range(7)
@@ -127,9 +127,12 @@ def gemm_wgrad(dY, X, dW=None, db=None, accumulate=False, want_bias=True):
     return dW, db
 
 
-def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None, dbias=None, accumulate_dbias=False):
+def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None, dbias=None, accumulate_dbias=False,
+              want_cmask=False):
     """dbias: optional [small_ch] tensor that receives (accumulate_dbias: is added) the per-channel sum of the output
-    -- the bias gradient of the transposed-conv layer whose pre-activation gradient this call produces."""
+    -- the bias gradient of the transposed-conv layer whose pre-activation gradient this call produces.
+    want_cmask (epi = EPI_RELU): also returns the output's channel-quad mask (uint8, numel / 4: EPI_MUL_CMASK of the
+    layer's data gradient, conv_up) -- (out, cmask)."""
     nimg = big.shape[0]
     (cb, hb, _), (cs, hs, _) = conv_shapes(layer)
     assert tuple(big.shape[1:]) == (cb, hb, hb) and big.is_contiguous(), big.shape
@@ -140,12 +143,13 @@ def conv_down(layer, big, w, bias=None, epi=EPI_NONE, aux=None, out=None, dbias=
     # workspace: the channel-sum partials (dbias) and the bf16x6 kernel's weight pack (include/repo_hip.h)
     nb = lib().repo_conv_down_workspace_bytes(layer, nimg)
     ws = workspace(nb, big.device) if nb else None
+    cmask = torch.empty(nimg * (cs // 4) * hs * hs, dtype=torch.uint8, device=big.device) if want_cmask else None
     check(
         lib().repo_conv_down(layer, nimg, _ptr(big), int(is_u8), _ptr(_f32c(w)), _ptr(bias), _ptr(out), epi,
-                             _ptr(aux), _ptr(dbias), int(accumulate_dbias), _ptr(ws), nb, _stream()),
+                             _ptr(aux), _ptr(dbias), int(accumulate_dbias), _ptr(cmask), _ptr(ws), nb, _stream()),
         "repo_conv_down",
     )
-    return out
+    return (out, cmask) if want_cmask else out
 
 
 def conv_up_pack(layer, w):

@@ -391,6 +391,49 @@ def test_conv_down_quad_mask_any_geometry(ops, layer):
         assert torch.equal(a, m), (layer, nimg)
 
 
+@pytest.mark.parametrize("layer", [0, 1, 2])
+@pytest.mark.parametrize("engine", [1, 0], ids=["bf16x6", "fp32"])
+def test_channel_quad_mask_written_by_conv_down_read_by_conv_up(ops, layer, engine):
+    """REPO_EPI_MUL_CMASK: the encoder layer's forward writes the channel-quad mask of its ReLU from the accumulators
+    (repo_conv_down relu_cmask: byte ((n * C/4 + c/4) * P + p), bit c % 4 <=> relu > 0), the data gradient of the
+    layer above (repo_conv_up on the scatter kernels: enc2 / enc3 / enc4, 961- / 196- / 36-pixel planes, both
+    drains) multiplies by it: the mask equals the activation's signs and the gradient equals REPO_EPI_MUL_DRELU's bit
+    for bit; ragged image counts; a 3-channel layer has no channel quads (REPO_E_BADARG)."""
+    import repo_amd.ops as rops
+    from repo_amd._lib import RepoHipError, lib
+
+    rs = np.random.RandomState(90 + layer)
+    (cb, hb, _), (cs, hs, _) = rops.conv_shapes(layer)
+    ks = rops.CONV_GEO[layer][3]
+    up = layer + 1   # the layer whose data gradient lands on this layer's output
+    (ucb, uhb, _), (ucs, uhs, _) = rops.conv_shapes(up)
+    assert (ucb, uhb) == (cs, hs)
+    uks = rops.CONV_GEO[up][3]
+    prev = lib().repo_debug_bconv(engine)
+    try:
+        for nimg in (1, 5, 37):
+            big = dev(rnd(rs, nimg, cb, hb, hb))
+            w = dev(rnd(rs, cs, cb, ks, ks, scale=0.2))
+            b = dev(rnd(rs, cs, scale=0.1))
+            h, cmask = ops.conv_down(layer, big, w, b, epi=rops.EPI_RELU, want_cmask=True)
+            assert torch.equal(h, ops.conv_down(layer, big, w, b, epi=rops.EPI_RELU))
+            bits = (h > 0).to(torch.uint8).view(nimg, cs // 4, 4, hs * hs)
+            want = bits[:, :, 0] | (bits[:, :, 1] << 1) | (bits[:, :, 2] << 2) | (bits[:, :, 3] << 3)
+            assert torch.equal(cmask.view(nimg, cs // 4, hs * hs), want), (layer, nimg)
+            assert 0.2 < float((h > 0).float().mean()) < 0.8
+            d = dev(rnd(rs, nimg, ucs, uhs, uhs))
+            uw = dev(rnd(rs, ucs, ucb, uks, uks, scale=0.1))
+            a = ops.conv_up(up, d, uw, None, epi=rops.EPI_MUL_DRELU, aux=h)
+            m = ops.conv_up(up, d, uw, None, epi=rops.EPI_MUL_CMASK, aux=cmask)
+            assert torch.equal(a, m), (layer, nimg)
+    finally:
+        lib().repo_debug_bconv(prev)
+    if layer == 0:
+        with pytest.raises(RepoHipError):   # the 3-channel data gradient runs on the gather engine: no channel quads
+            ops.conv_up(0, dev(rnd(rs, 1, 32, 31, 31)), dev(rnd(rs, 32, 3, 4, 4)), None, epi=rops.EPI_MUL_CMASK,
+                        aux=torch.zeros(64, dtype=torch.uint8, device="cuda"))
+
+
 @pytest.mark.parametrize("layer,u8", [(6, True), (6, False), (12, True), (12, False)])
 def test_conv_up_nll(ops, layer, u8):
     """The gather engine's fused output layer + pixel NLL (layer 12: the 128 x 128 stack's; layer 6: a second
