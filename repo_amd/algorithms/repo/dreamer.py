@@ -98,6 +98,10 @@ class Dreamer:
         ovl = os.environ.get("REPO_OVL", "wsC")
         self._side_stream = torch.cuda.Stream(device=self.device) if "s" in ovl else None
         self._wgrad_stream = torch.cuda.Stream(device=self.device) if "w" in ovl else None
+        # ... but only for batches that fill the chip: at a strong-scaling shard's size (B = 6 .. 13 sequences) the
+        # forks and joins of the weight-gradient stream cost more than the overlap gives (round 4, one box:
+        # B = 6: 2.52 -> 2.40 ms, B = 13: 3.15 -> 2.91 without it; B = 25 and 50: equal within 0.5 %)
+        self._wgrad_min_batch = 20
         # "c" (experiment) borrows the world-model lane's weight-gradient stream instead of creating a stream
         self._ac_side_stream = (self._wgrad_stream if "C" in ovl else
                                 torch.cuda.Stream(device=self.device)) if ("c" in ovl or "C" in ovl) else None
@@ -177,6 +181,10 @@ class Dreamer:
         # REPO_DP_BUCKETS=1: the whole 20.7 MB model gradient as ONE all-reduce after the backward (the round-2
         # exchange; kept for A/B runs on a multi-GPU node and for the bucketed-equals-single test)
         self._dp_two_buckets = os.environ.get("REPO_DP_BUCKETS", "2") != "1"
+
+    def _wgrad_side(self, batch):
+        """The weight-gradient side stream for a batch of `batch` sequences, or None (in line)."""
+        return self._wgrad_stream if batch >= self._wgrad_min_batch else None
 
     def _pg(self, module):
         """(params, grads) of a module as detached tensors / flat-gradient views, state_dict order."""
@@ -283,6 +291,7 @@ class Dreamer:
         sv = st["sv"]
         feat = st["feat"]
         dev = self.device
+        wside = self._wgrad_side(st["frames"].shape[0] // sv.featx[1:].shape[0])   # sequences in the batch
         dfeat = torch.empty(rows, feat.shape[1], device=dev)
         pw, gw = self._pg(self.reward_model)
         ops.mlp_bwd(pw, feat, st["rew_hid"], st["drew"].view(rows, 1), dparams=gw, dx=dfeat)
@@ -307,7 +316,7 @@ class Dreamer:
                 fn()
             main.wait_stream(side)
             self._model_bucket_begin(tail=True)   # decoder + reward-head gradients are final
-            Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
+            Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=wside)
             return
         # RePo: the decoder is a probe on detached latents (repo.py:46-48), so its backward is
         # independent of the RSSM/encoder backward.  The reverse scan is a latency-bound chain
@@ -319,10 +328,10 @@ class Dreamer:
         with torch.cuda.stream(side):
             ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=dpm, dps=dps, dqm=dqm, dqs=dqs, dembeds=dembeds,
                                  min_std=self.transition_model.min_std_dev)
-        Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, side=self._wgrad_stream)
+        Fn.decoder_bwd(pd, feat, st["dec_saved"], gd, side=wside)
         main.wait_stream(side)
         self._model_bucket_begin(tail=True)   # decoder + reward-head gradients are final (15.7 MB of 20.7)
-        Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
+        Fn.encoder_bwd(pe, st["frames"], st["enc_saved"], dembeds, ge, side=wside)
 
     def _model_bucket_begin(self, tail):
         """Data parallel: start the SUM all-reduce of one of the two model-gradient buckets on RCCL's stream,

@@ -115,19 +115,20 @@ class MultitaskDreamer(Dreamer):
         c, dev = self.c, self.device
         rows, sv, featc, cond = st["rows"], st["sv"], st["featc"], st["cond"]
         F_ = c.belief_size + c.state_size
+        wside = self._wgrad_side(rows // sv.featx[1:].shape[0])   # sequences in the batch
         dfeatc = torch.empty_like(featc)
         pw, gw = self._pg(self.reward_model)
         ops.mlp_bwd(pw, featc, st["rew_hid"], st["drew"].view(rows, 1), dparams=gw, dx=dfeatc)
         pd, gd = self._pg(self.obs_model)
         Fm.cond_decoder_bwd(pd, st["feat"], cond, st["dec_saved"], gd, dfeat=dfeatc[:, :F_] if decoder_attached else None,
-                            accumulate_dfeat=True, side=self._wgrad_stream)
+                            accumulate_dfeat=True, side=wside)
         pr, gr = self._pg(self.transition_model)
         dembeds = torch.empty(rows, c.embedding_size, device=dev)
         dpm, dps, dqm, dqs = kl_grads
         ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeatc[:, :F_].contiguous(), dpm=dpm, dps=dps, dqm=dqm, dqs=dqs,
                              dembeds=dembeds, min_std=self.transition_model.min_std_dev)
         pe, ge = self._pg(self.encoder)
-        Fm.cond_encoder_bwd(pe, st["frames"], cond, st["enc_saved"], dembeds, ge, side=self._wgrad_stream)
+        Fm.cond_encoder_bwd(pe, st["frames"], cond, st["enc_saved"], dembeds, ge, side=wside)
 
     def _prep_mt_batch(self, tasks, obs, actions, rewards, nonterms):
         obs, actions, rewards, nonterms = self._prep_batch(obs, actions, rewards, nonterms)

@@ -95,7 +95,7 @@ class RePo(Dreamer):
             Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=None)
         pd, gd = self._pg(self.obs_model)
         nll_sum, dec_saved = Fn.decoder_fwd_nll(pd, feat, frames, 1.0 / grow)
-        Fn.decoder_bwd(pd, feat, dec_saved, gd, side=self._wgrad_stream)
+        Fn.decoder_bwd(pd, feat, dec_saved, gd, side=self._wgrad_side(B))
         if self.dp is not None and self._dp_two_buckets:
             main.wait_event(ev_rew)
             g, cut = self.model_optimizer.grad, self._model_cut

@@ -64,7 +64,7 @@ class FinetunedRePo(RePo):
         dembeds = torch.empty(rows, c.embedding_size, device=dev)
         ops.rssm_observe_bwd(pr, sv, self._scratch_gr, dfeat=dfeat, dpm=klg[0], dps=klg[1], dqm=klg[2], dqs=klg[3],
                              dembeds=dembeds, min_std=self.transition_model.min_std_dev)
-        Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=self._wgrad_stream)
+        Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=self._wgrad_side(B))
         opt = self.encoder_optimizer
         self._allreduce(opt.grad)
         opt.clip_and_step(c.grad_clip_norm)

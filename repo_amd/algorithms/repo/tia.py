@@ -175,7 +175,7 @@ class TIA(Dreamer):
         # -- backward, task side: reward head -> decoder (attached) -> reverse scan
         pr_t, gr_t = self._pg(self.transition_model)
         pr_d, gr_d = self._pg(self.distractor_transition_model)
-        side = self._wgrad_stream
+        side = self._wgrad_side(B)
         dfeat_t = torch.empty(rows, D + S, device=dev)
         dembeds = torch.empty(rows, c.embedding_size, device=dev)
         dembeds_d = torch.empty(rows, c.embedding_size, device=dev)
