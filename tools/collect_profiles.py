@@ -28,6 +28,7 @@ pairs = [
     ("r04_bench_mt.json", "r04_bench_mt.json"),
     ("r04_bgemm_probe.txt", "r04_bgemm_probe.txt"),
     ("r04_gemm_isolated.txt", "r04_gemm_isolated.txt"),
+    ("r04_rollout_engines.txt", "r04_rollout_engines.txt"),
 ]
 for src, dst in pairs:
     s = os.path.join(G, src)

@@ -12,7 +12,7 @@ python3 tools/layers_in_update.py $O/r04_bench_pipelined_kernel_stats.csv --json
 python3 tools/launch_count.py $O/r04_bench_pipelined_kernel_stats.csv > $O/r04_launch_count.txt 2>&1
 bash tools/pmc.sh dec3 "buconv_scatter|uconv_scatter|bconv_down|dconv_down|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv dec3" > /dev/null 2>&1
 bash tools/pmc.sh convs "buconv_scatter|uconv_scatter|bconv_down|dconv_down|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv enc2" "conv enc3" "conv enc4" "conv dec2" > /dev/null 2>&1
-bash tools/pmc.sh scan_rollout "observe_|imagine_" tools/run_scan_rollout.py > /dev/null 2>&1
+bash tools/pmc.sh scan_rollout "observe_|imagine" tools/run_scan_rollout.py > /dev/null 2>&1
 bash tools/pmc.sh c3 "dconv_dec4|Geo<3, 32|Geo<3,32" tools/run_micro_case.py "conv enc1" "conv dec4" "dec4 forward" > /dev/null 2>&1
 bash tools/pmc.sh mlp "mlp_(fwd|bwd)_kernel|wgrad_direct" tools/run_micro_case.py "mlp_fwd value" "mlp_bwd value head" "mlp_bwd actor" > /dev/null 2>&1
 python3 tools/lane_time.py > $O/r04_lane_time.txt 2>&1
@@ -27,6 +27,7 @@ python3 bench.py --config c4x128 2>/dev/null | grep '^{' > $O/r04_bench_c4x128.j
 python3 bench.py --config tia 2>/dev/null | grep '^{' > $O/r04_bench_tia.json
 python3 bench.py --config mt 2>/dev/null | grep '^{' > $O/r04_bench_mt.json
 tools/probe/bin/bgemm_probe > $O/r04_bgemm_probe.txt 2>&1
+python3 tools/rowtile32_ab.py > $O/r04_rollout_engines.txt 2>&1
 python3 tools/layers_isolated.py gemm > $O/r04_gemm_isolated.txt 2>&1
 python3 bench.py > $O/bench_full.log 2>&1
 grep '^{' $O/bench_full.log > $O/r04_bench_final.json
