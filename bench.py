@@ -587,7 +587,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "dtype_note": "fp32 inputs, outputs and accumulation, the reference's precision; the MFMA-bound conv / dense "
-                          "kernels (csrc/bgemm.h, bconv.h, buconv.h) form each fp32 product EXACTLY-split as six bf16 x bf16 "
+                          "kernels (csrc/bgemm.h, bconv.h, buconv.h, bwgrad.h) and the imagination rollout (csrc/imagine32.hip) form each fp32 product EXACTLY-split as six bf16 x bf16 "
                           "partial products on the bf16 matrix pipe -- measured error at or below the fp32-MFMA kernels' "
                           "(tests/test_ops_gpu.py::test_bf16x6_*, test_bgemm_*); nothing is rounded to bf16",
             "data": "synthetic",
