@@ -516,6 +516,53 @@ def test_no_uninitialised_lds(ops):
         assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
 
 
+def test_no_uninitialised_lds_row_tile_kernels(ops):
+    """The persistent row-tile kernels (rollout forward / reverse on both engines, the fused heads) after the LDS of every
+    CU has been filled with NaN patterns: same bits as before -- their tiles' padding columns meet zero weights, so they
+    must hold finite values the kernels wrote themselves."""
+    from repo_amd._lib import lib
+    from oracle import fixtures as fx
+
+    def poison():
+        assert lib().repo_debug_poison_lds(torch.cuda.current_stream().cuda_stream) == 0
+
+    rs = np.random.RandomState(78)
+    Hm, N, A, D, S = 3, 75, 6, 200, 30
+    P = fx.make_params(A, 7)
+    rp = [torch.tensor(v).cuda() for v in P["transition_model"].values()]
+    ap = [torch.tensor(v).cuda() for v in P["actor_model"].values()]
+    vp = [torch.tensor(v).cuda() for v in P["value_model"].values()]
+    b0, s0 = dev(rnd(rs, N, D, scale=0.3)), dev(rnd(rs, N, S))
+    ea, ep = dev(rnd(rs, Hm, N, A)), dev(rnd(rs, Hm, N, S))
+    dfeat = dev(rnd(rs, Hm, N, D + S, scale=0.01))
+    for engine in (1, 0):
+        prev = lib().repo_debug_rowtile32(engine)
+        try:
+            outs = []
+            for p in (False, True):
+                if p:
+                    poison()
+                sv = ops.rssm_imagine_fwd(rp, ap, b0, s0, ea, ep)
+                if p:
+                    poison()
+                d_araw, dfeat0 = ops.rssm_imagine_bwd(rp, sv, dfeat, want_dfeat0=True)
+                outs.append((sv.featx.clone(), sv.gates.clone(), sv.a_hidden.clone(), d_araw.clone(), dfeat0.clone()))
+            for a, b in zip(*outs):
+                assert torch.isfinite(b).all() and torch.equal(a, b), engine
+        finally:
+            lib().repo_debug_rowtile32(prev)
+    x = dev(rnd(rs, 1000, D + S))
+    ref, rh = ops.mlp_fwd(vp, x)
+    dx_ref = torch.empty_like(x)
+    ops.mlp_bwd(vp, x, rh, dev(rnd(np.random.RandomState(1), 1000, 1)), dparams=None, dx=dx_ref)
+    poison()
+    got, gh = ops.mlp_fwd(vp, x)
+    poison()
+    dx = torch.empty_like(x)
+    ops.mlp_bwd(vp, x, gh, dev(rnd(np.random.RandomState(1), 1000, 1)), dparams=None, dx=dx)
+    assert torch.equal(ref, got) and all(torch.equal(a, b) for a, b in zip(rh, gh)) and torch.equal(dx_ref, dx)
+
+
 def test_device_check_and_arch_guard():
     """repo_device_check: the MI355X passes, an ordinal that does not exist is a bad argument; every entry
     point runs the same (cached) check before launching (REPO_E_ARCH on anything that is not gfx950)."""
