@@ -346,9 +346,17 @@ __global__ __launch_bounds__(512) void imagine32_bwd_kernel(Img32BwdArgs p) {
   // three windows: W_sp's (4 blocks) has one of its own, the other six streams of a step alternate between two
   WinB wa, wb, wc;
   wopen32<BS2, kPDb, false>(wc, rw, wave < ntH, p.Wsp, 0, Hd, min(wave, ntH - 1), lane);
+  const unsigned lrow_inv = lrow;
+  const int c0_inv = c0, tid_inv = tid;
   for (int t = Hm - 1; t >= 0; --t) {
     const size_t rb = (size_t)t * N + r0;
     const unsigned tN = (unsigned)(t * N);
+    // per-step copies the compiler cannot see through: the dozens of global byte offsets derived from them are then
+    // recomputed where they are used (a multiply-add each) instead of being hoisted out of the step loop, spilled to
+    // scratch memory and re-loaded -- one exposed memory round trip per address -- in front of every use
+    unsigned lrow = lrow_inv;
+    int c0 = c0_inv, tid = tid_inv;
+    asm volatile("" : "+v"(lrow), "+v"(c0), "+v"(tid));
     // ---- G += dfeat[t]; the prior head's sample / mean / std gradients -> d [mean | raw_std].  Everything the two
     //      phases read from global memory is requested first (one exposed round trip instead of one per loop
     //      iteration); a thread takes quads of dfeat with consecutive lanes on consecutive rows (LDS: contiguous)
