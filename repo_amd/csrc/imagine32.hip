@@ -127,6 +127,12 @@ __global__ __launch_bounds__(512) void imagine32_fwd_kernel(Img32FwdArgs p) {
                        __attribute__((always_inline)) {
     if (swave) store_tile32(T, ps, ncols, dst + first_row * ld, (unsigned)r0, nr, ld, 0u, lane);
   };
+  // ... and behind a NARROW layer (the actor's head: one column tile, the prior head's output: two) every wave without a
+  // tile takes a share: one wave's 1.5 us would outlast the layer
+  auto save_tile_shared = [&](const char* T, int ps, int ncols, const float* dst, unsigned ld, size_t first_row,
+                              int busy) __attribute__((always_inline)) {
+    if (wave >= busy) store_tile32(T, ps, ncols, dst + first_row * ld, (unsigned)r0, nr, ld, 0u, lane, wave - busy, kW - busy);
+  };
   const std::integral_constant<int, BF> nbF{};
   const std::integral_constant<int, BW> nbW{};
   const std::integral_constant<int, BX> nbX{};
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(512) void imagine32_fwd_kernel(Img32FwdArgs p) {
     dopen32<BW>(wa, rw, p.aW[4], p.aB[4], 2 * A, wave, lane);
     dense(nbW, HA, psH, wb, HB);
     lds_barrier();
-    save_tile(HB, psH, Hd, p.a_hidden, (unsigned)Hd, 3 * rowsAll + tN);
+    save_tile_shared(HB, psH, Hd, p.a_hidden, (unsigned)Hd, 3 * rowsAll + tN, 1);   // beside the head (wave 0)
     dopen32<BX>(wb, rw, p.Wsa, p.Bsa, D, wave, lane);
     head(wa, HB);
     lds_barrier();
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(512) void imagine32_fwd_kernel(Img32FwdArgs p) {
     dopen32<BW>(wb, rw, p.Wsp, p.Bsp, 2 * S, wave, lane);
     dense(nbW, Fp, psF, wa, HB);
     lds_barrier();
-    save_tile(HB, psH, Hd, p.hp, (unsigned)Hd, tN);
+    save_tile_shared(HB, psH, Hd, p.hp, (unsigned)Hd, tN, 2);   // beside the prior head's output layer (waves 0, 1)
     dopen32<BF>(wa, rw, p.aW[0], p.aB[0], Hd, wave, lane);  // the next step's first layer
     head(wb, HB);
     lds_barrier();

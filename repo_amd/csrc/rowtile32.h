@@ -246,8 +246,9 @@ __device__ __forceinline__ void wrun32(f32x16v& c, const char* X, int ps, WWin32
 // vector-memory queue then holds loads only (on gfx9 a load issued behind a store is not seen complete before the
 // store is acknowledged), and the CU's address path sees 128-byte runs instead of the accumulators' 32-byte ones.
 // row0: the tile's first global row; nr: its valid rows; ld: floats per global row
+// g0 / gstep: this wave takes column groups g0, g0 + gstep, ... (a layer that leaves several waves idle shares the tile out)
 __device__ __forceinline__ void store_tile32(const char* T, int ps, int ncols, const float* dst, unsigned row0,
-                                             int nr, unsigned ld, unsigned soff, int lane) {
+                                             int nr, unsigned ld, unsigned soff, int lane, int g0 = 0, int gstep = 1) {
 #ifdef RT32_NO_TILESTORE
   return;
 #endif
@@ -271,13 +272,14 @@ __device__ __forceinline__ void store_tile32(const char* T, int ps, int ncols, c
   // column group g: the quad at columns 32 g + 4 piece; its planes are 2048 g bytes further in the tile
   const int ng = (ncols + 31) >> 5;
   const bool mine_last = (ng - 1) * 32 + 4 * piece < ncols;  // the last group may be ragged (ncols % 4 == 0)
+  if (g0 >= ng) return;
   f32x4v cur[4], nxt[4];
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) cur[rg] = ldq32(src[rg], ps, 0, 0);
-  for (int g = 0; g < ng; ++g) {
-    if (g + 1 < ng) {
+  for (int rg = 0; rg < 4; ++rg) cur[rg] = ldq32(src[rg] + 2048 * g0, ps, 0, 0);
+  for (int g = g0; g < ng; g += gstep) {
+    if (g + gstep < ng) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) nxt[rg] = ldq32(src[rg] + 2048 * (g + 1), ps, 0, 0);
+      for (int rg = 0; rg < 4; ++rg) nxt[rg] = ldq32(src[rg] + 2048 * (g + gstep), ps, 0, 0);
     }
     const bool ok = g + 1 < ng || mine_last;
 #pragma unroll
