@@ -33,7 +33,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define REPO_ABI_VERSION 5
+#define REPO_ABI_VERSION 6
 
 #define REPO_OK 0
 #define REPO_E_BADARG (-1)
@@ -70,13 +70,18 @@ const char* repo_strerror(int code);
 int repo_device_check(int device);
 /* Test aid: fills every CU's LDS with NaN patterns (see tests/test_ops_gpu.py::test_no_uninitialised_lds). */
 int repo_debug_poison_lds(hipStream_t stream);
-/* Test aid: polls a spin-wait of the column-split scans makes before it gives up (default 1 << 22; `polls` < 0
- * restores it).  Process-wide and meant for tests only (tests/test_rssm_gpu.py::test_scan_timeout_reaches_the_host
- * sets 0 to see the status word of repo_rssm_observe_fwd / _bwd raised); returns the previous value. */
+/* The four repo_debug_* switches below are TEST AIDS and THREAD-LOCAL: a setting belongs to the calling host thread and
+ * governs the launches that thread issues afterwards (it is read when an entry point is called, never by a kernel);
+ * other threads -- e.g. the driver of another stream -- keep their own, default, settings.  The library therefore has
+ * no process-global mutable state beyond the once-initialised per-device architecture cache.
+ *
+ * Polls a spin-wait of the column-split scans makes before it gives up (default 1 << 22; `polls` < 0 restores it);
+ * tests/test_rssm_gpu.py::test_scan_timeout_* set 0 to see the status word of repo_rssm_observe_fwd / _bwd raised;
+ * returns the previous value. */
 int repo_debug_scan_spin_limit(int polls);
 /* Test aid: enable (default) / disable the bf16x6 dense engine (csrc/bgemm.h: big products of repo_gemm /
  * repo_gemm_wgrad formed as six exact bf16 partial products per fp32 multiply on the bf16 matrix pipe -- same inputs,
- * outputs and accuracy as the fp32-MFMA engines); process-wide, for A/B runs; returns the previous setting. */
+ * outputs and accuracy as the fp32-MFMA engines); for A/B runs; returns the calling thread's previous setting. */
 int repo_debug_bgemm(int enable);
 /* The same switch for the bf16x6 stride-2 "down" convolution kernel (csrc/bconv.h). */
 int repo_debug_bconv(int enable);
@@ -393,10 +398,13 @@ int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const float* ps, c
                     void* ws, size_t ws_bytes, hipStream_t stream);
 /* Lagrangian dual ascent on log_beta (repo.py:83,93-105): grad = -(kl_sum/rows - target_kl),
  * one Adam step (state exp_avg/exp_avg_sq on device, `step` = 1-based count) if apply.
- * scalars_out[4] = {kl_div, kl_loss = beta_old*viol, beta_loss = -log_beta_old*viol, beta_new}. */
+ * scalars_out[4] = {kl_div, kl_loss = beta_old*viol, beta_loss = -log_beta_old*viol, beta_new}.
+ * skip_if_nonzero: see repo_clip_adam -- a faulted update leaves log_beta and its moments untouched (the scalars are
+ * still written: they are what the caller logs, NaN included). */
 int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const float* kl_sum,
                    int64_t rows, float target_kl, float lr, float beta1, float beta2, float eps,
-                   int64_t step, int apply, float* scalars_out, hipStream_t stream);
+                   int64_t step, int apply, float* scalars_out, const unsigned* skip_if_nonzero,
+                   hipStream_t stream);
 /* Unit-variance Gaussian NLL of a scalar head (reward repo.py:58-61, value dreamer.py:365-368):
  * sums2[0] = sum 0.5*(pred-target)^2*mask, sums2[1] = sum mask (mask NULL = ones);
  * dpred = (pred-target)*mask*scale (nullable). */
@@ -467,10 +475,11 @@ int repo_kl_balance_tasks(int64_t rows, int64_t S, int64_t C, const float* pm, c
                           size_t ws_bytes, hipStream_t stream);
 /* Dual ascent on the per-task log_beta vector (repo_mt.py:95-112): beta_loss = -mean_rows(lb_row * viol_row), so
  * grad[i] = -sums[3+i] / rows; ONE Adam step on the C-vector if apply (`step` = 1-based count, state on device).
- * rows = the GLOBAL row count.  scalars_out[3 + C] = { kl_div, kl_loss, beta_loss, exp(log_beta[i]) after the step }. */
+ * rows = the GLOBAL row count.  scalars_out[3 + C] = { kl_div, kl_loss, beta_loss, exp(log_beta[i]) after the step }.
+ * skip_if_nonzero: as repo_dual_step. */
 int repo_dual_step_tasks(int64_t C, float* log_beta, float* exp_avg, float* exp_avg_sq, const float* sums,
                          int64_t rows, float lr, float beta1, float beta2, float eps, int64_t step, int apply,
-                         float* scalars_out, hipStream_t stream);
+                         float* scalars_out, const unsigned* skip_if_nonzero, hipStream_t stream);
 
 /* ------------------------------------------------------------------ optimiser
  * *sqnorm = sum g^2 over a flat, 16-byte aligned buffer (global norm of
@@ -479,10 +488,15 @@ size_t repo_grad_sqnorm_workspace_bytes(void);
 int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* ws, size_t ws_bytes,
                      hipStream_t stream);
 /* g *= min(1, max_norm/(sqrt(*sqnorm)+1e-6)) fused with torch.optim.Adam's update
- * (betas, eps, no weight decay; `step` = 1-based count).  sqnorm NULL = no clipping. */
+ * (betas, eps, no weight decay; `step` = 1-based count).  sqnorm NULL = no clipping.
+ * skip_if_nonzero (ABI v6, nullable): a device word -- the update's copy of the scans' asynchronous `status`
+ * (repo_rssm_observe_fwd), reduced over the ranks of a data-parallel job.  If it is non-zero when the kernel runs,
+ * NOTHING is written: parameters and both moments keep their values, so that an update whose scan timed out (its
+ * gradients are NaN-poisoned by then) costs the caller one retry, not the model.  The reference has no counterpart:
+ * its optimiser steps cannot be reached by a failed kernel (an exception unwinds repo.py:86-90 first). */
 int repo_clip_adam(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    const float* sqnorm, float max_norm, float lr, float beta1, float beta2, float eps,
-                   int64_t step, hipStream_t stream);
+                   int64_t step, const unsigned* skip_if_nonzero, hipStream_t stream);
 
 #ifdef __cplusplus
 }

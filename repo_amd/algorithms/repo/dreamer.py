@@ -119,6 +119,14 @@ class Dreamer:
         self._act_graph_enabled = os.environ.get("REPO_ACT_GRAPH", "1") == "1"
         self._last_scalars = {}
         self.last_grad_norms = {}
+        # fail-safe updates (include/repo_hip.h, repo_clip_adam `skip_if_nonzero`): every update owns one word of this
+        # ring -- its copy of the scans' asynchronous status, taken (and, data parallel, MAX-reduced) right before its
+        # first optimiser step; all of its steps skip themselves on a non-zero word and `_flush_log` raises.  A ring
+        # because the actor-critic lane of update k still reads its word while update k+1 takes the next one.
+        self._status_ring = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self._ustatus = self._status_ring[7:8]
+        self._update_seq = 0
+        self._restore_point = None
 
     # ------------------------------------------------------------------ construction
     def build_models(self, config, env):
@@ -346,7 +354,26 @@ class Dreamer:
         # the reverse scan's side stream is idle from here to the end of the backward: the bucket rides on it
         self._model_works.append(self.dp.all_reduce_begin(g[cut:], stream=self._side_stream))
 
+    def _steppers(self):
+        """Everything of this agent that counts optimiser steps (FlatAdam groups, the dual variables' Adam states)."""
+        return [v for v in vars(self).values() if hasattr(v, "step_count") and hasattr(v, "exp_avg")]
+
+    def _take_status(self):
+        """Called on the stream that has joined every scan of this update, before its first optimiser step: the
+        update's own status word (ops.take_scan_status) becomes the `skip` word of every step of this update."""
+        st = self._status_ring[self._update_seq % 8 : self._update_seq % 8 + 1]
+        word = ops.scan_status(self.device)
+        st.copy_(word)
+        word.zero_()
+        if self.dp is not None:
+            self.dp.all_reduce_status(st)
+        self._ustatus = st
+        for opt in self._steppers():
+            opt.skip = st
+        return st
+
     def _model_step(self):
+        self._take_status()
         # the optimiser step WRITES the world-model parameters the previous update's imagination
         # may still be reading on the actor-critic stream
         if self._ev_ac_done is not None:
@@ -361,6 +388,9 @@ class Dreamer:
         self.model_optimizer.clip_and_step(self.c.grad_clip_norm)
 
     def _prep_batch(self, obs, actions, rewards, nonterms):
+        # the first thing every train_dynamics variant calls: where a faulted update is rolled back to (_flush_log)
+        self._update_seq += 1
+        self._restore_point = (self._update_seq, self._noise_counter, [(o, o.step_count) for o in self._steppers()])
         obs = obs.contiguous()
         assert obs.dtype in (torch.uint8, torch.float32), obs.dtype
         return obs, actions.float().contiguous(), rewards.float().contiguous(), nonterms.float().contiguous()
@@ -487,7 +517,9 @@ class Dreamer:
         """Gather every logged scalar of this update into one device buffer and start ONE
         asynchronous device->host copy; the values are turned into floats (and handed to the
         logger) when they are first needed: `last_scalars`, or the next update's log call."""
-        self._flush_log()
+        # the PREVIOUS update's log is read here; if it reports a fault, the exception leaves only after this
+        # update's own copy has been enqueued (an update that is already in flight keeps its log)
+        fault = self._flush_log(defer=True)
         msc, dual, grow = self._pending_model   # [nll, rsq, rmask, kl, model_sqnorm] (+ dual[4])
         ret_sum, ent_sum, lat_sum, v_sums, Hm, gN = self._pending_ac
         cur = torch.cuda.current_stream(self.device)
@@ -501,8 +533,9 @@ class Dreamer:
                  self.value_optimizer.sqnorm, xn]
         if dual is not None:
             parts.append(dual)
-        # LAST: the scans' sticky status word (bits reinterpreted, the copy is exact), see ops.scan_status
-        parts.append(ops.scan_status(self.device).view(torch.float32))
+        # LAST: this update's status word (bits reinterpreted, the copy is exact; already global under data
+        # parallelism), see _take_status
+        parts.append(self._ustatus.view(torch.float32))
         buf = torch.cat([p.reshape(-1) for p in parts])
         # the leading entries (losses) are per-rank partial sums; the gradient norms behind them are already global
         self._allreduce_scalars(buf, n_sum=sum(p.numel() for p in parts[:6]))
@@ -510,7 +543,10 @@ class Dreamer:
         self._log_host[:n].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(cur)
-        self._log_pending = (ev, n, dual.numel() if dual is not None else 0, grow, Hm, gN, xs.numel(), xn.numel())
+        self._log_pending = (ev, n, dual.numel() if dual is not None else 0, grow, Hm, gN, xs.numel(), xn.numel(),
+                             self._restore_point)
+        if fault is not None:
+            raise fault
 
     def _dual_scalars(self, out, dual):
         """The dual step's scalars (RePo: repo.py:99-105; per-task betas: repo_mt.py:100-112)."""
@@ -523,14 +559,20 @@ class Dreamer:
     def _extra_scalars(self, out, sums, norms, grow):
         """Hook of the sibling algorithms: rewrite / add logged scalars from their own sums (see _log_update)."""
 
-    def _flush_log(self):
+    def _flush_log(self, defer=False):
+        """defer: return a fault's exception instead of raising it (see _log_update)."""
         if self._log_pending is None:
-            return
-        ev, n, n_dual, grow, Hm, gN, nxs, nxn = self._log_pending
+            return None
+        ev, n, n_dual, grow, Hm, gN, nxs, nxn, restore = self._log_pending
         self._log_pending = None
         ev.synchronize()
         c = self.c
-        ops.raise_scan_status(int(self._log_host[n - 1 : n].view(torch.int32).item()))
+        try:
+            self._raise_update_fault(int(self._log_host[n - 1 : n].view(torch.int32).item()), restore)
+        except Exception as fault:  # noqa: BLE001  (RepoHipError)
+            if defer:
+                return fault
+            raise
         h = self._log_host[: n - 1].tolist()
         nll, rsq, rmask, kl, ret, ent, lat, vsq, _vn = h[:9]
         xsums, h = h[9 : 9 + nxs], h[:9] + h[9 + nxs :]
@@ -558,6 +600,25 @@ class Dreamer:
                                 "value": math.sqrt(max(gv_, 0.0))}
         for k, v in out.items():
             self.logger.record(k, v)
+        return None
+
+    def _raise_update_fault(self, word, restore):
+        """word != 0: a scan of that update timed out.  Every optimiser step of the update has skipped itself on the
+        device (parameters, moments, dual variables unchanged -- on every rank of a data-parallel job, which all get
+        here in the same update).  If no later update has been started the host-side counters are rolled back too
+        (Adam step counts for the bias correction, the Philox offset), so that calling the update again -- e.g. under
+        REPO_SCAN_CS=0 -- is exactly the update that failed; with a later update already in flight (train_agent's
+        pipelining) they stay: that update ran on the unchanged parameters with its bias correction one step ahead."""
+        if not word:
+            return
+        rolled = restore is not None and restore[0] == self._update_seq
+        if rolled:
+            self._noise_counter = restore[1]
+            for opt, n in restore[2]:
+                opt.step_count = n
+        ops.raise_scan_status(word, "the update's optimiser steps were skipped: parameters, Adam moments and dual "
+                              "variables are unchanged" + ("; step counts and the noise offset were rolled back, the "
+                              "update can be retried as it was" if rolled else " (a later update was already in flight)"))
 
     @property
     def last_scalars(self):
@@ -606,9 +667,13 @@ class Dreamer:
         with torch.cuda.stream(ac):
             ac.wait_event(ev_wm)
             beliefs.record_stream(ac)  # views of the scan's feature buffer, allocated on the WM stream
-            self.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
-            self._ev_ac_done = torch.cuda.Event()
-            self._ev_ac_done.record(ac)
+            try:
+                self.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
+            finally:
+                # also when the previous update's fault is raised from this one's log call: the next model step
+                # must still wait for this update's imagination
+                self._ev_ac_done = torch.cuda.Event()
+                self._ev_ac_done.record(ac)
         if join:
             self.synchronize()
 
@@ -653,7 +718,8 @@ class Dreamer:
         outs = self.transition_model.observe(belief, posterior_state, action.unsqueeze(0), embed.unsqueeze(0))
         belief, posterior_state = outs[0].squeeze(0), outs[4].squeeze(0)
         action = self.actor_model.get_action(belief, posterior_state, det=not explore)
-        if explore and self.c.action_noise > 0:
+        if explore:   # drawn and clamped unconditionally, as the reference does (dreamer.py:193-195): with
+            # action_noise == 0 the draw still advances torch's generator, so seeded runs stay in step
             action = torch.clamp(action + torch.randn_like(action) * self.c.action_noise, -1, 1)
         return belief, posterior_state, action
 

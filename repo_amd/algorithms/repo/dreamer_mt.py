@@ -53,6 +53,11 @@ class MultitaskDreamer(Dreamer):
                 "representation (share_repr=False, the default of train_repo.py:70) is built")
         dev = self.device
         C = self.num_tasks = int(env.num_tasks)
+        if not 1 <= C <= 13:
+            # checked HERE, before seed data is collected and buffers are allocated: repo_kl_balance_tasks and the
+            # conditioned rollout take at most 13 / 16 condition columns (include/repo_hip.h); the reference's
+            # multitask suites all have 3 tasks
+            raise NotImplementedError(f"multitask agents: num_tasks = {C} is outside the kernels' 1..13")
         c = config
         # same construction order as the reference (dreamer_mt.py:66-127) => same default init under a seed
         self.encoder = ConditionalEncoder(False, obs_size, c.embedding_size, C, c.cnn_activation_function).to(dev)
@@ -177,9 +182,11 @@ class MultitaskDreamer(Dreamer):
             ac.wait_event(ev_wm)
             beliefs.record_stream(ac)
             start_tasks.record_stream(ac)
-            self.train_actor_critic(start_tasks, beliefs.flatten(0, 1), post.flatten(0, 1))
-            self._ev_ac_done = torch.cuda.Event()
-            self._ev_ac_done.record(ac)
+            try:
+                self.train_actor_critic(start_tasks, beliefs.flatten(0, 1), post.flatten(0, 1))
+            finally:   # also when the previous update's fault leaves through this one's log call (Dreamer.update)
+                self._ev_ac_done = torch.cuda.Event()
+                self._ev_ac_done.record(ac)
         if join:
             self.synchronize()
 
@@ -201,7 +208,8 @@ class MultitaskDreamer(Dreamer):
                                              embed.unsqueeze(0))
         belief, posterior_state = outs[0].squeeze(0), outs[4].squeeze(0)
         action = self.actor_model.get_action(belief, posterior_state, task, det=not explore)
-        if explore and self.c.action_noise > 0:
+        if explore:   # drawn and clamped unconditionally, as the reference does (dreamer_mt.py:161-163): with
+            # action_noise == 0 the draw still advances torch's generator, so seeded runs stay in step
             action = torch.clamp(action + torch.randn_like(action) * self.c.action_noise, -1, 1)
         return belief, posterior_state, action
 

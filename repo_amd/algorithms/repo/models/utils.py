@@ -65,6 +65,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.skip = None   # the current update's status word (ops.take_scan_status): non-zero = the step is skipped
         self.gviews = []
         with torch.no_grad():
             for p, o, n in zip(self.params, self.offsets, sizes):
@@ -89,6 +90,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+        self.skip = None
         self.gviews = parent.gviews[:n_params]
         return self
 
@@ -102,12 +104,12 @@ class FlatAdam:
         self.step_count += 1
         ops.grad_sqnorm(self.grad, out=self.sqnorm)
         ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.sqnorm, max_norm, self.lr,
-                      self.step_count, self.betas, self.eps)
+                      self.step_count, self.betas, self.eps, skip=self.skip)
 
     def step(self):
         self.step_count += 1
         ops.clip_adam(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, None, 0.0, self.lr, self.step_count,
-                      self.betas, self.eps)
+                      self.betas, self.eps, skip=self.skip)
 
     # -- torch.optim.Adam-compatible checkpoint layout -------------------------------------
     def state_dict(self):

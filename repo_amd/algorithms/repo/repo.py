@@ -109,7 +109,7 @@ class RePo(Dreamer):
         bo = self.beta_optimizer
         bo.step_count += 1
         ops.dual_step(self.log_beta, bo.exp_avg, bo.exp_avg_sq, kl_global, grow, c.target_kl, bo.lr, bo.step_count,
-                      betas=bo.betas, eps=bo.eps, out=self._dual_out)
+                      betas=bo.betas, eps=bo.eps, out=self._dual_out, skip=self._ustatus)
         self._pending_model = (torch.cat([nll_sum, rew_sums, kl_sum, self.model_optimizer.sqnorm]), self._dual_out.clone(),
                                grow)
         return sv.featx[1:, :, :D], sv.featx[1:, :, D:]
@@ -137,7 +137,7 @@ class RePo(Dreamer):
         bo = self.beta_optimizer
         bo.step_count += 1
         ops.dual_step(self.log_beta, bo.exp_avg, bo.exp_avg_sq, kl_global, grow, c.target_kl, bo.lr, bo.step_count,
-                      betas=bo.betas, eps=bo.eps, out=self._dual_out)
+                      betas=bo.betas, eps=bo.eps, out=self._dual_out, skip=self._ustatus)
         self._pending_model = (torch.cat([st["nll_sum"], st["rew_sums"], kl_sum, self.model_optimizer.sqnorm]),
                                self._dual_out.clone(), grow)
         D = c.belief_size

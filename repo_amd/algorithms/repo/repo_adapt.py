@@ -66,6 +66,7 @@ class FinetunedRePo(RePo):
                              dembeds=dembeds, min_std=self.transition_model.min_std_dev)
         Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=self._wgrad_side(B))
         opt = self.encoder_optimizer
+        self._take_status()   # both scans are behind us on this stream: the step and the dual step skip on a fault
         self._allreduce(opt.grad)
         opt.clip_and_step(c.grad_clip_norm)
         kl_global = kl_sum
@@ -75,23 +76,23 @@ class FinetunedRePo(RePo):
         bo = self.beta_optimizer
         bo.step_count += 1
         ops.dual_step(self.log_beta, bo.exp_avg, bo.exp_avg_sq, kl_global, grow, c.target_kl, bo.lr, bo.step_count,
-                      betas=bo.betas, eps=bo.eps, out=self._dual_out)
+                      betas=bo.betas, eps=bo.eps, out=self._dual_out, skip=self._ustatus)
         # logging: one asynchronous copy, read when first needed
         self._flush_enc_log()
-        buf = torch.cat([rew_sums, self._dual_out, opt.sqnorm, ops.scan_status(dev).view(torch.float32)])
+        buf = torch.cat([rew_sums, self._dual_out, opt.sqnorm, self._ustatus.view(torch.float32)])
         self._allreduce_scalars(buf, n_sum=2)
         self._enc_host[:8].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        self._enc_log = (ev, grow)
+        self._enc_log = (ev, grow, self._restore_point)
 
     def _flush_enc_log(self):
         if self._enc_log is None:
             return
-        ev, grow = self._enc_log
+        ev, grow, restore = self._enc_log
         self._enc_log = None
         ev.synchronize()
-        ops.raise_scan_status(int(self._enc_host[7:8].view(torch.int32).item()))
+        self._raise_update_fault(int(self._enc_host[7:8].view(torch.int32).item()), restore)
         rsq, rmask, kl_div, kl_loss, beta_loss, beta, gsq = self._enc_host[:7].tolist()
         reward_loss = (rsq + 0.5 * LOG_2PI * rmask) / grow
         out = {"train/reward_loss": reward_loss, "train/kl_loss": kl_loss, "train/kl_div": kl_div,

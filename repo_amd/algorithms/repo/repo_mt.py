@@ -70,7 +70,7 @@ class MultitaskRePo(MultitaskDreamer):
         bo = self.beta_optimizer
         bo.step_count += 1
         ops.dual_step_tasks(self.log_beta, bo.exp_avg, bo.exp_avg_sq, sums_global, grow, bo.lr, bo.betas, bo.eps,
-                            bo.step_count, out=self._dual_out)
+                            bo.step_count, out=self._dual_out, skip=self._ustatus)
         self._pending_model = (torch.cat([st["nll_sum"], st["rew_sums"], sums[:1], self.model_optimizer.sqnorm]),
                                self._dual_out.clone(), grow)
         D = c.belief_size

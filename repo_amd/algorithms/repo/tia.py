@@ -284,8 +284,10 @@ class TIA(Dreamer):
         params["model_optimizer"] = self._merged_model_state()
         # EXTRA keys behind the reference's (its loader reads its own keys only, so the layout stays compatible): without
         # them a resumed TIA run restores the Adam moments of five modules whose weights restart from their initial values
+        # (cloned like Dreamer.get_param_dict's entries: the parameters are views of FlatAdam's flat buffer, a held
+        # dict must not follow later updates, and torch.save would serialise the whole flat storage per view)
         for k in TIA_EXTRA_KEYS:
-            params[k] = getattr(self, k).state_dict()
+            params[k] = {name: v.detach().clone() for name, v in getattr(self, k).state_dict().items()}
         return params
 
     def load_param_dict(self, params):

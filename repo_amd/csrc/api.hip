@@ -92,11 +92,16 @@ extern "C" int repo_debug_poison_lds(hipStream_t stream) {
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
-// Test aid: the spin limit of the column-split scans' exchanges (scan_cs.hip reads it per launch).
+// Test aid: the spin limit of the column-split scans' exchanges (scan_cs.hip reads it per launch).  Like the engine
+// switches (repo_debug_bgemm / _bconv / _rowtile32) it is THREAD-LOCAL: a setting belongs to the host thread that
+// made it and governs the launches that thread issues afterwards -- another thread (another stream's driver) keeps its
+// own, default, setting, so the library has no process-global mutable state beyond the per-device arch cache above.
 namespace repo {
-static std::atomic<int> g_scan_spin_limit{1 << 22};
-int scan_cs_spin_limit() { return g_scan_spin_limit.load(std::memory_order_relaxed); }
+static thread_local int t_scan_spin_limit = 1 << 22;
+int scan_cs_spin_limit() { return t_scan_spin_limit; }
 }  // namespace repo
 extern "C" int repo_debug_scan_spin_limit(int polls) {
-  return repo::g_scan_spin_limit.exchange(polls < 0 ? (1 << 22) : polls, std::memory_order_relaxed);
+  const int prev = repo::t_scan_spin_limit;
+  repo::t_scan_spin_limit = polls < 0 ? (1 << 22) : polls;
+  return prev;
 }

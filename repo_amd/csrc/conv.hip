@@ -27,12 +27,12 @@
 #include "buconv.h"
 #include "bwgrad.h"
 
-#include <atomic>
 
 namespace repo {
 
-// Test aid (repo_debug_bconv): 0 keeps every conv layer on the fp32-MFMA kernels
-static std::atomic<int> g_bconv_enabled{1};
+// Test aid (repo_debug_bconv): 0 keeps every conv layer on the fp32-MFMA kernels.  Thread-local (api.hip): the setting
+// of the calling host thread, read at launch time.
+static thread_local int t_bconv_enabled = 1;
 
 template <int CB_, int CS_, int HB_, int KS_>
 struct Geo {
@@ -447,7 +447,7 @@ template <class G> constexpr bool kBDown = !std::is_same<typename BDownFor<G>::t
 
 template <class G>
 static bool bconv_down_on(int64_t nimg) {
-  if constexpr (kBDown<G>) return g_bconv_enabled.load(std::memory_order_relaxed) && nimg * (int64_t)G::PS > 512;
+  if constexpr (kBDown<G>) return t_bconv_enabled && nimg * (int64_t)G::PS > 512;
   return false;
 }
 template <class G>
@@ -582,7 +582,7 @@ template <> struct BUConf<GEnc4> { using type = BSConf<GEnc4, 8, 2>; };   // CS 
 template <> struct BUConf<GDec2> { using type = BSConf<GDec2, 5, 4>; };   // CS = 128, k5: per-class tap sets
 template <class G>
 static bool buconv_on() {
-  if constexpr (!std::is_void<typename BUConf<G>::type>::value) return g_bconv_enabled.load(std::memory_order_relaxed) != 0;
+  if constexpr (!std::is_void<typename BUConf<G>::type>::value) return t_bconv_enabled != 0;
   return false;
 }
 
@@ -687,7 +687,7 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
   int rc;
   if constexpr (kBWgrad<G> && std::is_same<BigT, float>::value) {
     static_assert(DTileFor<G>::Wgrad::GI % BWgradFor<G>::type::GI == 0, "images per split: a multiple of both kernels' chunks");
-    if (g_bconv_enabled.load(std::memory_order_relaxed)) rc = launch_bconv_wgrad<G, typename BWgradFor<G>::type>(a, dsplits, s);
+    if (t_bconv_enabled) rc = launch_bconv_wgrad<G, typename BWgradFor<G>::type>(a, dsplits, s);
     else rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
   } else {
     rc = launch_dconv_wgrad<G, BigT, typename DTileFor<G>::Wgrad>(a, dsplits, s);
@@ -751,7 +751,11 @@ extern "C" size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg) {
                                    (size_t)conv_down_tiles<G>(nimg) * G::CS * sizeof(float)))
 }
 
-extern "C" int repo_debug_bconv(int enable) { return g_bconv_enabled.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int repo_debug_bconv(int enable) {
+  const int prev = t_bconv_enabled;
+  t_bconv_enabled = enable ? 1 : 0;
+  return prev;
+}
 
 extern "C" size_t repo_conv_up_workspace_bytes(int layer) {
   REPO_LAYER_SWITCH(layer, return (conv_up_ws_bytes<G>()))

@@ -11,7 +11,7 @@
 namespace repo {
 
 // Test aid (repo_debug_bgemm): 0 keeps every product on the fp32-MFMA tile engines, for A/B runs in one process.
-static std::atomic<int> g_bgemm_enabled{1};
+static thread_local int t_bgemm_enabled = 1;   // thread-local: see api.hip
 
 template <bool TA, bool TB>
 struct GemmOp {
@@ -463,7 +463,7 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
     return REPO_OK;
   }
   // big products: the bf16x6 engine (bgemm.h): fp32-accurate at 6/16 of the fp32 MFMA's time per k
-  if (g_bgemm_enabled.load(std::memory_order_relaxed) && bgemm_ok(M, N, K, !transa, lda, transb != 0, ldb, A, B)) {
+  if (t_bgemm_enabled && bgemm_ok(M, N, K, !transa, lda, transb != 0, ldb, A, B)) {
     BgArgs a{Dense2D{A, 4u * (unsigned)(transa ? (K - 1) * lda + M : (M - 1) * lda + K), (int)lda},
              Dense2D{B, 4u * (unsigned)(transb ? (N - 1) * ldb + K : (K - 1) * ldb + N), (int)ldb},
              bias, aux, C, (int)ldc, (int)ldaux, (int)bias_div, (int)M, (int)N, (int)K, epi, accumulate};
@@ -510,7 +510,11 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
 #undef REPO_GEMM_CASE
 }
 
-extern "C" int repo_debug_bgemm(int enable) { return g_bgemm_enabled.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int repo_debug_bgemm(int enable) {
+  const int prev = t_bgemm_enabled;
+  t_bgemm_enabled = enable ? 1 : 0;
+  return prev;
+}
 
 extern "C" size_t repo_gemm_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -540,7 +544,7 @@ extern "C" int repo_gemm_wgrad(int64_t M, int64_t N, int64_t K, const float* dY,
   }
   // a big weight gradient without a bias column (the decoder's 1024 x 3200 first transposed conv): ONE product on the
   // bf16x6 engine, dW[n][k] = sum_rows dY[row][n] X[row][k] with both operands row-contiguous -- no split-K slabs
-  if (!db && g_bgemm_enabled.load(std::memory_order_relaxed) && bgemm_ok(N, K, M, false, lddy, false, ldx, dY, X)) {
+  if (!db && t_bgemm_enabled && bgemm_ok(N, K, M, false, lddy, false, ldx, dY, X)) {
     BgArgs a{Dense2D{dY, 4u * (unsigned)((M - 1) * lddy + N), (int)lddy}, Dense2D{X, 4u * (unsigned)((M - 1) * ldx + K), (int)ldx},
              nullptr, nullptr, dW, (int)lddw, 0, 1, (int)N, (int)K, (int)M, REPO_EPI_NONE, accumulate};
     return bgemm_dispatch<false, false>(a, stream);

@@ -20,21 +20,21 @@ namespace repo {
 __global__ void actor_head_fwd_kernel(int rows, int A, int S, const float* __restrict__ raw,
                                       const float* __restrict__ eps, const float* __restrict__ state, int ldstate,
                                       float min_std, float init_std, float mean_scale, float* __restrict__ mean,
-                                      float* __restrict__ stdv, float* __restrict__ xsa) {
-  const int X = S + A;
+                                      float* __restrict__ stdv, float* __restrict__ xsa, int ldx) {
+  const int X = S + A;   // ldx >= X: the conditioned rollout keeps C more columns per xsa row ([state | action | cond])
   const int total = rows * (eps ? X : A);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     if (eps) {
       const int row = i / X, k = i % X;
       if (k < S) {
-        xsa[(size_t)row * X + k] = state[(size_t)row * ldstate + k];
+        xsa[(size_t)row * ldx + k] = state[(size_t)row * ldstate + k];
       } else {
         const int a = k - S;
         const float mu = mean_scale * tanh_fast(raw[(size_t)row * 2 * A + a] / mean_scale);
         const float sd = softplus(raw[(size_t)row * 2 * A + A + a] + init_std) + min_std;
         mean[(size_t)row * A + a] = mu;
         stdv[(size_t)row * A + a] = sd;
-        xsa[(size_t)row * X + k] = tanh_fast(fmaf(sd, eps[(size_t)row * A + a], mu));
+        xsa[(size_t)row * ldx + k] = tanh_fast(fmaf(sd, eps[(size_t)row * A + a], mu));
       }
     } else {
       const int row = i / A, a = i % A;
@@ -376,16 +376,23 @@ extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
 }
 
 // =================================================================== actor distribution head
+static int actor_head_fwd_ld(int64_t rows, int64_t A, int64_t S, const float* raw, const float* eps,
+                             const float* state, int64_t ldstate, float min_std, float init_std, float mean_scale,
+                             float* mean, float* std, float* xsa, int64_t ldx, hipStream_t stream) {
+  REPO_REQUIRE(rows > 0 && A > 0 && ldx >= S + A && rows * ldx < kMaxIdx, REPO_E_SHAPE);
+  REPO_REQUIRE(raw && mean && std && (!eps || (state && xsa)), REPO_E_BADARG);
+  hipLaunchKernelGGL(actor_head_fwd_kernel, dim3(ew_blocks(rows * (S + A))), dim3(256), 0, stream, (int)rows, (int)A,
+                     (int)S, raw, eps, state, (int)ldstate, min_std, init_std, mean_scale, mean, std, xsa, (int)ldx);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
 extern "C" int repo_actor_head_fwd(int64_t rows, int64_t A, int64_t S, const float* raw, const float* eps,
                                    const float* state, int64_t ldstate, float min_std, float init_std,
                                    float mean_scale, float* mean, float* std, float* xsa, hipStream_t stream) {
   REPO_ARCH_GUARD();
-  REPO_REQUIRE(rows > 0 && A > 0 && rows * (S + A) < kMaxIdx, REPO_E_SHAPE);
-  REPO_REQUIRE(raw && mean && std && (!eps || (state && xsa)), REPO_E_BADARG);
-  hipLaunchKernelGGL(actor_head_fwd_kernel, dim3(ew_blocks(rows * (S + A))), dim3(256), 0, stream, (int)rows, (int)A,
-                     (int)S, raw, eps, state, (int)ldstate, min_std, init_std, mean_scale, mean, std, xsa);
-  REPO_CHECK_LAUNCH();
-  return REPO_OK;
+  return actor_head_fwd_ld(rows, A, S, raw, eps, state, ldstate, min_std, init_std, mean_scale, mean, std, xsa, S + A,
+                           stream);
 }
 
 extern "C" int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, const float* dstd,
@@ -402,6 +409,8 @@ extern "C" int repo_actor_head_bwd(int64_t rows, int64_t A, const float* dmean, 
 }
 
 // =================================================================== imagination rollout
+// most condition columns the per-step engine takes (the multitask kernels' own limit is 13: multitask.hip)
+constexpr int64_t kImgMaxCond = 16;
 static bool img_dims_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S) {
   return Hm >= 1 && N > 0 && A > 0 && D > 0 && Hd > 0 && S > 0 && (Hm + 1) * N * 4 * D < kMaxIdx;
 }
@@ -409,7 +418,9 @@ static bool img_dims_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
 extern "C" size_t repo_rssm_imagine_fwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S) {
   // per-step engine: gate / head scratch + room to materialise the two noise tensors when they are drawn in-library
-  const size_t unfused = ((size_t)N * (6 * D + 2 * S) + (size_t)Hm * N * (A + S)) * sizeof(float);
+  // (+ the [belief | state | cond] rows of one step when the rollout is conditioned and outside the persistent
+  // engines' shapes: C <= kImgMaxCond)
+  const size_t unfused = ((size_t)N * (6 * D + 2 * S + D + S + kImgMaxCond) + (size_t)Hm * N * (A + S)) * sizeof(float);
   size_t fused = imagine_fused_fwd_ws_floats(A, D, Hd, S) * sizeof(float);
   const size_t fused32 = imagine32_fwd_ws_bytes(A, D, Hd, S);
   if (fused32 > fused) fused = fused32;
@@ -434,8 +445,10 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_fwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
   REPO_REQUIRE(C >= 0 && (C == 0 || cond), REPO_E_BADARG);
-  // a conditioned rollout runs on the persistent engine only (the condition rides in the K padding of its tiles)
-  REPO_REQUIRE(C == 0 || imagine_fused_ok(Hm, N, A, D, Hd, S, n_actor_layers, C), REPO_E_SHAPE);
+  // a conditioned rollout rides in the K padding of the persistent engines' tiles where it fits (230 + C <= 240 and
+  // S + A + C within S + A's 16-column block: A = 3..8 at S = 30); other shapes -- the reference's A = 2 multitask suites,
+  // tabletop/pointmass.py:114 and the dmc-mixed tasks -- take the per-step engine below with widened rows
+  REPO_REQUIRE(C <= kImgMaxCond, REPO_E_SHAPE);
   if (imagine32_ok(Hm, N, A, D, Hd, S, n_actor_layers, C))
     return imagine32_fwd(Hm, N, A, D, Hd, S, rssm_params, actor_params, belief0, state0, cond, C,
                          NoiseSrc{eps_act, noise_seed, noise_offset},
@@ -447,13 +460,14 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                              NoiseSrc{eps_act, noise_seed, noise_offset},
                              NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_init_std, a_mean_scale, featx, prior_mean, prior_std, a_hidden,
                              a_layer_rows, a_raw, a_mean, a_std, xsa, e, gates, hp, ws, stream);
-  const int64_t F = D + S, X = S + A, rowsAll = Hm * N;
+  const int64_t F = D + S, X = S + A + C, Fw = F + C, rowsAll = Hm * N;   // X, Fw: the conditioned rows' widths
   const float* const* P = rssm_params;
   float* gi = (float*)ws;
   float* gh = gi + (size_t)N * 3 * D;
   float* pout = gh + (size_t)N * 3 * D;
+  float* wide = pout + (size_t)N * 2 * S;   // [belief | state | cond] rows of the current step (C > 0)
   if (!eps_act) {  // draw the tensors the fused engine would have drawn element by element
-    float* na = pout + (size_t)N * 2 * S;
+    float* na = wide + (size_t)N * (F + kImgMaxCond);
     float* np_ = na + (size_t)Hm * N * A;
     REPO_RC(philox_fill(na, Hm * N * A, noise_seed, noise_offset, stream));
     REPO_RC(philox_fill(np_, Hm * N * S, noise_seed, noise_offset + (uint64_t)(Hm * N * A), stream));
@@ -473,9 +487,20 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
     // actor MLP on (detached) [belief, state]
     float* hid[8];
     for (int l = 0; l < n_actor_layers - 1; ++l) hid[l] = a_hidden + ((size_t)l * a_layer_rows + r0) * Hd;
-    REPO_RC(mlp_fwd_layers(N, F, Hd, 2 * A, n_actor_layers, ft, F, actor_params, hid, a_raw + r0 * 2 * A, 2 * A, stream));
-    REPO_RC(repo_actor_head_fwd(N, A, S, a_raw + r0 * 2 * A, eps_act + r0 * A, ft + D, F, a_min_std, a_init_std,
-                                a_mean_scale, a_mean + r0 * A, a_std + r0 * A, xsa + r0 * X, stream));
+    const float* ain = ft;
+    if (C) {   // the actor's fc1 and W_sa carry C more input columns: [belief | state | cond], [state | action | cond]
+      hipLaunchKernelGGL(add_cols_kernel, dim3(ew_blocks(N * F)), dim3(256), 0, stream, (int)N, (int)F, ft, (int)F,
+                         (const float*)nullptr, 0, wide, (int)Fw);
+      hipLaunchKernelGGL(add_cols_kernel, dim3(ew_blocks(N * C)), dim3(256), 0, stream, (int)N, (int)C, cond, (int)C,
+                         (const float*)nullptr, 0, wide + F, (int)Fw);
+      hipLaunchKernelGGL(add_cols_kernel, dim3(ew_blocks(N * C)), dim3(256), 0, stream, (int)N, (int)C, cond, (int)C,
+                         (const float*)nullptr, 0, xsa + r0 * X + S + A, (int)X);
+      REPO_CHECK_LAUNCH();
+      ain = wide;
+    }
+    REPO_RC(mlp_fwd_layers(N, Fw, Hd, 2 * A, n_actor_layers, ain, Fw, actor_params, hid, a_raw + r0 * 2 * A, 2 * A, stream));
+    REPO_RC(actor_head_fwd_ld(N, A, S, a_raw + r0 * 2 * A, eps_act + r0 * A, ft + D, F, a_min_std, a_init_std,
+                              a_mean_scale, a_mean + r0 * A, a_std + r0 * A, xsa + r0 * X, X, stream));
     // belief update
     REPO_RC(lin(N, D, X, xsa + r0 * X, X, P[0], P[1], e + r0 * D, D, REPO_EPI_ELU, stream));
     REPO_RC(lin(N, 3 * D, D, e + r0 * D, D, P[2], P[4], gi, 3 * D, REPO_EPI_NONE, stream));
@@ -496,7 +521,7 @@ extern "C" int repo_rssm_imagine_fwd(int64_t Hm, int64_t N, int64_t A, int64_t D
 extern "C" size_t repo_rssm_imagine_bwd_workspace_bytes(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd,
                                                         int64_t S) {
   // g(F) carry(F) dpout(2S) dhp(Hd) dbel(D) dgi(3D) dgh(3D) de(D) dxsa(S+A) + the two noise tensors
-  const size_t unfused = ((size_t)N * (2 * (D + S) + 2 * S + Hd + D + 6 * D + D + (S + A)) + (size_t)Hm * N * (A + S)) * sizeof(float);
+  const size_t unfused = ((size_t)N * (2 * (D + S) + 2 * S + Hd + D + 6 * D + D + (S + A + kImgMaxCond)) + (size_t)Hm * N * (A + S)) * sizeof(float);
   size_t fused = imagine_fused_bwd_ws_floats(A, D, Hd, S) * sizeof(float);
   if (fused < imagine32_bwd_ws_bytes(A, D, Hd, S)) fused = imagine32_bwd_ws_bytes(A, D, Hd, S);
   return unfused > fused ? unfused : fused;
@@ -516,7 +541,7 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                    hp && dfeat && d_araw,
                REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_rssm_imagine_bwd_workspace_bytes(Hm, N, A, D, Hd, S), REPO_E_WS_TOO_SMALL);
-  REPO_REQUIRE(C == 0 || imagine_fused_ok(Hm, N, A, D, Hd, S, 5, C), REPO_E_SHAPE);
+  REPO_REQUIRE(C >= 0 && C <= kImgMaxCond, REPO_E_SHAPE);
   if (imagine32_ok(Hm, N, A, D, Hd, S, 5, C))
     return imagine32_bwd(Hm, N, A, D, Hd, S, rssm_params, C, NoiseSrc{eps_act, noise_seed, noise_offset},
                          NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std,
@@ -527,7 +552,7 @@ extern "C" int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D
                              NoiseSrc{eps_prior, noise_seed, noise_offset + (uint64_t)(Hm * N * A)}, min_std, a_min_std, a_mean_scale,
                              featx, prior_std, a_mean, a_std, xsa, e, gates, hp, dfeat, dprior_mean, dprior_std,
                              d_araw, dfeat0, ws, stream);
-  const int64_t F = D + S, X = S + A;
+  const int64_t F = D + S, X = S + A + C;   // xsa rows = [state | action | cond]; the cond columns' gradient is unused
   const float* const* P = rssm_params;
   float* w = (float*)ws;
   float* g = w;      w += (size_t)N * F;   // total grad on featx[t+1]

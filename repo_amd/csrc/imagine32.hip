@@ -568,8 +568,8 @@ constexpr int kBF32 = 15, kBW32 = 13, kBX32 = 3;
 #ifndef RT32_DEFAULT
 #define RT32_DEFAULT 1
 #endif
-static std::atomic<int> g_rowtile32_enabled{RT32_DEFAULT};
-bool rowtile32_enabled() { return g_rowtile32_enabled.load(std::memory_order_relaxed) != 0; }
+static thread_local int t_rowtile32_enabled = RT32_DEFAULT;   // thread-local: see api.hip
+bool rowtile32_enabled() { return t_rowtile32_enabled != 0; }
 
 bool imagine32_ok(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64_t S, int n_actor_layers, int64_t C) {
   auto blk = [](int64_t k) { return pad16((int)k) >> 4; };
@@ -704,5 +704,7 @@ int imagine32_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t Hd, int64
 }  // namespace repo
 
 extern "C" int repo_debug_rowtile32(int enable) {
-  return repo::g_rowtile32_enabled.exchange(enable ? 1 : 0, std::memory_order_relaxed);
+  const int prev = repo::t_rowtile32_enabled;
+  repo::t_rowtile32_enabled = enable ? 1 : 0;
+  return prev;
 }

@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void kl_kernel(int rows, int S, const float* _
 __global__ void dual_step_kernel(float* __restrict__ log_beta, float* __restrict__ m, float* __restrict__ v,
                                  const float* __restrict__ kl_sum, float inv_rows, float target_kl, float lr, float b1,
                                  float b2, float eps, float bc1, float bc2_sqrt, int apply,
-                                 float* __restrict__ scalars_out) {
+                                 float* __restrict__ scalars_out, const unsigned* __restrict__ skip) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (skip && *skip) apply = 0;   // a faulted update: log the (NaN) scalars, leave the dual variable alone
   const float lb = *log_beta;
   const float kl_div = *kl_sum * inv_rows;
   const float viol = kl_div - target_kl;
@@ -400,14 +401,14 @@ extern "C" int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const f
 
 extern "C" int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const float* kl_sum, int64_t rows,
                               float target_kl, float lr, float beta1, float beta2, float eps, int64_t step, int apply,
-                              float* scalars_out, hipStream_t stream) {
+                              float* scalars_out, const unsigned* skip_if_nonzero, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(log_beta && exp_avg && exp_avg_sq && kl_sum && scalars_out && rows > 0 && step >= 1, REPO_E_BADARG);
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(dual_step_kernel, dim3(1), dim3(64), 0, stream, log_beta, exp_avg, exp_avg_sq, kl_sum,
                      (float)(1.0 / (double)rows), target_kl, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), apply,
-                     scalars_out);
+                     scalars_out, skip_if_nonzero);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }

@@ -153,9 +153,10 @@ __global__ void mt_final_sum_kernel(const float* __restrict__ parts, int n, int 
 __global__ void dual_step_tasks_kernel(int C, float* __restrict__ log_beta, float* __restrict__ m,
                                        float* __restrict__ v, const float* __restrict__ sums, float inv_rows, float lr,
                                        float b1, float b2, float eps, float bc1, float bc2_sqrt, int apply,
-                                       float* __restrict__ scalars_out) {
+                                       float* __restrict__ scalars_out, const unsigned* __restrict__ skip) {
   const int i = threadIdx.x;
   if (blockIdx.x != 0) return;
+  if (skip && *skip) apply = 0;   // a faulted update: see repo_clip_adam
   if (i == 0) {
     scalars_out[0] = sums[0] * inv_rows;
     scalars_out[1] = sums[1] * inv_rows;
@@ -238,14 +239,16 @@ extern "C" int repo_kl_balance_tasks(int64_t rows, int64_t S, int64_t C, const f
 
 extern "C" int repo_dual_step_tasks(int64_t C, float* log_beta, float* exp_avg, float* exp_avg_sq, const float* sums,
                                     int64_t rows, float lr, float beta1, float beta2, float eps, int64_t step,
-                                    int apply, float* scalars_out, hipStream_t stream) {
+                                    int apply, float* scalars_out, const unsigned* skip_if_nonzero,
+                                    hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(C >= 1 && C <= kMtMaxTasks && rows > 0 && step >= 1, REPO_E_SHAPE);
   REPO_REQUIRE(log_beta && exp_avg && exp_avg_sq && sums && scalars_out, REPO_E_BADARG);
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(dual_step_tasks_kernel, dim3(1), dim3(64), 0, stream, (int)C, log_beta, exp_avg, exp_avg_sq, sums,
-                     (float)(1.0 / (double)rows), lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), apply, scalars_out);
+                     (float)(1.0 / (double)rows), lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), apply, scalars_out,
+                     skip_if_nonzero);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }

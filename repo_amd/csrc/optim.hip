@@ -34,7 +34,9 @@ __global__ void sqnorm_final_kernel(const float* __restrict__ parts, int n, floa
 __global__ __launch_bounds__(256) void clip_adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         const float* __restrict__ sqnorm, float max_norm, float lr_bc1,
-                                                        float b1, float b2, float eps, float inv_bc2_sqrt) {
+                                                        float b1, float b2, float eps, float inv_bc2_sqrt,
+                                                        const unsigned* __restrict__ skip) {
+  if (skip && *skip) return;   // a faulted update (scan timeout: NaN gradients) must not touch the model
   float coef = 1.f;
   if (sqnorm) {
     coef = max_norm / (sqrtf(*sqnorm) + 1e-6f);
@@ -75,7 +77,7 @@ extern "C" int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* 
 
 extern "C" int repo_clip_adam(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                               const float* sqnorm, float max_norm, float lr, float beta1, float beta2, float eps,
-                              int64_t step, hipStream_t stream) {
+                              int64_t step, const unsigned* skip_if_nonzero, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(n > 0 && step >= 1, REPO_E_SHAPE);
   REPO_REQUIRE(params && grads && exp_avg && exp_avg_sq, REPO_E_BADARG);
@@ -85,7 +87,7 @@ extern "C" int repo_clip_adam(int64_t n, float* params, const float* grads, floa
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, params, grads, exp_avg,
                      exp_avg_sq, sqnorm, max_norm, (float)((double)lr / bc1), beta1, beta2, eps,
-                     (float)(1.0 / sqrt(bc2)));
+                     (float)(1.0 / sqrt(bc2)), skip_if_nonzero);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }

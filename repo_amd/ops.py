@@ -290,7 +290,9 @@ def scan_status(device):
     column-split engine ORs REPO_SCAN_STATUS_* bits into it when a spin-wait on a peer workgroup times out).  One int32
     per device, zeroed once; every scan launch of this process passes it.  The agents append it to their per-update
     scalar copy (`Dreamer._log_update`) -- no extra transfer -- and raise; anyone else calls `check_scan_status`."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
+    device = torch.device(device)
+    # (a host word for CPU devices: the data-parallel status protocol is exercised over gloo without a GPU)
+    idx = "cpu" if device.type == "cpu" else device.index if device.index is not None else torch.cuda.current_device()
     w = _scan_status.get(idx)
     if w is None:
         w = _scan_status[idx] = torch.zeros(1, dtype=torch.int32, device=device)
@@ -300,19 +302,39 @@ def scan_status(device):
 SCAN_STATUS_TEXT = {1: "forward", 2: "reverse", 3: "forward and reverse"}
 
 
-def raise_scan_status(word):
+def raise_scan_status(word, consequence="the outputs of that call are NaN-poisoned"):
     """word: the status value read on the host (0 = fine)."""
     if word:
         from ._lib import RepoHipError
         raise RepoHipError(
             f"column-split observe scan ({SCAN_STATUS_TEXT.get(word & 3, word)}): a spin-wait on a peer workgroup timed "
-            "out (the group's workgroups were not co-resident); the outputs of that update are NaN-poisoned.  "
+            f"out (the group's workgroups were not co-resident); {consequence}.  "
             "REPO_SCAN_CS=0 selects the row-scan engine, which has no cross-workgroup waits.")
 
 
 def check_scan_status(device):
-    """Synchronising read of the status word (tests, callers outside the agents' update loop)."""
-    raise_scan_status(int(scan_status(device).item()))
+    """Synchronising read of the status word (tests, callers outside the agents' update loop).  The word is cleared
+    before the exception leaves: the fault is reported once, the caller may recover (REPO_SCAN_CS=0) and go on."""
+    w = scan_status(device)
+    word = int(w.item())
+    if word:
+        w.zero_()
+    raise_scan_status(word)
+
+
+def take_scan_status(device, dp=None):
+    """The per-UPDATE status word: a copy of the device's sticky word, which is cleared in the same stream order --
+    call it on the stream that has joined every scan of the update, before the first optimiser step.  Every step of
+    the update then takes the copy as `skip` (repo_clip_adam: a faulted update leaves parameters, moments and the dual
+    variable untouched) and the agent appends it to the update's scalar copy.  Data parallel: the copy is MAX-reduced
+    over the ranks first, so that a timeout on ONE rank makes EVERY rank skip the same steps and raise in the same
+    update (its NaN gradient has been summed into every replica's buffer by then)."""
+    w = scan_status(device)
+    st = w.clone()
+    w.zero_()
+    if dp is not None:
+        dp.all_reduce_status(st)
+    return st
 
 
 class ObserveSaved:
@@ -583,12 +605,13 @@ def kl_balance(pm, ps, qm, qs, mode, alpha, log_beta, free_nats, scale, want_gra
 
 
 def dual_step(log_beta, exp_avg, exp_avg_sq, kl_sum, rows, target_kl, lr, step, apply=True, betas=(0.9, 0.999),
-              eps=1e-8, out=None):
+              eps=1e-8, out=None, skip=None):
+    """skip: the update's status word (int32 device tensor, see `take_scan_status`): non-zero = leave log_beta alone."""
     if out is None:
         out = torch.empty(4, dtype=torch.float32, device=log_beta.device)
     check(
         lib().repo_dual_step(_ptr(log_beta), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(kl_sum), rows, float(target_kl),
-                             float(lr), betas[0], betas[1], eps, step, int(apply), _ptr(out), _stream()),
+                             float(lr), betas[0], betas[1], eps, step, int(apply), _ptr(out), _ptr(skip), _stream()),
         "repo_dual_step",
     )
     return out
@@ -704,10 +727,12 @@ def grad_sqnorm(g, out=None):
     return out
 
 
-def clip_adam(p, g, m, v, sqnorm, max_norm, lr, step, betas=(0.9, 0.999), eps=1e-8):
+def clip_adam(p, g, m, v, sqnorm, max_norm, lr, step, betas=(0.9, 0.999), eps=1e-8, skip=None):
+    """skip: the update's status word (int32 device tensor, see `take_scan_status`): if it is non-zero when the kernel
+    runs, parameters and moments are left untouched (include/repo_hip.h, repo_clip_adam)."""
     check(
         lib().repo_clip_adam(p.numel(), _ptr(_f32c(p)), _ptr(_f32c(g)), _ptr(_f32c(m)), _ptr(_f32c(v)), _ptr(sqnorm),
-                             float(max_norm), float(lr), betas[0], betas[1], eps, step, _stream()),
+                             float(max_norm), float(lr), betas[0], betas[1], eps, step, _ptr(skip), _stream()),
         "repo_clip_adam",
     )
 
@@ -766,11 +791,11 @@ def kl_balance_tasks(pm, ps, qm, qs, alpha, log_beta, tasks, target_kl, scale):
     return sums, g
 
 
-def dual_step_tasks(log_beta, exp_avg, exp_avg_sq, sums, rows, lr, betas, eps, step, apply=True, out=None):
+def dual_step_tasks(log_beta, exp_avg, exp_avg_sq, sums, rows, lr, betas, eps, step, apply=True, out=None, skip=None):
     C = log_beta.numel()
     if out is None:
         out = torch.empty(3 + C, dtype=torch.float32, device=log_beta.device)
     check(lib().repo_dual_step_tasks(C, _ptr(log_beta), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(sums), int(rows), float(lr),
                                      float(betas[0]), float(betas[1]), float(eps), int(step), int(bool(apply)), _ptr(out),
-                                     _stream()), "repo_dual_step_tasks")
+                                     _ptr(skip), _stream()), "repo_dual_step_tasks")
     return out

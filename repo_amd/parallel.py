@@ -46,6 +46,14 @@ class DataParallel:
         dist.all_reduce(buf[:n], op=dist.ReduceOp.SUM, group=self.group)
         return buf
 
+    def all_reduce_status(self, word):
+        """MAX all-reduce of an update's int32 status word (ops.take_scan_status): bit patterns are small non-negative
+        integers (REPO_SCAN_STATUS_*: 1 = forward, 2 = reverse, 3 = both), so the maximum is non-zero on every rank as
+        soon as it is on one -- and every rank then skips the same optimiser steps and raises in the same update
+        instead of one rank raising alone while its peers wait in the next gradient all-reduce."""
+        dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group)
+        return word
+
     def all_reduce_begin(self, t, stream=None):
         """Start a SUM all-reduce of `t` (a contiguous slice of a flat gradient buffer) so that the kernels
         issued next overlap it (the encoder backward while the decoder's 15.7 MB bucket is on the wire);

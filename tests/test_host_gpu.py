@@ -322,6 +322,17 @@ class ThreadDP:
         self.all_reduce(buf[:n])
         return buf
 
+    def all_reduce_status(self, word):   # MAX of small non-negative integers, as DataParallel.all_reduce_status
+        sh = self.sh
+        sh["slot"][self.rank] = word
+        torch.cuda.current_stream().synchronize()
+        sh["barrier"].wait()
+        top = torch.stack([sh["slot"][r] for r in range(self.world_size)]).amax(0)
+        torch.cuda.current_stream().synchronize()
+        sh["barrier"].wait()
+        word.copy_(top)
+        return word
+
     # the agent's bucketed exchange (Dreamer._model_bucket_begin): begun in the same order on every rank; the
     # stand-in completes each bucket at once, RCCL completes it on its own stream
     def all_reduce_begin(self, t, stream=None):

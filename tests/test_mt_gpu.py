@@ -116,13 +116,16 @@ def test_kl_balance_tasks_and_dual_step_match_torch(rows, C):
     assert bool((dlb.cpu()[~touched] == lb0[~touched]).all())
 
 
-def test_conditioned_rollout_matches_oracle():
+@pytest.mark.parametrize("A,C", [(6, 3), (2, 3), (2, 10), (9, 13)])
+def test_conditioned_rollout_matches_oracle(A, C):
     """repo_rssm_imagine_fwd / _bwd with cond (ConditionalTransitionModel.imagine + ConditionalActorModel,
     models/rssm.py:221-249): every saved tensor against the oracle's conditioned rollout, the actor-output gradient and
-    the start-state gradient against autograd through it."""
+    the start-state gradient against autograd through it.  A = 6: the persistent engines (the condition in their K
+    padding); A = 2 -- the reference's pointmass and dmc-mixed multitask suites (tabletop/pointmass.py:114) -- and
+    C = 13: outside their shapes, the per-step engine with widened rows."""
     from repo_amd import ops
 
-    A, C, D, S, Hm, N = 6, 3, 200, 30, 4, 37
+    D, S, Hm, N = 200, 30, 4, 37
     P = fx.make_params(A, 7, cond=C)
     rp = {k: torch.from_numpy(v).requires_grad_(False) for k, v in P["transition_model"].items()}
     ap = {k: torch.from_numpy(v).requires_grad_(True) for k, v in P["actor_model"].items()}
@@ -191,11 +194,12 @@ def test_mt_update_matches_reference_goldens(golden_dir, fname, algo):
         assert abs(sums[n] - s_) <= 1e-3 * abs(a_) + 1e-7, (n, sums[n], s_)
 
 
-@pytest.mark.parametrize("algo", ["dreamer_multitask", "repo_multitask"])
-def test_mt_update_matches_oracle_grads(algo):
+@pytest.mark.parametrize("algo,A", [("dreamer_multitask", 6), ("repo_multitask", 6), ("repo_multitask", 2)])
+def test_mt_update_matches_oracle_grads(algo, A):
     """Flat pre-clip gradients of the three optimisers against the oracle's autograd, per module too (the FiLM layers'
-    and the condition columns' gradients vanish in the flat norm), with the KL term active."""
-    L, B, H, A, C = 9, 5, 5, 6, 3
+    and the condition columns' gradients vanish in the flat norm), with the KL term active.  A = 2: the action size of
+    two of the reference's three multitask suites (the rollout then runs on the per-step engine)."""
+    L, B, H, C = 9, 5, 5, 3
     over = dict(init_beta=0.05, target_kl=0.3, beta_lr=1e-2, free_nats=0.1)
     agent, cfg = make_mt(algo, L, B, H, A, C, **over)
     oracle = ro.OracleMultitask(cfg, A, C, seed=7)

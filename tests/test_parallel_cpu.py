@@ -270,3 +270,52 @@ def test_dp_dropping_any_exchange_is_detected(drop, expect):
     want = _full_batch(L, B, H, A)
     got = _run_world(L, B, H, A, world, drop=drop)
     assert expect in _mismatches(got[0], want), (drop, _mismatches(got[0], want))
+
+
+def _fault_worker(rank, world, port, faulty_rank, out):
+    """The status protocol of a faulted update (Dreamer._take_status / _raise_update_fault) over gloo: a scan timeout
+    on ONE rank must make EVERY rank skip its steps and raise in the same update, and the collectives behind it must
+    still line up (nobody is left waiting in the next gradient all-reduce)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from repo_amd import ops
+    from repo_amd._lib import RepoHipError
+
+    dp = DataParallel()
+    cpu = torch.device("cpu")
+    events = []
+    for update, fault in enumerate((None, faulty_rank, None)):
+        # ... the scans of this update ran; the column-split engine ORed a bit into THIS rank's sticky word
+        if fault == rank:
+            ops.scan_status(cpu).fill_(2)
+        st = ops.take_scan_status(cpu, dp)                 # the update's own copy, MAX-reduced; sticky word cleared
+        assert int(ops.scan_status(cpu).item()) == 0
+        grad = torch.full((5,), float(rank + 1))
+        dp.all_reduce(grad)                                # the gradient exchange every rank still takes part in
+        stepped = int(st.item()) == 0                      # what repo_clip_adam's skip_if_nonzero decides on the device
+        try:
+            ops.raise_scan_status(int(st.item()), "the update's optimiser steps were skipped")
+            events.append((update, "ok", stepped, float(grad[0])))
+        except RepoHipError as e:
+            events.append((update, "raised", stepped, "reverse" in str(e)))
+    dp.barrier()
+    out.put((rank, events))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("faulty_rank", [0, 1])
+def test_dp_rank_local_scan_fault_raises_on_every_rank_in_the_same_update(faulty_rank):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, faulty_rank, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get() for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0          # neither rank hung or died
+    want = [(0, "ok", True, 3.0), (1, "raised", False, True), (2, "ok", True, 3.0)]
+    assert got[0] == want and got[1] == want, got

@@ -687,3 +687,83 @@ def test_scan_timeout_reaches_the_host():
     agent, _ = make_agent("repo", 6, 3, 4, 6)
     agent.update(dev_batch(6, 3, 6, 11)[0])
     assert all(math.isfinite(v) for v in agent.last_scalars.values())
+
+
+def _agent_state(agent):
+    opts = [agent.model_optimizer, agent.actor_optimizer, agent.value_optimizer]
+    ts = [t.clone() for o in opts for t in (o.flat, o.exp_avg, o.exp_avg_sq)]
+    ts += [agent.log_beta.clone(), agent.beta_optimizer.exp_avg.clone(), agent.beta_optimizer.exp_avg_sq.clone()]
+    counts = [o.step_count for o in opts] + [agent.beta_optimizer.step_count, agent._noise_counter]
+    return ts, counts
+
+
+def test_scan_timeout_skips_every_step_and_the_update_can_be_retried(monkeypatch):
+    """A scan timeout must cost the caller a retry, not the model (include/repo_hip.h, repo_clip_adam's
+    skip_if_nonzero): with the spin limit forced to 0 the update's gradients are NaN, every optimiser step of that
+    update (model, dual, actor, critic) skips itself on the device, the agent raises RepoHipError -- and parameters,
+    moments, log_beta, step counts and the noise offset are what they were.  The SAME update retried on the row-scan
+    engine (REPO_SCAN_CS=0) then equals, bit for bit, a twin agent that never faulted."""
+    from repo_amd import ops
+    from repo_amd._lib import RepoHipError, lib
+    from tests.test_update_gpu import dev_batch, make_agent
+
+    L, B, H, A = 6, 3, 4, 6
+    word = ops.scan_status(torch.device("cuda", 0))
+    word.zero_()
+    torch.manual_seed(3)
+    agent, _ = make_agent("repo", L, B, H, A)
+    torch.manual_seed(3)
+    twin, _ = make_agent("repo", L, B, H, A)
+    b0, b1 = dev_batch(L, B, A, 11)[0], dev_batch(L, B, A, 12)[0]
+    for ag in (agent, twin):   # one clean update: non-zero moments, step counts 1
+        ag.update(b0)
+        assert all(math.isfinite(v) for v in ag.last_scalars.values())
+    before, counts = _agent_state(agent)
+    try:
+        lib().repo_debug_scan_spin_limit(0)
+        agent.update(b1)
+        with pytest.raises(RepoHipError, match="optimiser steps were skipped.*rolled back"):
+            agent.last_scalars
+    finally:
+        lib().repo_debug_scan_spin_limit(-1)
+        torch.cuda.synchronize()
+    assert int(word.item()) == 0                       # the fault was reported once; the device word is clear again
+    after, counts_after = _agent_state(agent)
+    assert counts_after == counts, (counts, counts_after)
+    for i, (a, b) in enumerate(zip(before, after)):
+        assert torch.equal(a, b), i                    # nothing was written, NaN or otherwise
+    monkeypatch.setenv("REPO_SCAN_CS", "0")
+    for ag in (agent, twin):
+        ag.update(b1)
+    sa, st = agent.last_scalars, twin.last_scalars
+    assert sa == st and all(math.isfinite(v) for v in sa.values()), (sa, st)
+    for i, (a, b) in enumerate(zip(_agent_state(agent)[0], _agent_state(twin)[0])):
+        assert torch.equal(a, b), i
+    assert _agent_state(agent)[1] == _agent_state(twin)[1]
+
+
+def test_scan_timeout_with_a_later_update_in_flight_keeps_the_model_finite():
+    """Pipelined updates (train_agent's join=False): the fault of update k is raised while update k+1 is in flight;
+    update k's steps were skipped, update k+1 (clean) ran on the unchanged parameters; nothing is NaN afterwards."""
+    from repo_amd import ops
+    from repo_amd._lib import RepoHipError, lib
+    from tests.test_update_gpu import dev_batch, make_agent
+
+    L, B, H, A = 6, 3, 4, 6
+    ops.scan_status(torch.device("cuda", 0)).zero_()
+    agent, _ = make_agent("repo", L, B, H, A)
+    b0, b1 = dev_batch(L, B, A, 11)[0], dev_batch(L, B, A, 12)[0]
+    agent.update(b0, join=False)
+    try:
+        lib().repo_debug_scan_spin_limit(0)
+        agent.update(b1, join=False)            # faults; flushes update 0's log (clean)
+        torch.cuda.synchronize()
+    finally:
+        lib().repo_debug_scan_spin_limit(-1)
+    with pytest.raises(RepoHipError, match="later update was already in flight"):
+        agent.update(b0, join=False)            # enqueued clean; its log call flushes the faulted update's
+    agent.synchronize()
+    assert all(math.isfinite(v) for v in agent.last_scalars.values())
+    for o in (agent.model_optimizer, agent.actor_optimizer, agent.value_optimizer):
+        assert bool(torch.isfinite(o.flat).all()) and bool(torch.isfinite(o.exp_avg).all())
+    assert bool(torch.isfinite(agent.log_beta))
