@@ -665,9 +665,10 @@ def test_scan_timeout_reaches_the_host():
         assert int(word.item()) == 2, int(word.item())         # reverse scan only
         with pytest.raises(RepoHipError, match="reverse"):
             ops.check_scan_status(b0.device)
+        assert int(word.item()) == 0                           # reported once: the read clears the word
         bad = ops.rssm_observe_fwd(p, b0, s0, act, non, emb, None, None, 0.1, noise=(3, 0))
         torch.cuda.synchronize()
-        assert int(word.item()) == 3
+        assert int(word.item()) == 1                           # forward scan
         assert not bool(torch.isfinite(bad.featx).all())       # and nothing plausible is left behind
         # the agent: the word travels inside the update's one scalar copy
         word.zero_()
