@@ -26,6 +26,7 @@
 #include "bconv.h"
 #include "buconv.h"
 #include "bwgrad.h"
+#include "bdec4.h"
 
 
 namespace repo {
@@ -814,7 +815,9 @@ static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, cons
   const int nparts = dec4_nll_grid(nimg);
   NllArgs a{h3, w, bias, target, recon, dpre, mask4, (float*)ws, grad_scale, (int)nimg,
             (unsigned)(nimg * G::CS * G::PS * sizeof(float))};
-  hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
+  // the bf16x6 kernel (bdec4.h) unless repo_debug_bconv(0) asks for the fp32-MFMA twin
+  if (t_bconv_enabled) hipLaunchKernelGGL((bdec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
   REPO_CHECK_LAUNCH();
   if (loss_sum) {
     hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)ws, nparts,
