@@ -118,8 +118,15 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   constexpr int PLMAX_E = ODD ? cmin(NIMG_MAX * LENFULL_E, ((2 * (BN / G::WS + 2) + NIMG_MAX * (G::KS - 2)) * WBE + 3) & ~3)
                               : PLMAX;
   constexpr int PPLANE = (CK * PLMAX_E * 2 + 15) & ~15;      // bytes of one patch plane
+  // QROW (round 5): an odd-width plane whose padded pitch is a multiple of 4 (31 -> 32: the encoder's conv2) is staged by
+  // LDS quads instead of memory quads: a unit = four consecutive slots of one LDS row = four consecutive elements of the
+  // memory row at a DWORD-aligned (not 16-byte-aligned) address -- one 16-byte buffer load, one aligned 8-byte store per
+  // plane, exactly the even-pitch path (the element-wise path below costs twelve 2-byte stores per unit: enc2's forward
+  // was bound by them, 312 vs 309 us on the fp32 kernel).  A row's last unit spills one element into the pad slot.
+  constexpr bool QROW = ODD && (WBE % 4 == 0);
+  constexpr int PLV_E = PLMAX_E / 4;
   constexpr int W_NV = 3 * NBLK * 2 * BM;                    // 16-byte weight vectors per chunk
-  constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * PLV + NT - 1) / NT;
+  constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * (QROW ? PLV_E : PLV) + NT - 1) / NT;
   constexpr int EPI_FLOATS = (NT / 64) * 32 * 36 + (NT / 64) * TM * 32;
   constexpr int LDS_BYTES = cmax(3 * WPLANE + 3 * PPLANE + 64, 4 * EPI_FLOATS);
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -151,9 +158,27 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   // ---- staging roles
   unsigned poff[P_PER];
   int plds[P_PER];
-  int plde[ODD ? P_PER : 1][4];  // ODD: byte offset of each of the vector's four elements (or -1)
+  int plde[(ODD && !QROW) ? P_PER : 1][4];  // ODD: byte offset of each of the vector's four elements (or -1)
 #pragma unroll
   for (int j = 0; j < P_PER; ++j) {
+    if (QROW) {
+      const int v = tid + j * NT, c = v / PLV_E, qe = (v % PLV_E) * 4;   // LDS slot offset inside the channel's image
+      int i, rel;
+      if (qe < lenA_e) {
+        i = ia;
+        rel = qe;
+      } else {
+        i = ia + 1 + (qe - lenA_e) / LENFULL_E;
+        rel = (qe - lenA_e) % LENFULL_E;
+      }
+      const int rows_i = (i == ia) ? 2 * (la_ - fa) + G::KS : (i == ib ? 2 * lb + G::KS : ROWS_FULL);
+      const int r = rel / WBE, col = rel % WBE;
+      const bool act = c < CK && i <= ib && r < rows_i;
+      const int f = (i == ia) ? fa : 0;
+      poff[j] = act ? 4u * (unsigned)((i * G::CB + c) * G::PB + (2 * f + r) * G::WB + col) : kOobOffset;
+      plds[j] = act ? 2 * (c * PLMAX_E + span_start_e(i) + rel) : -1;
+      continue;
+    }
     const int v = tid + j * NT, c = v / PLV, q = (v % PLV) * 4;
     const bool act = c < CK && q < PL;
     int i, rel;
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
     const int f = (i == ia) ? fa : 0;
     poff[j] = act ? 4u * (unsigned)((i * G::CB + c) * G::PB + 2 * f * G::WB + rel) : kOobOffset;
     plds[j] = act ? 2 * (c * PLMAX_E + q) : -1;   // bytes inside a plane
-    if (ODD) {
+    if (ODD && !QROW) {
       // rows of the span in memory (its true length: the 16-byte vectors run up to 3 elements past it)
       const int rows_i = (i == ia) ? 2 * (la_ - fa) + G::KS : (i == ib ? 2 * lb + G::KS : ROWS_FULL);
 #pragma unroll
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
         unsigned a1, a2, a3, b1, b2, b3;
         bg_split3(rpv[j][0], rpv[j][1], a1, a2, a3);
         bg_split3(rpv[j][2], rpv[j][3], b1, b2, b3);
-        if (!ODD) {
+        if (!ODD || QROW) {
           *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{a1, b1};
           *reinterpret_cast<bg_u32x2*>(Pl + PPLANE + plds[j]) = bg_u32x2{a2, b2};
           *reinterpret_cast<bg_u32x2*>(Pl + 2 * PPLANE + plds[j]) = bg_u32x2{a3, b3};

@@ -441,8 +441,12 @@ template <class G> struct BDownFor { using type = NoBTile; };
 template <> struct BDownFor<GDec3> { using type = BTile<64, 256, 2, 1, 4>; };
 template <> struct BDownFor<GEnc3> { using type = BTile<64, 256, 4, 1, 4>; };
 template <> struct BDownFor<GEnc4> { using type = BTile<64, 128, 4, 1, 2>; };
-// (enc2 forward -- 31 x 31 planes, k4 -- measured equal on both kernels, 312 vs 309 us: with 4 taps per element the
-// element-wise staging of the padded pitch eats the gain; it stays on the fp32 kernel and saves the pack launch)
+// enc2 forward (31 x 31 planes, k4): with the element-wise staging of its padded pitch it measured equal on both kernels
+// (312 vs 309 us, round 4); staged by LDS quads (bconv.h, QROW) it is on the bf16 pipe
+#ifndef REPO_BT_ENC2
+#define REPO_BT_ENC2 BTile<64, 256, 4, 1, 4>
+#endif
+template <> struct BDownFor<GEnc2> { using type = REPO_BT_ENC2; };
 template <> struct BDownFor<GDec2> { using type = BTile<64, 128, 2, 1, 4>; };   // 13 x 13 planes, k5 (32 slots for 25 taps)
 template <class G> constexpr bool kBDown = !std::is_same<typename BDownFor<G>::type, NoBTile>::value;
 
