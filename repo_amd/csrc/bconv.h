@@ -31,10 +31,9 @@ struct BGeo {
   static constexpr int KKE = (TAPS + 7) & ~7;       // padded to whole 8-k fragments
   static constexpr int BPG = KKE / 8;               // MFMA k-blocks (16 k = 8 per lane half) per channel PAIR
   // dword-aligned tap pairs need an even row pitch: an odd-width plane (31 x 31, 13 x 13) is stored in LDS with its
-  // rows padded by one element (WBE) -- its staging then places every element on its own (three 2-byte stores
-  // instead of one 8-byte store per plane for four elements)
+  // rows padded to a multiple of FOUR elements (WBE: 32, 16) and staged by LDS quads (QROW in the kernel)
   static constexpr bool ODD = (G::WB & 1) != 0;
-  static constexpr int WBE = G::WB + (G::WB & 1);
+  static constexpr int WBE = ODD ? ((G::WB + 3) & ~3) : G::WB;
   static constexpr bool OK = G::CB % 2 == 0;
 };
 
@@ -118,12 +117,13 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   constexpr int PLMAX_E = ODD ? cmin(NIMG_MAX * LENFULL_E, ((2 * (BN / G::WS + 2) + NIMG_MAX * (G::KS - 2)) * WBE + 3) & ~3)
                               : PLMAX;
   constexpr int PPLANE = (CK * PLMAX_E * 2 + 15) & ~15;      // bytes of one patch plane
-  // QROW (round 5): an odd-width plane whose padded pitch is a multiple of 4 (31 -> 32: the encoder's conv2) is staged by
-  // LDS quads instead of memory quads: a unit = four consecutive slots of one LDS row = four consecutive elements of the
+  // QROW (round 5): an odd-width plane (pitch padded to a multiple of 4: 31 -> 32, the encoder's conv2; 13 -> 16, the
+  // decoder's conv2 data gradient: 221 -> 197 us) is staged by LDS quads instead of memory quads: a unit = four consecutive slots of one LDS row = four consecutive elements of the
   // memory row at a DWORD-aligned (not 16-byte-aligned) address -- one 16-byte buffer load, one aligned 8-byte store per
-  // plane, exactly the even-pitch path (the element-wise path below costs twelve 2-byte stores per unit: enc2's forward
-  // was bound by them, 312 vs 309 us on the fp32 kernel).  A row's last unit spills one element into the pad slot.
-  constexpr bool QROW = ODD && (WBE % 4 == 0);
+  // plane, exactly the even-pitch path (round 4 placed every element on its own, twelve 2-byte stores per unit: enc2's
+  // forward was bound by them, 312 vs 309 us on the fp32 kernel).  A row's last unit spills into the pad slots.
+  constexpr bool QROW = ODD;
+  static_assert(!ODD || WBE % 4 == 0, "padded pitch: whole quads per row");
   constexpr int PLV_E = PLMAX_E / 4;
   constexpr int W_NV = 3 * NBLK * 2 * BM;                    // 16-byte weight vectors per chunk
   constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * (QROW ? PLV_E : PLV) + NT - 1) / NT;
@@ -158,7 +158,6 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   // ---- staging roles
   unsigned poff[P_PER];
   int plds[P_PER];
-  int plde[(ODD && !QROW) ? P_PER : 1][4];  // ODD: byte offset of each of the vector's four elements (or -1)
 #pragma unroll
   for (int j = 0; j < P_PER; ++j) {
     if (QROW) {
@@ -192,15 +191,6 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
     const int f = (i == ia) ? fa : 0;
     poff[j] = act ? 4u * (unsigned)((i * G::CB + c) * G::PB + 2 * f * G::WB + rel) : kOobOffset;
     plds[j] = act ? 2 * (c * PLMAX_E + q) : -1;   // bytes inside a plane
-    if (ODD && !QROW) {
-      // rows of the span in memory (its true length: the 16-byte vectors run up to 3 elements past it)
-      const int rows_i = (i == ia) ? 2 * (la_ - fa) + G::KS : (i == ib ? 2 * lb + G::KS : ROWS_FULL);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = (rel + e) / G::WB, col = (rel + e) % G::WB;
-        plde[j][e] = (act && r < rows_i) ? 2 * (c * PLMAX_E + span_start_e(i) + r * WBE + col) : -1;
-      }
-    }
   }
   constexpr unsigned P_STEP = 4u * CK * G::PB;
   const unsigned wbase = (unsigned)(blockIdx.y * NSL) * (unsigned)P::CHUNK_BYTES;
@@ -247,21 +237,9 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
         unsigned a1, a2, a3, b1, b2, b3;
         bg_split3(rpv[j][0], rpv[j][1], a1, a2, a3);
         bg_split3(rpv[j][2], rpv[j][3], b1, b2, b3);
-        if (!ODD || QROW) {
-          *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{a1, b1};
-          *reinterpret_cast<bg_u32x2*>(Pl + PPLANE + plds[j]) = bg_u32x2{a2, b2};
-          *reinterpret_cast<bg_u32x2*>(Pl + 2 * PPLANE + plds[j]) = bg_u32x2{a3, b3};
-        } else {
-          const unsigned pk[3][2] = {{a1, b1}, {a2, b2}, {a3, b3}};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (plde[j][e] >= 0) {
-#pragma unroll
-              for (int q3 = 0; q3 < 3; ++q3)
-                *reinterpret_cast<unsigned short*>(Pl + q3 * PPLANE + plde[j][e]) =
-                    (unsigned short)(pk[q3][e >> 1] >> (16 * (e & 1)));
-            }
-        }
+        *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{a1, b1};
+        *reinterpret_cast<bg_u32x2*>(Pl + PPLANE + plds[j]) = bg_u32x2{a2, b2};
+        *reinterpret_cast<bg_u32x2*>(Pl + 2 * PPLANE + plds[j]) = bg_u32x2{a3, b3};
       }
   };
   // byte offset (inside a plane, from the half's base) of the dword that holds slots q, q + 1 of channel pair g
