@@ -23,10 +23,15 @@ starts its own ranks (one child process per GPU via torch.distributed.run, befor
 GPU); when an external launcher already set RANK/WORLD_SIZE it runs as that rank.  Rank 0 prints ONE JSON
 line; `n_gpus` is the number of ranks the process group saw.
 
-`roofline` is for the dominant kernel (the largest single launch: the decoder's 64->32 transposed
-convolution, `uconv_scatter_kernel<GDec3>`): algorithmic FLOPs of that launch / its average duration measured
-with HIP events recorded on its launch stream INSIDE the timed updates.  `traffic` comes from the
-rocprofv3 --pmc summary committed under profiles/ (named in `traffic_source`), never from this run.
+`roofline` is for the dominant kernel = the FIRST ROW BY TOTAL TIME of the committed rocprofv3 --kernel-trace --stats
+summary of this same command (profiles/dominant_kernel_rocprof.json, written from profiles/rNN_bench_kernel_stats_pipelined.csv
+by tools/layers_in_update.py): algorithmic FLOPs of one launch / its average duration measured live with HIP events on its
+launch stream INSIDE the timed updates; `peak` is the peak of the pipe the kernel EXECUTES on (157.3 TFLOP/s for the
+fp32-MFMA kernels; 2516.6 / 6 = 419.4 "fp32-equivalent" TFLOP/s for the bf16x6 kernels, which form every fp32 product
+from six bf16 products), `frac_of_fp32_mfma_peak` the same launch against the fp32 peak, `kernel_ms_rocprof` /
+`frac_at_rocprof_duration` the trace's own average for that row, `kernel_time_sum_ms` the trace's kernel time per update.
+`roofline.largest_launch` is the same object for the update's largest single product (decoder conv3 forward, 61 GFLOP).
+`traffic` comes from the rocprofv3 --pmc summaries committed under profiles/ (named in `traffic_source`), never from this run.
 `cpu_baseline` is the CPU oracle (PyTorch fp32 restatement of the reference) timed on this box's host
 cores on the full 50-sequence batch, 2 warm-up + 3 timed updates (rank 0, N=1 only).
 """
@@ -159,41 +164,107 @@ def synthetic_ring(buffer_cls, seed, A, device, image=64, num_tasks=0):
     return ring
 
 
-class LaunchTimer:
-    """HIP-event pairs around every launch of one conv layer, recorded on the launch stream while the
-    timed updates run (repo_amd.ops.conv_up is wrapped for the duration of the `with` block)."""
+# (CB, CS, HB, KS) of the conv layers (repo_amd.ops.CONV_GEO; repeated here so that the table below needs no import)
+_CONV_GEO = {(3, 32, 64, 4): 0, (32, 64, 31, 4): 1, (64, 128, 14, 4): 2, (128, 256, 6, 4): 3, (64, 128, 13, 5): 4,
+             (32, 64, 30, 6): 5, (3, 32, 64, 6): 6}
+_CONV_NAMES = ["encoder conv1", "encoder conv2", "encoder conv3", "encoder conv4", "decoder conv2", "decoder conv3",
+               "decoder conv4"]
+_SCAN_MAC, _IMG_MAC, _MLP4_MAC = 556e3 - 204.8e3, 467.6e3, 230 * 200 + 3 * 200 * 200   # per row and step
 
-    def __init__(self, layer):
-        self.layer, self.pairs = layer, []
+
+def kernel_spec(name, nimg, horizon_rows):
+    """What bench.py needs to time one kernel of the update live and to price it: the repo_amd.ops entry point whose call
+    launches it (+ the conv layer id to filter on), algorithmic FLOPs of one launch, the matrix pipe it executes on.
+    `name` is a rocprofv3 kernel name (any prefix / template spelling)."""
+    import re
+
+    m = re.search(r"Geo<(\d+), ?(\d+), ?(\d+), ?(\d+)>", name)
+    geo = tuple(int(x) for x in m.groups()) if m else None
+    layer = _CONV_GEO.get(geo)
+    conv = {"buconv_scatter_kernel": ("conv_up", "bf16x6"), "uconv_scatter_kernel": ("conv_up", "fp32"),
+            "bconv_down_kernel": ("conv_down", "bf16x6"), "dconv_down_kernel": ("conv_down", "fp32"),
+            "bconv_wgrad_kernel": ("conv_wgrad", "bf16x6"), "dconv_wgrad_kernel": ("conv_wgrad", "fp32")}
+    for k, (op, pipe) in conv.items():
+        if k in name and layer is not None:
+            cb, cs, hb, ks = geo
+            hs = (hb - ks) // 2 + 1
+            enc = layer < 4
+            role = {"conv_up": "data gradient" if enc else "forward", "conv_down": "forward" if enc else "data gradient",
+                    "conv_wgrad": "weight gradient"}[op]
+            note = " (+ its slab-reduce launch inside the bracket)" if op == "conv_wgrad" else ""
+            return {"op": op, "layer": layer, "pipe": pipe, "flop": 2.0 * nimg * cs * hs * hs * cb * ks * ks,
+                    "label": f"{k}<Geo<{cb},{cs},{hb},{ks}>> ({_CONV_NAMES[layer]} {role}){note}"}
+    other = {"bdec4_nll_kernel": ("decoder_out_nll", "bf16x6", 2.0 * nimg * 32 * 900 * 3 * 36, "decoder conv4 forward + pixel NLL"),
+             "dconv_dec4_nll_kernel": ("decoder_out_nll", "fp32", 2.0 * nimg * 32 * 900 * 3 * 36, "decoder conv4 forward + pixel NLL"),
+             "imagine32_fwd_kernel": ("rssm_imagine_fwd", "bf16x6", 2.0 * horizon_rows * _IMG_MAC, "imagination rollout forward"),
+             "imagine32_bwd_kernel": ("rssm_imagine_bwd", "bf16x6", 2.0 * horizon_rows * (_IMG_MAC - _MLP4_MAC), "imagination rollout reverse"),
+             "observe_cs_fwd_kernel": ("rssm_observe_fwd", "fp32", 2.0 * nimg * _SCAN_MAC, "observe scan forward (latency chain; incl. its hoisted GEMM launches)"),
+             "observe_cs_bwd_kernel": ("rssm_observe_bwd", "fp32", 4.0 * nimg * _SCAN_MAC, "observe scan reverse (latency chain; incl. its deferred GEMM launches)")}
+    for k, (op, pipe, flop, what) in other.items():
+        if k in name:
+            return {"op": op, "layer": None, "pipe": pipe, "flop": flop, "label": f"{k} ({what})"}
+    return None
+
+
+PIPE_PEAK = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x6": BF16_MFMA_PEAK_TFLOPS / 6.0}
+PIPE_NOTE = {"fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+             "bf16x6": "bf16 MFMA, every fp32 product as six exact bf16 products: peak = dense bf16 peak / 6, in fp32-equivalent FLOPs"}
+
+
+class LaunchTimer:
+    """HIP-event pairs around every call of one repo_amd.ops entry point (optionally one conv layer of it), recorded on
+    the launch stream while the timed updates run; keeps the arguments of the first call for the isolated replay."""
+
+    def __init__(self, spec):
+        self.spec, self.pairs, self.first = spec, [], None
 
     def __enter__(self):
         from repo_amd import functional as Fn
         from repo_amd import ops
 
-        self._ops, self._orig = ops, ops.conv_up
+        self._ops, self._orig = ops, getattr(ops, self.spec["op"])
         timer = self
 
-        def timed_conv_up(layer, *a, **k):
-            if layer != timer.layer:
-                return timer._orig(layer, *a, **k)
+        def timed(*a, **k):
+            if timer.spec["layer"] is not None and a[0] != timer.spec["layer"]:
+                return timer._orig(*a, **k)
             s = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
-            out = timer._orig(layer, *a, **k)
+            out = timer._orig(*a, **k)
             e1.record(s)
             timer.pairs.append((e0, e1))
+            if timer.first is None:
+                timer.first = (a, k)
             return out
 
-        ops.conv_up = timed_conv_up
+        setattr(ops, self.spec["op"], timed)
         assert Fn.ops is ops
         return self
 
     def __exit__(self, *exc):
-        self._ops.conv_up = self._orig
+        setattr(self._ops, self.spec["op"], self._orig)
         return False
 
     def mean_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+
+    def isolated_ms(self, iters=20):
+        """The same call (the first timed one's arguments) alone on an idle GPU."""
+        if self.first is None:
+            return None
+        a, k = self.first
+        torch.cuda.synchronize()
+        for _ in range(3):
+            self._orig(*a, **k)
+        stream = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            self._orig(*a, **k)
+        e1.record(stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
 
 
 class AllReduceTimer:
@@ -243,74 +314,86 @@ class AllReduceTimer:
                 "note": "rank 0; span from issue to the consumer stream's join, summed per update"}
 
 
-def dominant_kernel_isolated(nimg, iters=20):
-    """The same launch alone on an idle GPU (no other stream running): the kernel's own speed."""
-    from repo_amd import ops
-
-    dev = torch.device("cuda")
-    small = torch.randn(nimg, 64, 13, 13, device=dev).relu_()
-    w = torch.randn(64, 32, 6, 6, device=dev) * 0.05
-    bias = torch.randn(32, device=dev)
-    out = torch.empty(nimg, 32, 30, 30, device=dev)
-    for _ in range(3):
-        ops.conv_up(ops.DEC3, small, w, bias, epi=ops.EPI_RELU, out=out)
-    stream = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        ops.conv_up(ops.DEC3, small, w, bias, epi=ops.EPI_RELU, out=out)
-    e1.record(stream)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
 def under_profiler():
-    """rocprofv3 preloads its tool library into the profiled process: the isolated re-runs of the dominant
-    kernel are skipped then, so that its row in the kernel trace holds the launches INSIDE the updates only."""
+    """rocprofv3 preloads its tool library into the profiled process: the isolated re-runs of the timed kernels are
+    skipped then, so that their rows in the kernel trace hold the launches INSIDE the updates only."""
     pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("HSA_TOOLS_LIB", "")
     return "rocprof" in pre or "ROCPROFILER_REGISTER_FORCE_LOAD" in os.environ or os.environ.get("REPO_BENCH_NO_ISOLATED") == "1"
 
 
 ROCPROF_SUMMARY = os.path.join(ROOT, "profiles", "dominant_kernel_rocprof.json")
+LARGEST_LAUNCH = "buconv_scatter_kernel<Geo<32, 64, 30, 6>>"   # decoder conv3 forward: the update's largest single product
 
 
-def roofline(timer, nimg):
-    """Decoder conv3 (64x13x13 -> 32x30x30, k6 s2): the largest single launch of the update (61.05 GFLOP at
-    nimg=2450: every (input pixel, cin, cout, tap) MAC once).  `frac` uses the HIP-event
-    duration of the launches inside the timed updates; `kernel_ms_rocprof` is the same kernel's average in the
-    committed rocprofv3 --kernel-trace of the same command (in-update launches only)."""
-    flop = 2.0 * nimg * 169 * 64 * 32 * 36
-    ms = timer.mean_ms()
-    iso = None if under_profiler() else dominant_kernel_isolated(nimg)
-    achieved = flop / (ms * 1e-3) / 1e12
-    out = {
-        "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "buconv_scatter_kernel<Geo<32,64,30,6>> (decoder conv3 forward)",
-        # the kernel forms every fp32 product as six exact bf16 partial products on the bf16 matrix pipe (csrc/bgemm.h):
-        # `achieved` / `peak` / `frac` stay ALGORITHMIC fp32 FLOPs against the fp32-MFMA peak (the pipe the reference's
-        # precision would otherwise bind it to; frac may exceed 1); the same launch as EXECUTED bf16 FLOPs (6 x) against the
-        # dense bf16 peak:
-        "executed_bf16": {"achieved": round(6 * achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)},
-        "ms_per_launch": round(ms, 4), "launches_timed": len(timer.pairs), "flop_per_launch": flop,
-        "timing": "HIP events on the launch stream inside the timed updates (other streams of the update run "
-                  "beside it); frac = flop_per_launch / ms_per_launch / peak",
-    }
-    if iso is not None:
-        out["isolated_ms_per_launch"] = round(iso, 4)
-        out["isolated_frac"] = round(flop / (iso * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+def trace_summary():
+    """profiles/dominant_kernel_rocprof.json: the committed kernel trace's top row by total time, the largest launch's
+    row and the kernel time per update (tools/layers_in_update.py --json)."""
     if os.path.exists(ROCPROF_SUMMARY):
-        rp = json.load(open(ROCPROF_SUMMARY))
-        if rp.get("nimg") == nimg:
-            out["kernel_ms_rocprof"] = rp.get("avg_ms_in_update")
-            out["kernel_ms_rocprof_source"] = rp.get("source")
+        return json.load(open(ROCPROF_SUMMARY))
+    return {}
+
+
+def roofline_specs(nimg, horizon_rows):
+    """(top-by-time spec, largest-launch spec): which kernels this run times live."""
+    tr = trace_summary()
+    top_name = (tr.get("top_by_time") or {}).get("name") or LARGEST_LAUNCH
+    top = kernel_spec(top_name, nimg, horizon_rows) or kernel_spec(LARGEST_LAUNCH, nimg, horizon_rows)
+    big = kernel_spec(LARGEST_LAUNCH, nimg, horizon_rows)
+    return top, big
+
+
+def _roofline_obj(timer, row, nimg):
+    spec = timer.spec
+    flop, pipe = spec["flop"], spec["pipe"]
+    peak = PIPE_PEAK[pipe]
+    ms = timer.mean_ms()
+    achieved = flop / (ms * 1e-3) / 1e12 if ms else 0.0
+    out = {
+        "bound": "mfma", "kernel": spec["label"], "pipe": PIPE_NOTE[pipe],
+        "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+        "traffic": None, "ms_per_launch": round(ms, 4), "launches_timed": len(timer.pairs), "flop_per_launch": flop,
+        "timing": "HIP events on the launch stream inside the timed updates (other streams of the update run beside "
+                  "it); achieved = flop_per_launch / ms_per_launch (ALGORITHMIC fp32 FLOPs), frac = achieved / peak",
+    }
+    if not under_profiler():
+        iso = timer.isolated_ms()
+        if iso:
+            out["isolated_ms_per_launch"] = round(iso, 4)
+            out["isolated_frac"] = round(flop / (iso * 1e-3) / 1e12 / peak, 4)
+    if row and row.get("nimg") == nimg:
+        out["kernel_ms_rocprof"] = row.get("avg_ms_in_update")
+        if row.get("avg_ms_in_update"):
+            out["frac_at_rocprof_duration"] = round(flop / (row["avg_ms_in_update"] * 1e-3) / 1e12 / peak, 4)
+        out["share_of_kernel_time"] = row.get("share_of_kernel_time")
     if os.path.exists(PMC_SUMMARY):
-        pmc = json.load(open(PMC_SUMMARY))
-        if pmc.get("nimg") == nimg:
-            out["traffic"] = pmc.get("traffic_bytes_per_launch")
-            out["traffic_source"] = "profiles/dominant_kernel_pmc.json <- " + str(pmc.get("source"))
-            out["mfma_pipe_busy_pmc"] = pmc.get("mfma_pipe_busy")
+        pmc = json.load(open(PMC_SUMMARY)).get("kernels", {})
+        key = next((k for k in pmc if k.split("<")[0] in spec["label"] and _geo_of(k) == _geo_of(spec["label"])), None)
+        if key and pmc[key].get("nimg") == nimg:
+            out["traffic"] = pmc[key].get("traffic_bytes_per_launch")
+            out["traffic_source"] = "profiles/dominant_kernel_pmc.json <- " + str(pmc[key].get("source"))
+            out["mfma_pipe_busy_pmc"] = pmc[key].get("mfma_pipe_busy")
+    return out
+
+
+def _geo_of(name):
+    import re
+
+    m = re.search(r"Geo<(\d+), ?(\d+), ?(\d+), ?(\d+)>", name)
+    return tuple(int(x) for x in m.groups()) if m else None
+
+
+def roofline(top_timer, big_timer, nimg):
+    """`roofline` of the JSON line: the trace's top kernel by total time, measured live; `largest_launch` nested."""
+    tr = trace_summary()
+    out = _roofline_obj(top_timer, tr.get("top_by_time"), nimg)
+    out["selected_by"] = ("first row by total time of " + str(tr.get("csv")) if tr.get("top_by_time")
+                          else "no committed trace summary: the largest launch")
+    if tr.get("nimg") == nimg or (tr.get("top_by_time") or {}).get("nimg") == nimg:
+        out["kernel_time_sum_ms"] = tr.get("kernel_time_sum_ms_per_update")
+        out["kernel_time_source"] = tr.get("source")
+    if big_timer is not top_timer:
+        out["largest_launch"] = _roofline_obj(big_timer, tr.get("largest_launch"), nimg)
     return out
 
 
@@ -521,8 +604,15 @@ def main():
     from repo_amd import ops
 
     ar = AllReduceTimer(dp) if dp is not None else None
-    timer = LaunchTimer(ops.DEC3)
-    with timer:
+    top_spec, big_spec = roofline_specs((L - 1) * Bl, (H - 1) * (L - 1) * Bl)
+    timer = LaunchTimer(top_spec)
+    big_timer = timer if big_spec["label"] == top_spec["label"] else LaunchTimer(big_spec)
+    import contextlib
+
+    with contextlib.ExitStack() as stack:
+        stack.enter_context(timer)
+        if big_timer is not timer:
+            stack.enter_context(big_timer)
         dt = timed(main_loop, args.steps)
     if ar is not None:
         ar.stop()
@@ -605,7 +695,7 @@ def main():
             "pinned_path_ms": round(dt_pin / args.steps * 1e3, 3) if dt_pin is not None else None,
             "last_scalars": {k: round(float(v), 6) for k, v in agent.last_scalars.items()},
         }
-        line["roofline"] = roofline(timer, (L - 1) * Bl)
+        line["roofline"] = roofline(timer, big_timer, (L - 1) * Bl)
         if strong is not None:
             line["strong"] = strong
         if ar is not None:

@@ -1,34 +1,34 @@
 #!/bin/bash
-# Everything under profiles/r04_* from the CURRENT kernels, in one call on the GPU box:
+# Everything under profiles/r05_* from the CURRENT kernels, in one call on the GPU box:
 #   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh'      then      python tools/collect_profiles.py --write-json
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-python3 tools/layers_isolated.py > $O/r04_layers_isolated.txt 2>&1
-bash tools/prof_bench.sh r04_bench_pipelined > /dev/null 2>&1
-bash tools/prof_bench.sh r04_bench_join --join > /dev/null 2>&1
-python3 tools/layers_in_update.py $O/r04_bench_pipelined_kernel_stats.csv --json $O/dominant_kernel_rocprof.json > $O/r04_layers_in_update.txt 2>&1
-python3 tools/launch_count.py $O/r04_bench_pipelined_kernel_stats.csv > $O/r04_launch_count.txt 2>&1
+python3 tools/layers_isolated.py > $O/r05_layers_isolated.txt 2>&1
+bash tools/prof_bench.sh r05_bench_pipelined > /dev/null 2>&1
+bash tools/prof_bench.sh r05_bench_join --join > /dev/null 2>&1
+python3 tools/layers_in_update.py $O/r05_bench_pipelined_kernel_stats.csv --json $O/dominant_kernel_rocprof.json --csv-name profiles/r05_bench_kernel_stats_pipelined.csv > $O/r05_layers_in_update.txt 2>&1
+python3 tools/launch_count.py $O/r05_bench_pipelined_kernel_stats.csv > $O/r05_launch_count.txt 2>&1
 bash tools/pmc.sh dec3 "buconv_scatter|uconv_scatter|bconv_down|dconv_down|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv dec3" > /dev/null 2>&1
 bash tools/pmc.sh convs "buconv_scatter|uconv_scatter|bconv_down|dconv_down|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv enc2" "conv enc3" "conv enc4" "conv dec2" > /dev/null 2>&1
 bash tools/pmc.sh scan_rollout "observe_|imagine" tools/run_scan_rollout.py > /dev/null 2>&1
 bash tools/pmc.sh c3 "dconv_dec4|Geo<3, 32|Geo<3,32" tools/run_micro_case.py "conv enc1" "conv dec4" "dec4 forward" > /dev/null 2>&1
 bash tools/pmc.sh mlp "mlp_(fwd|bwd)_kernel|wgrad_direct" tools/run_micro_case.py "mlp_fwd value" "mlp_bwd value head" "mlp_bwd actor" > /dev/null 2>&1
-python3 tools/lane_time.py > $O/r04_lane_time.txt 2>&1
-python3 tools/phase_time.py > $O/r04_phase_time.txt 2>&1
-(python3 bench.py --config c4 | grep '^{'; python3 bench.py --config c5 | grep '^{') > $O/r04_bench_c4_c5.json 2>/dev/null
-(for b in 7 6 13 25; do python3 bench.py --no-cpu-baseline --batch $b --steps 50 | grep '^{'; done) > $O/r04_bench_shards.json 2>/dev/null
-python3 tools/scan_cs_time.py > $O/r04_scan_cs.txt 2>&1
-ISO_IMAGE=128 python3 tools/layers_isolated.py @128 dec3 > $O/r04_layers_isolated_128.txt 2>&1
-bash tools/prof_bench.sh r04_c4x128 --config c4x128 > /dev/null 2>&1
-python3 tools/layers_in_update.py $O/r04_c4x128_kernel_stats.csv --nimg 1568 > $O/r04_c4x128_layers_in_update.txt 2>&1
-python3 bench.py --config c4x128 2>/dev/null | grep '^{' > $O/r04_bench_c4x128.json
-python3 bench.py --config tia 2>/dev/null | grep '^{' > $O/r04_bench_tia.json
-python3 bench.py --config mt 2>/dev/null | grep '^{' > $O/r04_bench_mt.json
-tools/probe/bin/bgemm_probe > $O/r04_bgemm_probe.txt 2>&1
-python3 tools/rowtile32_ab.py > $O/r04_rollout_engines.txt 2>&1
-python3 tools/layers_isolated.py gemm > $O/r04_gemm_isolated.txt 2>&1
+python3 tools/lane_time.py > $O/r05_lane_time.txt 2>&1
+python3 tools/phase_time.py > $O/r05_phase_time.txt 2>&1
+(python3 bench.py --config c4 | grep '^{'; python3 bench.py --config c5 | grep '^{') > $O/r05_bench_c4_c5.json 2>/dev/null
+(for b in 7 6 13 25; do python3 bench.py --no-cpu-baseline --batch $b --steps 50 | grep '^{'; done) > $O/r05_bench_shards.json 2>/dev/null
+python3 tools/scan_cs_time.py > $O/r05_scan_cs.txt 2>&1
+ISO_IMAGE=128 python3 tools/layers_isolated.py @128 dec3 > $O/r05_layers_isolated_128.txt 2>&1
+bash tools/prof_bench.sh r05_c4x128 --config c4x128 > /dev/null 2>&1
+python3 tools/layers_in_update.py $O/r05_c4x128_kernel_stats.csv --nimg 1568 > $O/r05_c4x128_layers_in_update.txt 2>&1
+python3 bench.py --config c4x128 2>/dev/null | grep '^{' > $O/r05_bench_c4x128.json
+python3 bench.py --config tia 2>/dev/null | grep '^{' > $O/r05_bench_tia.json
+python3 bench.py --config mt 2>/dev/null | grep '^{' > $O/r05_bench_mt.json
+tools/probe/bin/bgemm_probe > $O/r05_bgemm_probe.txt 2>&1
+python3 tools/rowtile32_ab.py > $O/r05_rollout_engines.txt 2>&1
+python3 tools/layers_isolated.py gemm > $O/r05_gemm_isolated.txt 2>&1
 python3 bench.py > $O/bench_full.log 2>&1
-grep '^{' $O/bench_full.log > $O/r04_bench_final.json
-tail -c 700 $O/r04_bench_final.json
+grep '^{' $O/bench_full.log > $O/r05_bench_final.json
+tail -c 700 $O/r05_bench_final.json
