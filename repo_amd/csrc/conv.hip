@@ -438,16 +438,28 @@ template <> struct DLatTile<GEnc4> { using type = DTile<32, 128, 8, 1, 4>; };
 // big-row pitch; NoBTile = the layer stays on the fp32-MFMA kernel (3-channel layers: bandwidth / epilogue bound).  Test aid repo_debug_bconv(0) keeps every layer on the fp32 kernel.
 struct NoBTile {};
 template <class G> struct BDownFor { using type = NoBTile; };
-template <> struct BDownFor<GDec3> { using type = BTile<64, 256, 2, 1, 4>; };
-template <> struct BDownFor<GEnc3> { using type = BTile<64, 256, 4, 1, 4>; };
-template <> struct BDownFor<GEnc4> { using type = BTile<64, 128, 4, 1, 2>; };
+#ifndef REPO_BT_DEC3
+#define REPO_BT_DEC3 BTile<64, 256, 2, 1, 4>
+#endif
+template <> struct BDownFor<GDec3> { using type = REPO_BT_DEC3; };
+#ifndef REPO_BT_ENC3
+#define REPO_BT_ENC3 BTile<128, 128, 4, 2, 2>   // one M tile: the patch is staged (and split) once, 169 -> 146 us
+#endif
+#ifndef REPO_BT_ENC4
+#define REPO_BT_ENC4 BTile<128, 64, 4, 2, 2>    // 112 -> 101 us
+#endif
+template <> struct BDownFor<GEnc3> { using type = REPO_BT_ENC3; };
+template <> struct BDownFor<GEnc4> { using type = REPO_BT_ENC4; };
 // enc2 forward (31 x 31 planes, k4): with the element-wise staging of its padded pitch it measured equal on both kernels
 // (312 vs 309 us, round 4); staged by LDS quads (bconv.h, QROW) it is on the bf16 pipe
 #ifndef REPO_BT_ENC2
 #define REPO_BT_ENC2 BTile<64, 256, 4, 1, 4>
 #endif
 template <> struct BDownFor<GEnc2> { using type = REPO_BT_ENC2; };
-template <> struct BDownFor<GDec2> { using type = BTile<64, 128, 2, 1, 4>; };   // 13 x 13 planes, k5 (32 slots for 25 taps)
+#ifndef REPO_BT_DEC2
+#define REPO_BT_DEC2 BTile<64, 128, 2, 1, 4>
+#endif
+template <> struct BDownFor<GDec2> { using type = REPO_BT_DEC2; };   // 13 x 13 planes, k5 (32 slots for 25 taps)
 template <class G> constexpr bool kBDown = !std::is_same<typename BDownFor<G>::type, NoBTile>::value;
 
 template <class G>
