@@ -34,7 +34,9 @@ struct BGeo {
   // rows padded to a multiple of FOUR elements (WBE: 32, 16) and staged by LDS quads (QROW in the kernel)
   static constexpr bool ODD = (G::WB & 1) != 0;
   static constexpr int WBE = ODD ? ((G::WB + 3) & ~3) : G::WB;
-  static constexpr bool OK = G::CB % 2 == 0;
+  // an odd channel count (the encoder's 3-channel first layer) is padded to a channel PAIR: the phantom channel's patch
+  // is staged as zeros (out-of-range loads) against zero weights in the pack
+  static constexpr int CBP = G::CB + (G::CB & 1);
 };
 
 // BM x BN tile, CK channels per chunk (even), WM x WN waves
@@ -49,25 +51,40 @@ struct BTile {
 template <class G, class T>
 struct BPack {
   static constexpr int NBLK = (T::CK / 2) * BGeo<G>::BPG;            // k-blocks per chunk
-  static constexpr int NSL = G::CB / T::CK;                           // chunks
+  static constexpr int NSL = BGeo<G>::CBP / T::CK;                    // chunks
   static constexpr int MT = (G::CS + T::BM - 1) / T::BM;              // M tiles
   static constexpr int WPLANE = NBLK * 2 * T::BM * 16;                // bytes of one plane of one chunk
   static constexpr int CHUNK_BYTES = 3 * WPLANE;
   static constexpr size_t BYTES = (size_t)MT * NSL * CHUNK_BYTES;
-  static_assert(G::CB % T::CK == 0, "channel chunk must divide CB");
+  // uint8 frames (below): the folded bias vector sits behind the weight planes
+  static constexpr size_t BYTES_U8 = BYTES + (size_t)((G::CS * 4 + 255) & ~255);
+  static_assert(BGeo<G>::CBP % T::CK == 0, "channel chunk must divide the (pair-padded) channel count");
 };
 
 struct BPackArgs {
   const float* w;   // [CS][CB][KS][KS]
   char* wp;
+  const float* bias;  // U8 only (nullable)
 };
 
-// one thread per (M tile, chunk, block, half, m): the 8 k of one A fragment, all three planes
-template <class G, class T>
+// one thread per (M tile, chunk, block, half, m): the 8 k of one A fragment, all three planes.
+// U8 (the frames of the encoder's first layer stay uint8 in HBM; reference: x = (v / 255) * 2 - 1, common/utils.py:79):
+//   sum_k w_k x_k + b  =  sum_k (2 w_k / 255) v_k  +  (b - sum_k w_k)
+// -- the kernel multiplies the RAW bytes v (exact in ONE bf16: no split of the activation, three products instead of six)
+// with weights scaled here, and its bias is the folded vector written behind the planes.
+template <class G, class T, bool U8 = false>
 __global__ __launch_bounds__(256) void bconv_pack_kernel(BPackArgs p) {
   typedef BGeo<G> BG;
   typedef BPack<G, T> P;
   const int total = P::MT * P::NSL * P::NBLK * 2 * T::BM;
+  if (U8) {
+    float* fb = reinterpret_cast<float*>(p.wp + P::BYTES);
+    for (int cs = blockIdx.x * 256 + threadIdx.x; cs < G::CS; cs += gridDim.x * 256) {
+      double s = 0.0;
+      for (int k = 0; k < G::CB * G::KK; ++k) s += (double)p.w[(size_t)cs * G::CB * G::KK + k];
+      fb[cs] = (float)((double)(p.bias ? p.bias[cs] : 0.f) - s);
+    }
+  }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     int r = i;
     const int m = r % T::BM;
@@ -83,7 +100,8 @@ __global__ __launch_bounds__(256) void bconv_pack_kernel(BPackArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int q = 8 * b + j, ky = q / BG::KSE, kx = q % BG::KSE;
-      v[j] = (q < BG::TAPS && kx < G::KS && cs < G::CS) ? p.w[((size_t)cs * G::CB + cb) * G::KK + ky * G::KS + kx] : 0.f;
+      v[j] = (q < BG::TAPS && kx < G::KS && cs < G::CS && cb < G::CB) ? p.w[((size_t)cs * G::CB + cb) * G::KK + ky * G::KS + kx] : 0.f;
+      if (U8) v[j] *= 2.f / 255.f;
     }
     unsigned pl[3][4];
 #pragma unroll
@@ -95,11 +113,14 @@ __global__ __launch_bounds__(256) void bconv_pack_kernel(BPackArgs p) {
   }
 }
 
-template <class G, class T>
+template <class G, class T, class BigT = float>
 __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   typedef BGeo<G> BG;
   typedef BPack<G, T> P;
-  static_assert(BG::OK, "bf16x6 down kernel: even channel count");
+  constexpr bool U8 = std::is_same<BigT, uint8_t>::value;   // raw bytes: ONE patch plane (a byte is exact in bf16)
+  constexpr int NPL = U8 ? 1 : 3;
+  static_assert(BG::CBP == G::CB || P::NSL == 1, "a padded channel count: one chunk (the phantom channel is chunk-local)");
+  static_assert(!U8 || !BG::ODD, "uint8 frames: even row pitch");
   constexpr bool ODD = BG::ODD;
   constexpr int WBE = BG::WBE;
   constexpr int BM = T::BM, BN = T::BN, CK = T::CK, NT = T::NT, TM = T::TM, TN = T::TN;
@@ -128,7 +149,7 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   constexpr int W_NV = 3 * NBLK * 2 * BM;                    // 16-byte weight vectors per chunk
   constexpr int W_PER = (W_NV + NT - 1) / NT, P_PER = (CK * (QROW ? PLV_E : PLV) + NT - 1) / NT;
   constexpr int EPI_FLOATS = (NT / 64) * 32 * 36 + (NT / 64) * TM * 32;
-  constexpr int LDS_BYTES = cmax(3 * WPLANE + 3 * PPLANE + 64, 4 * EPI_FLOATS);
+  constexpr int LDS_BYTES = cmax(3 * WPLANE + NPL * PPLANE + 64, 4 * EPI_FLOATS);
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* Wl = lds;
   char* Pl = lds + 3 * WPLANE;
@@ -189,10 +210,11 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
       rel = (q - lenA) % LENFULL;
     }
     const int f = (i == ia) ? fa : 0;
-    poff[j] = act ? 4u * (unsigned)((i * G::CB + c) * G::PB + 2 * f * G::WB + rel) : kOobOffset;
+    // (a phantom channel -- odd CB, single chunk -- loads zeros and stores them: its fragment reads meet zero weights)
+    poff[j] = (act && c < G::CB) ? (unsigned)sizeof(BigT) * (unsigned)((i * G::CB + c) * G::PB + 2 * f * G::WB + rel) : kOobOffset;
     plds[j] = act ? 2 * (c * PLMAX_E + q) : -1;   // bytes inside a plane
   }
-  constexpr unsigned P_STEP = 4u * CK * G::PB;
+  constexpr unsigned P_STEP = (unsigned)sizeof(BigT) * CK * G::PB;
   const unsigned wbase = (unsigned)(blockIdx.y * NSL) * (unsigned)P::CHUNK_BYTES;
 
   // ---- per-lane byte bases of the B fragments: the lane's pixel, its half's channel of the pair
@@ -214,7 +236,8 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 rwv[W_PER], rpv[P_PER];
+  f32x4 rwv[W_PER];
+  typename Patch4<BigT>::raw_t rpv[P_PER];
   auto gload = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < W_PER; ++j) {
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < P_PER; ++j)
-      rpv[j] = VecLoad<4>::load(rbig, poff[j] == kOobOffset ? kOobOffset : poff[j] + (unsigned)t * P_STEP);
+      rpv[j] = Patch4<BigT>::load(rbig, poff[j] == kOobOffset ? kOobOffset : poff[j] + (unsigned)t * P_STEP);
   };
   auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -234,12 +257,20 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
 #pragma unroll
     for (int j = 0; j < P_PER; ++j)
       if (plds[j] >= 0) {
-        unsigned a1, a2, a3, b1, b2, b3;
-        bg_split3(rpv[j][0], rpv[j][1], a1, a2, a3);
-        bg_split3(rpv[j][2], rpv[j][3], b1, b2, b3);
-        *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{a1, b1};
-        *reinterpret_cast<bg_u32x2*>(Pl + PPLANE + plds[j]) = bg_u32x2{a2, b2};
-        *reinterpret_cast<bg_u32x2*>(Pl + 2 * PPLANE + plds[j]) = bg_u32x2{a3, b3};
+        if constexpr (U8) {
+          // four bytes -> four bf16 (exact): float(v) has at most 8 significant bits, its upper half IS the bf16
+          const unsigned v = rpv[j];
+          const unsigned f0 = __builtin_bit_cast(unsigned, (float)(v & 0xffu)), f1 = __builtin_bit_cast(unsigned, (float)((v >> 8) & 0xffu));
+          const unsigned f2 = __builtin_bit_cast(unsigned, (float)((v >> 16) & 0xffu)), f3 = __builtin_bit_cast(unsigned, (float)(v >> 24));
+          *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{(f0 >> 16) | (f1 & 0xffff0000u), (f2 >> 16) | (f3 & 0xffff0000u)};
+        } else {
+          unsigned a1, a2, a3, b1, b2, b3;
+          bg_split3(rpv[j][0], rpv[j][1], a1, a2, a3);
+          bg_split3(rpv[j][2], rpv[j][3], b1, b2, b3);
+          *reinterpret_cast<bg_u32x2*>(Pl + plds[j]) = bg_u32x2{a1, b1};
+          *reinterpret_cast<bg_u32x2*>(Pl + PPLANE + plds[j]) = bg_u32x2{a2, b2};
+          *reinterpret_cast<bg_u32x2*>(Pl + 2 * PPLANE + plds[j]) = bg_u32x2{a3, b3};
+        }
       }
   };
   // byte offset (inside a plane, from the half's base) of the dword that holds slots q, q + 1 of channel pair g
@@ -251,14 +282,14 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
       const int g = blk / BG::BPG, b = blk % BG::BPG;
-      bg_bf16x8 fa[TM][3], fb[TN][3];
+      bg_bf16x8 fa[TM][3], fb[TN][NPL];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
           fa[i][pl] = *reinterpret_cast<const bg_bf16x8*>(Wl + pl * WPLANE + blk * (2 * BM * 16) + abase + i * 32 * 16);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < (pl < NPL ? TN : 0); ++j) {
           const char* pb = Pl + pl * PPLANE + bbh[j];
           u32x4s d;
 #pragma unroll
@@ -271,12 +302,18 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           f32x16 c = acc[i][j];  // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+          if constexpr (U8) {   // the byte plane is exact: w = w1 + w2 + w3 against it
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+          } else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][NPL > 1 ? 1 : 0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NPL > 2 ? 2 : 0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NPL > 1 ? 1 : 0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+          }
           acc[i][j] = c;
         }
     }
@@ -286,7 +323,7 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   if (ODD) {
     // the pad column of every row is read (slot kx = KS of an odd kernel, against a zero weight): it must hold a
     // finite value, and no store below ever touches it
-    for (int i = tid; i < 3 * PPLANE / 16; i += NT) reinterpret_cast<f32x4*>(Pl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < NPL * PPLANE / 16; i += NT) reinterpret_cast<f32x4*>(Pl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
   }
   lstore();
@@ -303,18 +340,20 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   dconv_down_epilogue<G, T>(p, reinterpret_cast<float*>(lds), acc, n0, m0, Ntot);
 }
 
-template <class G, class T>
+template <class G, class T, class BigT = float>
 inline int launch_bconv_down(const DownArgs& a, const float* w, char* pack, hipStream_t s) {
   typedef BPack<G, T> P;
+  constexpr bool U8 = std::is_same<BigT, uint8_t>::value;
   const int total = P::MT * P::NSL * P::NBLK * 2 * T::BM;
-  hipLaunchKernelGGL((bconv_pack_kernel<G, T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, BPackArgs{w, pack});
+  hipLaunchKernelGGL((bconv_pack_kernel<G, T, U8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, BPackArgs{w, pack, a.bias});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   DownArgs b = a;
   b.w = reinterpret_cast<const float*>(pack);
   b.w_bytes = (unsigned)P::BYTES;
+  if (U8) b.bias = reinterpret_cast<const float*>(pack + P::BYTES);   // the folded bias: b - sum w (pack kernel)
   const long gx = ((long)a.nimg * G::PS + T::BN - 1) / T::BN, gy = P::MT;
-  hipLaunchKernelGGL((bconv_down_kernel<G, T>), dim3((unsigned)gx, (unsigned)gy), dim3(T::NT), 0, s, b);
+  hipLaunchKernelGGL((bconv_down_kernel<G, T, BigT>), dim3((unsigned)gx, (unsigned)gy), dim3(T::NT), 0, s, b);
   e = hipGetLastError();
   return e == hipSuccess ? REPO_OK : (int)e;
 }

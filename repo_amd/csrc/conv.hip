@@ -17,6 +17,7 @@
 //          split over images into slabs, reduced in fixed order.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "igemm.h"
@@ -461,25 +462,41 @@ template <> struct BDownFor<GEnc2> { using type = REPO_BT_ENC2; };
 #endif
 template <> struct BDownFor<GDec2> { using type = REPO_BT_DEC2; };   // 13 x 13 planes, k5 (32 slots for 25 taps)
 template <class G> constexpr bool kBDown = !std::is_same<typename BDownFor<G>::type, NoBTile>::value;
+// ... and for uint8 frames (the encoder's first layer as train_agent() feeds it): the bytes are exact in ONE bf16, so the
+// product needs three MFMAs per block instead of six and no split of the activation (bconv.h, U8); float frames of the
+// same layer stay on the fp32 kernel.
+template <class G> struct BDownU8For { using type = NoBTile; };
+#ifndef REPO_BT_ENC1U8
+#define REPO_BT_ENC1U8 BTile<32, 512, 4, 1, 8>
+#endif
+template <> struct BDownU8For<GEnc1> { using type = REPO_BT_ENC1U8; };
+template <class G> constexpr bool kBDownU8 = !std::is_same<typename BDownU8For<G>::type, NoBTile>::value;
+template <class G, class BigT>
+constexpr bool kBDownT = std::is_same<BigT, float>::value ? kBDown<G> : kBDownU8<G>;
+template <class G, class BigT>
+using BDownTile = typename std::conditional<std::is_same<BigT, float>::value, typename BDownFor<G>::type, typename BDownU8For<G>::type>::type;
 
-template <class G>
+template <class G, class BigT = float>
 static bool bconv_down_on(int64_t nimg) {
-  if constexpr (kBDown<G>) return t_bconv_enabled && nimg * (int64_t)G::PS > 512;
+  if constexpr (kBDownT<G, BigT>) return t_bconv_enabled && nimg * (int64_t)G::PS > 512;
   return false;
 }
-template <class G>
+template <class G, class BigT = float>
 static size_t bconv_pack_bytes() {
-  if constexpr (kBDown<G>) return (BPack<G, typename BDownFor<G>::type>::BYTES + 255) & ~(size_t)255;
+  if constexpr (kBDownT<G, BigT>) {
+    typedef BPack<G, BDownTile<G, BigT>> P;
+    return ((std::is_same<BigT, float>::value ? P::BYTES : P::BYTES_U8) + 255) & ~(size_t)255;
+  }
   return 0;
 }
 
 // pixel tiles of the direct conv's grid = rows of the channel-sum partials (repo_conv_down's dbias)
-template <class G>
+template <class G, class BigT = float>
 static long conv_down_tiles(int64_t nimg) {
   const long px = nimg * (long)G::PS;
   long bn = px <= 512 ? DLatTile<G>::type::BN : DTileFor<G>::Down::BN;
-  if constexpr (kBDown<G>)
-    if (bconv_down_on<G>(nimg)) bn = BDownFor<G>::type::BN;
+  if constexpr (kBDownT<G, BigT>)
+    if (bconv_down_on<G, BigT>(nimg)) bn = BDownTile<G, BigT>::BN;
   return (px + bn - 1) / bn;
 }
 
@@ -493,14 +510,14 @@ static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const floa
   // on the fp32-MFMA kernel (ws stays optional for callers that want no dbias)
   bool bf = false;
   size_t pack_bytes = 0;
-  if constexpr (kBDown<G> && std::is_same<BigT, float>::value) {
-    pack_bytes = bconv_pack_bytes<G>();
-    bf = bconv_down_on<G>(nimg) && ws && ws_bytes >= pack_bytes + (dbias ? (size_t)conv_down_tiles<G>(nimg) * G::CS * sizeof(float) : 0);
+  if constexpr (kBDownT<G, BigT>) {
+    pack_bytes = bconv_pack_bytes<G, BigT>();
+    bf = bconv_down_on<G, BigT>(nimg) && ws && ws_bytes >= pack_bytes + (dbias ? (size_t)conv_down_tiles<G, BigT>(nimg) * G::CS * sizeof(float) : 0);
     if (!bf) pack_bytes = 0;
   }
-  long tiles = conv_down_tiles<G>(nimg);
-  if constexpr (kBDown<G>)
-    if (!bf && bconv_down_on<G>(nimg)) {   // the pack did not fit: the fp32 kernel's grid
+  long tiles = conv_down_tiles<G, BigT>(nimg);
+  if constexpr (kBDownT<G, BigT>)
+    if (!bf && bconv_down_on<G, BigT>(nimg)) {   // the pack did not fit: the fp32 kernel's grid
       const long px = nimg * (long)G::PS;
       tiles = (px + DTileFor<G>::Down::BN - 1) / DTileFor<G>::Down::BN;
     }
@@ -509,8 +526,8 @@ static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const floa
   DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
              (unsigned)(G::CS * G::CB * G::KK * sizeof(float)), parts, cmask};
   int rc;
-  if constexpr (kBDown<G> && std::is_same<BigT, float>::value) {
-    if (bf) rc = launch_bconv_down<G, typename BDownFor<G>::type>(a, w, (char*)ws, s);
+  if constexpr (kBDownT<G, BigT>) {
+    if (bf) rc = launch_bconv_down<G, BDownTile<G, BigT>, BigT>(a, w, (char*)ws, s);
     else rc = (nimg * (int64_t)G::PS <= 512) ? launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s)
                                             : launch_dconv_down<G, BigT, typename DTileFor<G>::Down>(a, s);
   } else {
@@ -764,8 +781,10 @@ extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_
 
 extern "C" size_t repo_conv_down_workspace_bytes(int layer, int64_t nimg) {
   if (nimg <= 0) return 0;
-  REPO_LAYER_SWITCH(layer, return ((bconv_down_on<G>(nimg) ? bconv_pack_bytes<G>() : 0) +
-                                   (size_t)conv_down_tiles<G>(nimg) * G::CS * sizeof(float)))
+  // (the frame type is not known here: room for whichever of the float / uint8 variants needs more)
+  REPO_LAYER_SWITCH(layer, return (std::max(bconv_down_on<G, float>(nimg) ? bconv_pack_bytes<G, float>() : 0,
+                                            bconv_down_on<G, uint8_t>(nimg) ? bconv_pack_bytes<G, uint8_t>() : 0) +
+                                   (size_t)std::max(conv_down_tiles<G, float>(nimg), conv_down_tiles<G, uint8_t>(nimg)) * G::CS * sizeof(float)))
 }
 
 extern "C" int repo_debug_bconv(int enable) {
