@@ -481,6 +481,14 @@ int repo_dual_step_tasks(int64_t C, float* log_beta, float* exp_avg, float* exp_
                          int64_t rows, float lr, float beta1, float beta2, float eps, int64_t step, int apply,
                          float* scalars_out, const unsigned* skip_if_nonzero, hipStream_t stream);
 
+/* dst[c * ldd + r] = src[r * lds + c] for r < rows, c < cols; columns [rows, ldd) of dst are written as zeros
+ * (ldd - rows < 64; lds, ldd multiples of 4, 16-byte aligned pointers).  The host side uses it to hand the bf16x6 dense
+ * engine (repo_gemm) k-contiguous operands for the decoder's 1024 -> 3200 layer: forward on W^T (the reference's
+ * ConvTranspose2d weight keeps its (in, out, kH, kW) layout: models/decoder.py:43), weight gradient on the transposed
+ * activations -- torch's counterpart is the .t() view that at::mm resolves inside the BLAS call. */
+int repo_transpose(int64_t rows, int64_t cols, const float* src, int64_t lds, float* dst, int64_t ldd,
+                   hipStream_t stream);
+
 /* ------------------------------------------------------------------ optimiser
  * *sqnorm = sum g^2 over a flat, 16-byte aligned buffer (global norm of
  * nn.utils.clip_grad_norm_, repo.py:89).  Fixed-order two-level sum. */

@@ -18,6 +18,6 @@ def run(n):
 run(5)
 print("with per-update log flush: enqueue %.2f total %.2f ms" % run(40))
 orig = agent._flush_log
-agent._flush_log = lambda: setattr(agent, "_log_pending", None)
+agent._flush_log = lambda defer=False: setattr(agent, "_log_pending", None)
 run(5)
 print("without the flush (no host wait on the previous update): enqueue %.2f total %.2f ms" % run(40))
