@@ -355,93 +355,25 @@ struct DTileFor;
 // the 3-channel layers are one channel chunk per workgroup (no pipelining inside it): 8 waves per tile and short
 // weight-gradient bands measured best (tile sweep, round 2: enc1 fwd 148 -> 140 us, enc1 wgrad 224 -> 171,
 // dec4 dgrad 311-338 -> 247, dec4 wgrad 210 -> 201)
-#ifndef REPO_WT_ENC1
-#define REPO_WT_ENC1 WTile<32, 64, 1, 2, 1, 4, 2>
-#endif
-#ifndef REPO_DT_ENC1
-#define REPO_DT_ENC1 DTile<32, 512, 3, 1, 8>
-#endif
-template <> struct DTileFor<GEnc1> { using Down = REPO_DT_ENC1; using Wgrad = REPO_WT_ENC1; static constexpr int WGT = 3072; };
-#ifndef REPO_WT_ENC2
-#define REPO_WT_ENC2 WTile<64, 128, 2, 2, 1, 7, 2>
-#endif
-#ifndef REPO_DT_ENC2
-#define REPO_DT_ENC2 DTile<64, 128, 2, 2, 2>
-#endif
-template <> struct DTileFor<GEnc2> { using Down = REPO_DT_ENC2; using Wgrad = REPO_WT_ENC2; static constexpr int WGT = 768; };
-#ifndef REPO_WT_ENC3
-#define REPO_WT_ENC3 WTile<64, 128, 2, 2, 2, 6>
-#endif
-#ifndef REPO_DT_ENC3
-#define REPO_DT_ENC3 DTile<128, 128, 2, 2, 2>
-#endif
-template <> struct DTileFor<GEnc3> { using Down = REPO_DT_ENC3; using Wgrad = REPO_WT_ENC3; static constexpr int WGT = 1024; };
+template <> struct DTileFor<GEnc1> { using Down = DTile<32, 512, 3, 1, 8>; using Wgrad = WTile<32, 64, 1, 2, 1, 4, 2>; static constexpr int WGT = 3072; };
+template <> struct DTileFor<GEnc2> { using Down = DTile<64, 128, 2, 2, 2>; using Wgrad = WTile<64, 128, 2, 2, 1, 7, 2>; static constexpr int WGT = 768; };
+template <> struct DTileFor<GEnc3> { using Down = DTile<128, 128, 2, 2, 2>; using Wgrad = WTile<64, 128, 2, 2, 2, 6>; static constexpr int WGT = 1024; };
 // enc4 forward has only 9800 output pixels: 128 x 128 tiles are 154 workgroups on 256 CUs (171 us); 32 x 64: 125 us
-#ifndef REPO_WT_ENC4
-#define REPO_WT_ENC4 WTile<64, 128, 2, 2, 8, 2>
-#endif
-#ifndef REPO_DT_ENC4
-#define REPO_DT_ENC4 DTile<32, 64, 2, 1, 2>
-#endif
-template <> struct DTileFor<GEnc4> { using Down = REPO_DT_ENC4; using Wgrad = REPO_WT_ENC4; static constexpr int WGT = 768; };
-#ifndef REPO_WT_DEC2
-#define REPO_WT_DEC2 WTile<64, 128, 2, 2, 4, 5>
-#endif
-#ifndef REPO_DT_DEC2
-#define REPO_DT_DEC2 DTile<128, 128, 4, 2, 4, 1>  // 8 waves: 306 -> 274 us (A/B on one box)
-#endif
-template <> struct DTileFor<GDec2> { using Down = REPO_DT_DEC2; using Wgrad = REPO_WT_DEC2; static constexpr int WGT = 1536; };
-#ifndef REPO_WT_DEC3
-#define REPO_WT_DEC3 WTile<64, 128, 2, 2, 1, 7>
-#endif
-#ifndef REPO_DT_DEC3
-#define REPO_DT_DEC3 DTile<64, 128, 2, 2, 2>
-#endif
-template <> struct DTileFor<GDec3> { using Down = REPO_DT_DEC3; using Wgrad = REPO_WT_DEC3; static constexpr int WGT = 2048; };
-#ifndef REPO_WT_DEC4
-#define REPO_WT_DEC4 WTile<32, 128, 1, 4, 1, 2>
-#endif
-#ifndef REPO_DT_DEC4
-#define REPO_DT_DEC4 DTile<32, 256, 3, 1, 8>
-#endif
-template <> struct DTileFor<GDec4> { using Down = REPO_DT_DEC4; using Wgrad = REPO_WT_DEC4; static constexpr int WGT = 1536; };
+template <> struct DTileFor<GEnc4> { using Down = DTile<32, 64, 2, 1, 2>; using Wgrad = WTile<64, 128, 2, 2, 8, 2>; static constexpr int WGT = 768; };
+// (dec2 down: 8 waves, 306 -> 274 us, A/B on one box)
+template <> struct DTileFor<GDec2> { using Down = DTile<128, 128, 4, 2, 4, 1>; using Wgrad = WTile<64, 128, 2, 2, 4, 5>; static constexpr int WGT = 1536; };
+template <> struct DTileFor<GDec3> { using Down = DTile<64, 128, 2, 2, 2>; using Wgrad = WTile<64, 128, 2, 2, 1, 7>; static constexpr int WGT = 2048; };
+template <> struct DTileFor<GDec4> { using Down = DTile<32, 256, 3, 1, 8>; using Wgrad = WTile<32, 128, 1, 4, 1, 2>; static constexpr int WGT = 1536; };
 // 128 x 128 stack: tiles by analogy with the 64 x 64 layer of the same role (not swept)
-#ifndef REPO_WT_X1
-#define REPO_WT_X1 WTile<32, 64, 1, 2, 1, 2, 2>
-#endif
-#ifndef REPO_WT_X2
-#define REPO_WT_X2 WTile<64, 128, 2, 2, 1, 3, 2>
-#endif
-#ifndef REPO_WT_X3
-#define REPO_WT_X3 WTile<64, 128, 2, 2, 1, 7>
-#endif
-#ifndef REPO_WT_X4
-#define REPO_WT_X4 WTile<64, 128, 2, 2, 2, 6>
-#endif
-#ifndef REPO_WT_Y4
-#define REPO_WT_Y4 WTile<32, 128, 1, 4, 1, 2>
-#endif
-#ifndef REPO_WT_Y5
-#define REPO_WT_Y5 WTile<32, 64, 1, 2, 1, 2>
-#endif
-#ifndef REPO_WGT_X1
-#define REPO_WGT_X1 3072
-#endif
-#ifndef REPO_WGT_X2
-#define REPO_WGT_X2 1536
-#endif
-#ifndef REPO_WGT_Y5
-#define REPO_WGT_Y5 1536
-#endif
 // (GX1's weight gradient walks 2-row bands: with 4 rows of 63 pixels the 126 k-pairs of a band exceed what the
 // compiler unrolls, the chunk-ahead loads then index their registers at run time: 1935 us instead of ~400)
-template <> struct DTileFor<GX1> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = REPO_WT_X1; static constexpr int WGT = REPO_WGT_X1; };
-template <> struct DTileFor<GX2> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = REPO_WT_X2; static constexpr int WGT = REPO_WGT_X2; };
-template <> struct DTileFor<GX3> { using Down = DTile<128, 128, 2, 2, 2>; using Wgrad = REPO_WT_X3; static constexpr int WGT = 1024; };
-template <> struct DTileFor<GX4> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = REPO_WT_X4; static constexpr int WGT = 1024; };
-template <> struct DTileFor<GY4> { using Down = DTile<32, 256, 2, 1, 4>;  using Wgrad = REPO_WT_Y4; static constexpr int WGT = 1536; };
+template <> struct DTileFor<GX1> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = WTile<32, 64, 1, 2, 1, 2, 2>; static constexpr int WGT = 3072; };
+template <> struct DTileFor<GX2> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 1, 3, 2>; static constexpr int WGT = 1536; };
+template <> struct DTileFor<GX3> { using Down = DTile<128, 128, 2, 2, 2>; using Wgrad = WTile<64, 128, 2, 2, 1, 7>; static constexpr int WGT = 1024; };
+template <> struct DTileFor<GX4> { using Down = DTile<64, 128, 2, 2, 2>;  using Wgrad = WTile<64, 128, 2, 2, 2, 6>; static constexpr int WGT = 1024; };
+template <> struct DTileFor<GY4> { using Down = DTile<32, 256, 2, 1, 4>;  using Wgrad = WTile<32, 128, 1, 4, 1, 2>; static constexpr int WGT = 1536; };
 template <> struct DTileFor<GT4> { using Down = DTile<32, 256, 3, 1, 8>;  using Wgrad = WTile<32, 128, 1, 4, 1, 2>; static constexpr int WGT = 1536; };
-template <> struct DTileFor<GY5> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = REPO_WT_Y5; static constexpr int WGT = REPO_WGT_Y5; };
+template <> struct DTileFor<GY5> { using Down = DTile<32, 512, 3, 1, 8>;  using Wgrad = WTile<32, 64, 1, 2, 1, 2>; static constexpr int WGT = 1536; };
 
 // A handful of frames (the acting path encodes ONE per environment step): the throughput tiles leave 1-2
 // workgroups walking 16-64 dependent channel chunks (enc4: 147 us for one frame).  Latency tiles use 32
@@ -455,37 +387,20 @@ template <> struct DLatTile<GEnc4> { using type = DTile<32, 128, 8, 1, 4>; };
 // big-row pitch; NoBTile = the layer stays on the fp32-MFMA kernel (3-channel layers: bandwidth / epilogue bound).  Test aid repo_debug_bconv(0) keeps every layer on the fp32 kernel.
 struct NoBTile {};
 template <class G> struct BDownFor { using type = NoBTile; };
-#ifndef REPO_BT_DEC3
-#define REPO_BT_DEC3 BTile<64, 256, 2, 1, 4>
-#endif
-template <> struct BDownFor<GDec3> { using type = REPO_BT_DEC3; };
-#ifndef REPO_BT_ENC3
-#define REPO_BT_ENC3 BTile<128, 128, 4, 2, 2>   // one M tile: the patch is staged (and split) once, 169 -> 146 us
-#endif
-#ifndef REPO_BT_ENC4
-#define REPO_BT_ENC4 BTile<128, 64, 4, 2, 2>    // 112 -> 101 us
-#endif
-template <> struct BDownFor<GEnc3> { using type = REPO_BT_ENC3; };
-template <> struct BDownFor<GEnc4> { using type = REPO_BT_ENC4; };
+template <> struct BDownFor<GDec3> { using type = BTile<64, 256, 2, 1, 4>; };
+// enc3 / enc4: ONE M tile per workgroup (the patch is staged and split once): 169 -> 146 us, 112 -> 101 (round 5)
+template <> struct BDownFor<GEnc3> { using type = BTile<128, 128, 4, 2, 2>; };
+template <> struct BDownFor<GEnc4> { using type = BTile<128, 64, 4, 2, 2>; };
 // enc2 forward (31 x 31 planes, k4): with the element-wise staging of its padded pitch it measured equal on both kernels
 // (312 vs 309 us, round 4); staged by LDS quads (bconv.h, QROW) it is on the bf16 pipe
-#ifndef REPO_BT_ENC2
-#define REPO_BT_ENC2 BTile<64, 256, 4, 1, 4>
-#endif
-template <> struct BDownFor<GEnc2> { using type = REPO_BT_ENC2; };
-#ifndef REPO_BT_DEC2
-#define REPO_BT_DEC2 BTile<64, 128, 2, 1, 4>
-#endif
-template <> struct BDownFor<GDec2> { using type = REPO_BT_DEC2; };   // 13 x 13 planes, k5 (32 slots for 25 taps)
+template <> struct BDownFor<GEnc2> { using type = BTile<64, 256, 4, 1, 4>; };
+template <> struct BDownFor<GDec2> { using type = BTile<64, 128, 2, 1, 4>; };   // 13 x 13 planes, k5 (32 slots for 25 taps)
 template <class G> constexpr bool kBDown = !std::is_same<typename BDownFor<G>::type, NoBTile>::value;
 // ... and for uint8 frames (the encoder's first layer as train_agent() feeds it): the bytes are exact in ONE bf16, so the
 // product needs three MFMAs per block instead of six and no split of the activation (bconv.h, U8); float frames of the
 // same layer stay on the fp32 kernel.
 template <class G> struct BDownU8For { using type = NoBTile; };
-#ifndef REPO_BT_ENC1U8
-#define REPO_BT_ENC1U8 BTile<32, 512, 4, 1, 8>
-#endif
-template <> struct BDownU8For<GEnc1> { using type = REPO_BT_ENC1U8; };
+template <> struct BDownU8For<GEnc1> { using type = BTile<32, 512, 4, 1, 8>; };
 template <class G> constexpr bool kBDownU8 = !std::is_same<typename BDownU8For<G>::type, NoBTile>::value;
 template <class G, class BigT>
 constexpr bool kBDownT = std::is_same<BigT, float>::value ? kBDown<G> : kBDownU8<G>;
@@ -579,46 +494,16 @@ template <> struct UConf<GX4> { using type = SConf<GX4, 4, 1>; };
 //                           the last chunk's MFMAs each changed nothing): the scatter kernel stays
 struct NoTile {};
 template <class G> struct UpDirect { using type = NoTile; };
-#ifndef REPO_UPD_ENC2
-#define REPO_UPD_ENC2 NoTile
-#endif
-#ifndef REPO_UPD_ENC3
-#define REPO_UPD_ENC3 NoTile
-#endif
-#ifndef REPO_UPD_ENC4
-#define REPO_UPD_ENC4 NoTile
-#endif
-#ifndef REPO_UPD_DEC2
-#define REPO_UPD_DEC2 NoTile
-#endif
-#ifndef REPO_UPD_DEC3
-#define REPO_UPD_DEC3 NoTile
-#endif
-#ifndef REPO_UPD_X2
-#define REPO_UPD_X2 DTile<128, 128, 8, 2, 4>
-#endif
-#ifndef REPO_UPD_X3
-#define REPO_UPD_X3 NoTile
-#endif
-#ifndef REPO_UPD_X4
-#define REPO_UPD_X4 NoTile
-#endif
-#ifndef REPO_UPD_Y4
-#define REPO_UPD_Y4 DTile<64, 256, 4, 2, 4>
-#endif
-#ifndef REPO_UPD_T4
-#define REPO_UPD_T4 DTile<32, 256, 4, 1, 8>
-#endif
-template <> struct UpDirect<GEnc2> { using type = REPO_UPD_ENC2; };
-template <> struct UpDirect<GEnc3> { using type = REPO_UPD_ENC3; };
-template <> struct UpDirect<GEnc4> { using type = REPO_UPD_ENC4; };
-template <> struct UpDirect<GDec2> { using type = REPO_UPD_DEC2; };
-template <> struct UpDirect<GDec3> { using type = REPO_UPD_DEC3; };
-template <> struct UpDirect<GX2> { using type = REPO_UPD_X2; };
-template <> struct UpDirect<GX3> { using type = REPO_UPD_X3; };
-template <> struct UpDirect<GX4> { using type = REPO_UPD_X4; };
-template <> struct UpDirect<GY4> { using type = REPO_UPD_Y4; };
-template <> struct UpDirect<GT4> { using type = REPO_UPD_T4; };
+template <> struct UpDirect<GEnc2> { using type = NoTile; };
+template <> struct UpDirect<GEnc3> { using type = NoTile; };
+template <> struct UpDirect<GEnc4> { using type = NoTile; };
+template <> struct UpDirect<GDec2> { using type = NoTile; };
+template <> struct UpDirect<GDec3> { using type = NoTile; };
+template <> struct UpDirect<GX2> { using type = DTile<128, 128, 8, 2, 4>; };
+template <> struct UpDirect<GX3> { using type = NoTile; };
+template <> struct UpDirect<GX4> { using type = NoTile; };
+template <> struct UpDirect<GY4> { using type = DTile<64, 256, 4, 2, 4>; };
+template <> struct UpDirect<GT4> { using type = DTile<32, 256, 4, 1, 8>; };
 template <class G> constexpr bool kUpDirect = !std::is_same<typename UpDirect<G>::type, NoTile>::value;
 
 // The bf16x6 scatter kernel (buconv.h): the decoder's conv3 forward (the update's largest launch), conv2 forward, and the

@@ -1,6 +1,6 @@
 #!/bin/bash
 # build a variant of the library: tools/build_variant.sh <name> [-DFLAG=..]...   -> repo_amd/variants/lib_<name>.so
-# only conv.hip is recompiled with the flags; the other objects come from repo_amd/csrc/build
+# only conv.hip (or SRC=...) is recompiled with the flags (ablation macros such as -DBG_NO_SPLIT; tile choices are edited in the source since round 5); the other objects come from repo_amd/csrc/build
 N=$1; shift
 D=repo_amd/variants; mkdir -p $D
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result "$@" -c repo_amd/csrc/${SRC:-conv}.hip -o $D/${SRC:-conv}_$N.o || exit 1

@@ -29,6 +29,7 @@ pairs = [
     ("r05_bgemm_probe.txt", "r05_bgemm_probe.txt"),
     ("r05_gemm_isolated.txt", "r05_gemm_isolated.txt"),
     ("r05_rollout_engines.txt", "r05_rollout_engines.txt"),
+    ("r05_ab_vs_round4.txt", "r05_ab_vs_round4.txt"),
 ]
 for src, dst in pairs:
     s = os.path.join(G, src)

@@ -13,7 +13,7 @@ python3 tools/launch_count.py $O/r05_bench_pipelined_kernel_stats.csv > $O/r05_l
 bash tools/pmc.sh dec3 "buconv_scatter|uconv_scatter|bconv_down|dconv_down|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv dec3" > /dev/null 2>&1
 bash tools/pmc.sh convs "buconv_scatter|uconv_scatter|bconv_down|dconv_down|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv enc2" "conv enc3" "conv enc4" "conv dec2" > /dev/null 2>&1
 bash tools/pmc.sh scan_rollout "observe_|imagine" tools/run_scan_rollout.py > /dev/null 2>&1
-bash tools/pmc.sh c3 "dconv_dec4|Geo<3, 32|Geo<3,32" tools/run_micro_case.py "conv enc1" "conv dec4" "dec4 forward" > /dev/null 2>&1
+bash tools/pmc.sh c3 "dconv_dec4|bdec4|Geo<3, 32|Geo<3,32" tools/run_micro_case.py "conv enc1" "conv dec4" "dec4 forward" > /dev/null 2>&1
 bash tools/pmc.sh mlp "mlp_(fwd|bwd)_kernel|wgrad_direct" tools/run_micro_case.py "mlp_fwd value" "mlp_bwd value head" "mlp_bwd actor" > /dev/null 2>&1
 python3 tools/lane_time.py > $O/r05_lane_time.txt 2>&1
 python3 tools/phase_time.py > $O/r05_phase_time.txt 2>&1
@@ -29,6 +29,13 @@ python3 bench.py --config mt 2>/dev/null | grep '^{' > $O/r05_bench_mt.json
 tools/probe/bin/bgemm_probe > $O/r05_bgemm_probe.txt 2>&1
 python3 tools/rowtile32_ab.py > $O/r05_rollout_engines.txt 2>&1
 python3 tools/layers_isolated.py gemm > $O/r05_gemm_isolated.txt 2>&1
+# the round's gain on ONE box: the round-4 tree (git archive c56098e -> .r4tree, built in place) against this tree, alternating
+if [ -f .r4tree/bench.py ]; then
+  (for i in 1 2 3; do
+     echo -n "r4 tree : "; (cd .r4tree && python3 bench.py --no-cpu-baseline --steps 60 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'updates/s', d['ms_per_step'], 'ms', 'resident', d['resident_batch_ms'])")
+     echo -n "this tree: "; python3 bench.py --no-cpu-baseline --steps 60 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'updates/s', d['ms_per_step'], 'ms', 'resident', d['resident_batch_ms'])"
+   done) > $O/r05_ab_vs_round4.txt 2>&1
+fi
 python3 bench.py > $O/bench_full.log 2>&1
 grep '^{' $O/bench_full.log > $O/r05_bench_final.json
 tail -c 700 $O/r05_bench_final.json
