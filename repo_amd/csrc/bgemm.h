@@ -35,6 +35,10 @@ typedef unsigned bg_u32x2 __attribute__((ext_vector_type(2)));
 
 // two floats -> their three bf16 parts, packed pairwise (low half = first element)
 __device__ __forceinline__ void bg_split3(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+#ifdef BG_NO_SPLIT   // ablation build (tools/build_variant.sh; profiles/r05_split_ablation.txt): no split arithmetic in ANY
+  p1 = __builtin_bit_cast(unsigned, x0), p2 = __builtin_bit_cast(unsigned, x1), p3 = p1 ^ p2;   // kernel -- results wrong, time meaningful
+  return;
+#endif
   p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(bg_f32x2{x0, x1}, bg_bf16x2));
   const float r0 = x0 - __builtin_bit_cast(float, p1 << 16), r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
   p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(bg_f32x2{r0, r1}, bg_bf16x2));

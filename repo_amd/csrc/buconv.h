@@ -117,6 +117,15 @@ typedef bg_bf16x8 BFrag[3];  // the three planes of one 8-k fragment
 
 template <class C>
 __device__ __forceinline__ void buconv_split(const float (&raw)[C::KST], BFrag (&f)[C::KB]) {
+#ifdef BU_NO_SPLIT   // ablation build (profiles/r05_split_ablation.txt): this kernel's per-chunk split removed
+#pragma unroll
+  for (int kb = 0; kb < C::KB; ++kb)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      f[kb][q] = __builtin_bit_cast(bg_bf16x8, u32x4s{__builtin_bit_cast(unsigned, raw[8 * kb + q]), __builtin_bit_cast(unsigned, raw[8 * kb + q + 1]),
+                                                      __builtin_bit_cast(unsigned, raw[8 * kb + q + 2]), __builtin_bit_cast(unsigned, raw[8 * kb + q + 3])});
+  return;
+#endif
 #pragma unroll
   for (int kb = 0; kb < C::KB; ++kb) {
     unsigned pl[3][4];
