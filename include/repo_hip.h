@@ -70,6 +70,11 @@ const char* repo_strerror(int code);
 int repo_device_check(int device);
 /* Test aid: fills every CU's LDS with NaN patterns (see tests/test_ops_gpu.py::test_no_uninitialised_lds). */
 int repo_debug_poison_lds(hipStream_t stream);
+/* *taken = *sticky; *sticky = 0 -- one update's copy of the scans' sticky asynchronous status word (repo_rssm_observe_fwd),
+ * stream-ordered behind the scans that may have written it; the copy is what that update's optimiser steps take as
+ * `skip_if_nonzero` (repo_clip_adam) and what the caller reads back.  Device pointers, one launch. */
+int repo_take_status(unsigned* sticky, unsigned* taken, hipStream_t stream);
+
 /* The four repo_debug_* switches below are TEST AIDS and THREAD-LOCAL: a setting belongs to the calling host thread and
  * governs the launches that thread issues afterwards (it is read when an entry point is called, never by a kernel);
  * other threads -- e.g. the driver of another stream -- keep their own, default, settings.  The library therefore has

@@ -362,9 +362,7 @@ class Dreamer:
         """Called on the stream that has joined every scan of this update, before its first optimiser step: the
         update's own status word (ops.take_scan_status) becomes the `skip` word of every step of this update."""
         st = self._status_ring[self._update_seq % 8 : self._update_seq % 8 + 1]
-        word = ops.scan_status(self.device)
-        st.copy_(word)
-        word.zero_()
+        ops.take_status_into(ops.scan_status(self.device), st)
         if self.dp is not None:
             self.dp.all_reduce_status(st)
         self._ustatus = st

@@ -92,6 +92,23 @@ extern "C" int repo_debug_poison_lds(hipStream_t stream) {
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
+// One update's copy of the scans' sticky status word, taken and cleared in one launch (stream-ordered behind the scans).
+namespace repo {
+__global__ void take_status_kernel(unsigned* __restrict__ sticky, unsigned* __restrict__ taken) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *taken = *sticky;
+    *sticky = 0u;
+  }
+}
+}  // namespace repo
+extern "C" int repo_take_status(unsigned* sticky, unsigned* taken, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(sticky && taken && sticky != taken, REPO_E_BADARG);
+  hipLaunchKernelGGL(repo::take_status_kernel, dim3(1), dim3(64), 0, stream, sticky, taken);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
 // Test aid: the spin limit of the column-split scans' exchanges (scan_cs.hip reads it per launch).  Like the engine
 // switches (repo_debug_bgemm / _bconv / _rowtile32) it is THREAD-LOCAL: a setting belongs to the host thread that
 // made it and governs the launches that thread issues afterwards -- another thread (another stream's driver) keeps its

@@ -356,11 +356,20 @@ def take_scan_status(device, dp=None):
     over the ranks first, so that a timeout on ONE rank makes EVERY rank skip the same steps and raise in the same
     update (its NaN gradient has been summed into every replica's buffer by then)."""
     w = scan_status(device)
-    st = w.clone()
-    w.zero_()
+    st = torch.empty_like(w)
+    take_status_into(w, st)
     if dp is not None:
         dp.all_reduce_status(st)
     return st
+
+
+def take_status_into(sticky, taken):
+    """*taken = *sticky; *sticky = 0 in ONE launch on a HIP device (repo_take_status); plain tensor ops on the host."""
+    if sticky.is_cuda:
+        check(lib().repo_take_status(_ptr(sticky), _ptr(taken), _stream()), "repo_take_status")
+    else:
+        taken.copy_(sticky)
+        sticky.zero_()
 
 
 class ObserveSaved:
