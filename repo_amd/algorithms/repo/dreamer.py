@@ -242,6 +242,14 @@ class Dreamer:
         self._noise_counter += int(n)
         return self._noise_seed, off
 
+    def _zero_state(self, B):
+        """The initial (belief, state) of a scan -- zeros (repo.py:26-27) -- as constants of the agent: the scans only
+        read them, so the two fill launches per update are made once per batch size."""
+        z = self.__dict__.setdefault("_zero_states", {})
+        if B not in z:
+            z[B] = (torch.zeros(B, self.c.belief_size, device=self.device), torch.zeros(B, self.c.state_size, device=self.device))
+        return z[B]
+
     def _global_rows(self, local_rows):
         """Row count of the global batch (sum over data-parallel ranks)."""
         if self.dp is None:
@@ -270,8 +278,7 @@ class Dreamer:
         pe, _ = self._pg(self.encoder)
         embeds, st["enc_saved"] = Fn.encoder_fwd(pe, frames)
         pr, _ = self._pg(self.transition_model)
-        b0 = torch.zeros(B, D, device=dev)
-        s0 = torch.zeros(B, S, device=dev)
+        b0, s0 = self._zero_state(B)
         sv = ops.rssm_observe_fwd(
             pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
             self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev,

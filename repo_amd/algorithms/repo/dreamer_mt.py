@@ -95,7 +95,7 @@ class MultitaskDreamer(Dreamer):
         pr, _ = self._pg(self.transition_model)
         pseudo = torch.cat((actions[:-1], tasks[:-1]), dim=2).contiguous()
         sv = ops.rssm_observe_fwd(
-            pr, torch.zeros(B, D, device=dev), torch.zeros(B, S, device=dev), pseudo,
+            pr, *self._zero_state(B), pseudo,
             nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
             self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev,
             noise=self._draw(2 * T * B * S),

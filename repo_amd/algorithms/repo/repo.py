@@ -71,7 +71,7 @@ class RePo(Dreamer):
         embeds, enc_saved = Fn.encoder_fwd(pe, frames)
         pr, gr = self._pg(self.transition_model)
         sv = ops.rssm_observe_fwd(
-            pr, torch.zeros(B, D, device=dev), torch.zeros(B, S, device=dev), actions[:-1].contiguous(),
+            pr, *self._zero_state(B), actions[:-1].contiguous(),
             nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1), self._noise("obs_prior", (T, B, S)),
             self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev, noise=self._draw(2 * T * B * S))
         feat = sv.featx[1:].reshape(rows, D + S)

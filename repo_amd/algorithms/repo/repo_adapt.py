@@ -42,8 +42,7 @@ class FinetunedRePo(RePo):
         pe, ge = self._pg(self.encoder)
         embeds, enc_saved = Fn.encoder_fwd(pe, frames)
         pr, _ = self._pg(self.transition_model)
-        b0 = torch.zeros(B, D, device=dev)
-        s0 = torch.zeros(B, S, device=dev)
+        b0, s0 = self._zero_state(B)
         sv = ops.rssm_observe_fwd(
             pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
             self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev,

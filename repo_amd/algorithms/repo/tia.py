@@ -99,8 +99,7 @@ class TIA(Dreamer):
     def _observe(self, model, actions, nonterms, embeds, T, B, noise):
         c, dev = self.c, self.device
         pr, _ = self._pg(model)
-        b0 = torch.zeros(B, c.belief_size, device=dev)
-        s0 = torch.zeros(B, c.state_size, device=dev)
+        b0, s0 = self._zero_state(B)
         return ops.rssm_observe_fwd(
             pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
             noise[0], noise[1], model.min_std_dev, noise=noise[2],
