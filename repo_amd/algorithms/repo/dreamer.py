@@ -453,7 +453,11 @@ class Dreamer:
             wide.view(Hm + 1, N, Fw)[:, :, F_:] = cond
             x_all = wide
         feats = x_all[N:]
-        r_pred, r_hid = ops.mlp_fwd(pw, feats)
+        # the reward of the LAST imagined step is never used (lambda_return reads r[:-1], common/utils.py:61-71; the
+        # reference computes it all the same): the head runs on the first Hm - 1 steps' rows, forward and backward
+        nr_ = (Hm - 1) * N
+        r_pred = torch.empty(Hm * N, 1, device=dev)
+        _, r_hid = ops.mlp_fwd(pw, feats[:nr_], out=r_pred[:nr_])
         v_pred, v_hid = ops.mlp_fwd(pv, feats)
         # -- action entropy on the (attached) imagined states (dreamer.py:320-324).  The reference
         #    re-runs the actor on imag[0..Hm-1]; rows of steps 1..Hm-1 are the very inputs the rollout
@@ -476,8 +480,8 @@ class Dreamer:
                                                      gret)
         # -- backward: heads -> entropy path (input gradient only) -> reverse rollout
         dfeat = torch.empty(Hm * N, Fw, device=dev)
-        ops.mlp_bwd(pw, feats, r_hid, dr.view(Hm * N, 1), dparams=None, dx=dfeat)
-        ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat, accumulate_dx=True)
+        ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat)
+        ops.mlp_bwd(pw, feats[:nr_], r_hid, dr.view(Hm * N, 1)[:nr_], dparams=None, dx=dfeat[:nr_], accumulate_dx=True)
         # -- critic on detached imag[:-1] against detached returns (dreamer.py:362-373), forked onto a
         #    side stream: it needs only `returns` and the value head's saved activations (the value
         #    weights have not changed since v_pred was computed), so it runs while the reverse
