@@ -25,9 +25,12 @@ def encoder_fwd(p, obs):
         h3 = ops.conv_down(L[2], h2, p[4], p[5], epi=ops.EPI_RELU)
         h4 = ops.conv_down(L[3], h3, p[6], p[7], epi=ops.EPI_RELU)
         return ops.gemm(h4.view(h4.shape[0], -1), p[8], transb=True, bias=p[9]), (h1, h2, h3, h4)
-    # each layer also writes the channel-quad mask of its ReLU (1/16 of the activation's bytes): all the data
-    # gradient of the layer above needs of it (19 MB instead of 301 MB for h1 at 2450 frames)
-    h1, m1 = ops.conv_down(L[0], obs, p[0], p[1], epi=ops.EPI_RELU, want_cmask=True)
+    # conv2 and conv3 also write the channel-quad mask of their ReLU (1/16 of the activation's bytes): all the data
+    # gradient of the layer above needs of it
+    # (not h1's: since round 5 conv1 runs on the raw bytes at 100 us and its mask costs 40 us of byte stores, which is
+    # what conv2's data gradient saves by reading 19 MB instead of 301: update 6.351 / 6.359 / 6.369 ms without against
+    # 6.360 / 6.371 / 6.382 with, alternating on one box)
+    h1, m1 = ops.conv_down(L[0], obs, p[0], p[1], epi=ops.EPI_RELU), None
     h2, m2 = ops.conv_down(L[1], h1, p[2], p[3], epi=ops.EPI_RELU, want_cmask=True)
     h3, m3 = ops.conv_down(L[2], h2, p[4], p[5], epi=ops.EPI_RELU, want_cmask=True)
     h4 = ops.conv_down(L[3], h3, p[6], p[7], epi=ops.EPI_RELU)

@@ -80,8 +80,8 @@ for li, nm in enumerate(LAYERS):
         big, small, w, bs, bb = mk()
         out = torch.empty_like(small)
         if LAYERS[li].startswith("enc"):
-            # as the update calls it: enc1 .. enc3 also write the channel-quad mask of their ReLU
-            wm = LAYERS[li] in ("enc1", "enc2", "enc3") and os.environ.get("ISO_MASK", "1") == "1"
+            # as the update calls it: enc2 and enc3 also write the channel-quad mask of their ReLU
+            wm = LAYERS[li] in ("enc2", "enc3") and os.environ.get("ISO_MASK", "1") == "1"
             return lambda: ops.conv_down(li, big, w, bs, epi=ops.EPI_RELU, out=out, want_cmask=wm)
         aux = small.clone()
         if LAYERS[li] == "dec4" and os.environ.get("ISO_MASK", "1") == "1":   # as the update calls it: the ReLU operand is the quad mask of the fused output layer
@@ -95,7 +95,7 @@ for li, nm in enumerate(LAYERS):
         out = torch.empty_like(bigf)
         if LAYERS[li].startswith("dec"):
             return lambda: ops.conv_up(li, small, w, bb, epi=ops.EPI_RELU, out=out)
-        if LAYERS[li] in ("enc2", "enc3", "enc4") and os.environ.get("ISO_MASK", "1") == "1":
+        if LAYERS[li] in ("enc3", "enc4") and os.environ.get("ISO_MASK", "1") == "1":
             # as the update calls it: the ReLU operand is the channel-quad mask the forward wrote (1/16 of the bytes)
             cmask = torch.randint(0, 16, (bigf.numel() // 4,), device=dev, dtype=torch.uint8)
             return lambda: ops.conv_up(li, small, w, None, epi=ops.EPI_MUL_CMASK, aux=cmask, out=out)
