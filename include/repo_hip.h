@@ -60,6 +60,13 @@ typedef struct ihipStream_t* hipStream_t;
                                 whose drain owns four channels of a pixel): 19 MB of mask instead of 301 MB of
                                 activations for the encoder's first layer at 2450 frames                           */
 
+#define REPO_EPI_FILM_RELU 7 /* FiLM + ReLU of the multitask agents' conv stacks (models/encoder.py:75-88, decoder.py:108-123):
+                                relu(scale[n][c] * (x + bias[c]) + shift[n][c]) with aux = this layer's FiLM TABLE, fp32
+                                (nimg, 2, C): row n = [scale = 1 + gamma (C) | shift = beta (C)] (repo_film_tables).
+                                Accepted by repo_conv_down, repo_conv_up (scatter kernels) and repo_gemm (c = n /
+                                bias_div, ldaux = 2 C): the modulation is an epilogue, the pre-FiLM tensor is never
+                                written; the backward pass recovers it from the output (repo_film_bwd_h)             */
+
 int repo_abi_version(void);
 const char* repo_strerror(int code);
 /* REPO_OK if HIP device `device` is gfx950 (MI355X), REPO_E_ARCH if it is another architecture, REPO_E_BADARG
@@ -467,6 +474,17 @@ int repo_film_fwd(int64_t nimg, int64_t C, int64_t P, const float* y, const floa
                   int64_t gamma_off, int64_t beta_off, float* out, hipStream_t stream);
 int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* y, const float* film,
                   int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm, hipStream_t stream);
+/* The FiLM tables of the layers of one conv stack in ONE launch: film (nimg, ldfilm) is the FiLM Linear's output,
+ * [gammas of all layers | betas of all layers] (film(condition).chunk(2) then .split(channels), encoder.py:80-82); layer l
+ * with channels[l] channels at column offset sum(channels[:l]) gets tables + nimg * 2 * sum(channels[:l]) =
+ * (nimg, 2, channels[l]) = [1 + gamma | beta] per image (REPO_EPI_FILM_RELU's aux).  nlayers <= 4; `channels` is a HOST array. */
+int repo_film_tables(int64_t nimg, int nlayers, const int* channels, const float* film, int64_t ldfilm, float* tables,
+                     hipStream_t stream);
+/* repo_film_bwd when the layer ran with REPO_EPI_FILM_RELU and only its OUTPUT h = relu((1 + gamma) y + beta) exists:
+ * y = (h - beta) / (1 + gamma) wherever dh != 0 (there h > 0); a plane whose 1 + gamma is exactly 0 contributes no
+ * gamma gradient.  Relative error of the recovered y: eps * |beta| / |(1 + gamma) y|. */
+int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* h, const float* film,
+                    int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm, hipStream_t stream);
 /* MultitaskRePo's KL balance (repo_mt.py:75-93): the Lagrange multiplier is PER ROW, beta_row = exp(lb_row) with
  * lb_row = tasks[row] . log_beta (tasks (rows, C) one-hot, log_beta (C), C <= 13).  Gradients (nullable) of
  *   scale * sum_rows beta_row * (alpha*KL(sg q||p) + (1-alpha)*KL(q||sg p)),

@@ -315,6 +315,10 @@ __global__ __launch_bounds__(512) void bgemm_kernel(BgArgs p) {
           else if (p.epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
           else if (p.epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(p.aux[(size_t)m * p.ldaux + n]);
           else if (p.epi == REPO_EPI_MUL_DRELU) v = p.aux[(size_t)m * p.ldaux + n] > 0.f ? v : 0.f;
+          else if (p.epi == REPO_EPI_FILM_RELU) {   // row m's FiLM table: [scale (C) | shift (C)], C = ldaux / 2, channel n / bias_div
+            const int ch = p.bias_div == 1 ? n : n / p.bias_div;
+            v = fmaxf(fmaf(p.aux[(size_t)m * p.ldaux + ch], v, p.aux[(size_t)m * p.ldaux + (p.ldaux >> 1) + ch]), 0.f);
+          }
           float* c = p.C + (size_t)m * p.ldc + n;
           if (p.accumulate) v += *c;
           *c = v;

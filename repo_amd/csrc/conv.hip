@@ -550,6 +550,7 @@ static int conv_up_t(int64_t nimg, const float* small, const float* w, const flo
   using BC = typename BUConf<G>::type;
   // the channel-quad mask is what the scatter kernels' drain reads (a pixel's four channels per item)
   if (epi == REPO_EPI_MUL_CMASK && (kUpDirect<G> || std::is_void<UC>::value || G::CB % 4 != 0)) return REPO_E_BADARG;
+  if (epi == REPO_EPI_FILM_RELU && (kUpDirect<G> || std::is_void<UC>::value)) return REPO_E_BADARG;   // the scatter kernels' drains
   if constexpr (!std::is_void<BC>::value)
     if (buconv_on<G>()) return launch_buconv_scatter<G, BC>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   if constexpr (kUpDirect<G>) {
@@ -665,8 +666,9 @@ extern "C" int repo_conv_down(int layer, int64_t nimg, const void* big, int big_
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(big && w && small, REPO_E_BADARG);
   REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU ||
-                   ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_MASK4) && aux_), REPO_E_BADARG);
+                   ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_MASK4 || epi == REPO_EPI_FILM_RELU) && aux_), REPO_E_BADARG);
   REPO_REQUIRE(!relu_cmask || epi == REPO_EPI_RELU, REPO_E_BADARG);
+  REPO_REQUIRE(epi != REPO_EPI_FILM_RELU || !dbias_small, REPO_E_BADARG);
   const float* aux = (const float*)aux_;  // fp32 activations, or the quad mask's bytes (REPO_EPI_MUL_MASK4)
   if (big_is_u8) {
     REPO_REQUIRE(layer == 0 || layer == 7, REPO_E_BADARG);
@@ -712,7 +714,7 @@ extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const f
   if (nimg == 0) return REPO_OK;
   REPO_REQUIRE(small && w && big, REPO_E_BADARG);
   REPO_REQUIRE(epi == REPO_EPI_NONE || epi == REPO_EPI_RELU ||
-                   ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_CMASK) && aux), REPO_E_BADARG);
+                   ((epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_CMASK || epi == REPO_EPI_FILM_RELU) && aux), REPO_E_BADARG);
   REPO_LAYER_SWITCH(layer, return (conv_up_t<G>(nimg, small, w, bias, big, epi, aux, ws_is_packed, ws, ws_bytes, stream)))
 }
 

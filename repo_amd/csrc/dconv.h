@@ -131,7 +131,7 @@ __device__ __forceinline__ void dconv_down_epilogue(const DownArgs& p, float* ld
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) csum[i][q4] = 0.f;
   const __amdgpu_buffer_rsrc_t raux =
-      make_rsrc(p.aux ? p.aux : p.out, (p.epi == REPO_EPI_MUL_MASK4 ? 1u : 4u) * (unsigned)Ntot * G::CS);
+      make_rsrc((p.aux && p.epi != REPO_EPI_FILM_RELU) ? p.aux : p.out, (p.epi == REPO_EPI_MUL_MASK4 ? 1u : 4u) * (unsigned)Ntot * G::CS);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -161,11 +161,17 @@ __device__ __forceinline__ void dconv_down_epilogue(const DownArgs& p, float* ld
 #pragma unroll
               for (int e = 0; e < 4; ++e) a4[e] = (bits >> e) & 1u ? 1.f : 0.f;
             }
+            float fsc = 1.f, fsh = 0.f;   // REPO_EPI_FILM_RELU: this image's (scale, shift) of channel m
+            if (p.epi == REPO_EPI_FILM_RELU) {
+              fsc = p.aux[(size_t)(2 * img) * G::CS + m];
+              fsh = p.aux[(size_t)(2 * img + 1) * G::CS + m];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float x = v[e] + bv;
               if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
               else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_MASK4) x = a4[e] > 0.f ? x : 0.f;
+              else if (p.epi == REPO_EPI_FILM_RELU) x = fmaxf(fmaf(fsc, x, fsh), 0.f);
               v[e] = x;
             }
             qs = (v[0] + v[1]) + (v[2] + v[3]);
@@ -178,6 +184,8 @@ __device__ __forceinline__ void dconv_down_epilogue(const DownArgs& p, float* ld
                 const int oe = ((ne / G::PS) * G::CS + m) * G::PS + ne % G::PS;
                 float x = v[e] + bv;
                 if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
+                else if (p.epi == REPO_EPI_FILM_RELU)
+                  x = fmaxf(fmaf(p.aux[(size_t)(2 * (ne / G::PS)) * G::CS + m], x, p.aux[(size_t)(2 * (ne / G::PS) + 1) * G::CS + m]), 0.f);
                 else if (p.epi == REPO_EPI_MUL_DRELU) x = p.aux[oe] > 0.f ? x : 0.f;
                 else if (p.epi == REPO_EPI_MUL_MASK4)
                   x = (reinterpret_cast<const unsigned char*>(p.aux)[oe >> 2] >> (oe & 3)) & 1 ? x : 0.f;

@@ -54,6 +54,11 @@ struct GemmOp {
         else if (epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
         else if (epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(ax[dm * ldaux]);
         else if (epi == REPO_EPI_MUL_DRELU) v = ax[dm * ldaux] > 0.f ? v : 0.f;
+        else if (epi == REPO_EPI_FILM_RELU) {   // row's FiLM table [scale (C) | shift (C)], C = ldaux / 2 (bgemm.h)
+          const int ch = bias_div == 1 ? n : n / bias_div;
+          const float* tb = aux + (size_t)(mb + dm) * ldaux;
+          v = fmaxf(fmaf(tb[ch], v, tb[(ldaux >> 1) + ch]), 0.f);
+        }
         if (accumulate) v += c[dm * ldc];
         c[dm * ldc] = v;
       }
@@ -96,6 +101,11 @@ struct VGemmOp {
         else if (epi == REPO_EPI_RELU) v = fmaxf(v, 0.f);
         else if (epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(ax[dm * ldaux]);
         else if (epi == REPO_EPI_MUL_DRELU) v = ax[dm * ldaux] > 0.f ? v : 0.f;
+        else if (epi == REPO_EPI_FILM_RELU) {   // row's FiLM table [scale (C) | shift (C)], C = ldaux / 2 (bgemm.h)
+          const int ch = bias_div == 1 ? n : n / bias_div;
+          const float* tb = aux + (size_t)(mb + dm) * ldaux;
+          v = fmaxf(fmaf(tb[ch], v, tb[(ldaux >> 1) + ch]), 0.f);
+        }
         if (accumulate) v += c[dm * ldc];
         c[dm * ldc] = v;
       }
@@ -437,8 +447,10 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
   REPO_REQUIRE(M >= 0 && N >= 0 && K >= 0, REPO_E_SHAPE);
   if (M == 0 || N == 0) return REPO_OK;
   REPO_REQUIRE(A && B && C, REPO_E_BADARG);
-  REPO_REQUIRE(epi >= REPO_EPI_NONE && epi <= REPO_EPI_MUL_DRELU, REPO_E_BADARG);
-  REPO_REQUIRE((epi != REPO_EPI_MUL_DELU && epi != REPO_EPI_MUL_DRELU) || aux, REPO_E_BADARG);
+  REPO_REQUIRE((epi >= REPO_EPI_NONE && epi <= REPO_EPI_MUL_DRELU) || epi == REPO_EPI_FILM_RELU, REPO_E_BADARG);
+  REPO_REQUIRE((epi != REPO_EPI_MUL_DELU && epi != REPO_EPI_MUL_DRELU && epi != REPO_EPI_FILM_RELU) || aux, REPO_E_BADARG);
+  // FiLM: one table row per output row, [scale | shift] over the N / bias_div channels; not on the <= 8-row vector path
+  REPO_REQUIRE(epi != REPO_EPI_FILM_RELU || (M > 8 && !accumulate && ldaux % 2 == 0 && ldaux / 2 >= (N + (bias_div > 0 ? bias_div : 1) - 1) / (bias_div > 0 ? bias_div : 1)), REPO_E_BADARG);
   REPO_REQUIRE(M < kMaxIdx && N < kMaxIdx && K < kMaxIdx && lda < kMaxIdx && ldb < kMaxIdx && ldc < kMaxIdx,
                REPO_E_SHAPE);
   {  // operand offsets are 32-bit inside the kernel

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(long planes, int C, int P
 // dh is the gradient at the ReLU's INPUT (the producer -- a data-gradient kernel with the MUL_DRELU epilogue, or
 // repo_relu_mask -- has applied the mask): dy = dh * (1 + gamma); d gamma[n][c] = sum_p dh * y; d beta[n][c] = sum_p dh.
 // One wave per plane, fixed summation order.  dfilm rows are written (each (n, c) slot is owned by one plane).
+// FROM_H: `y` is the layer's OUTPUT h (the conv ran with REPO_EPI_FILM_RELU): y = (h - beta) / (1 + gamma) where dh != 0.
+template <bool FROM_H>
 __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P, const float* __restrict__ dh,
                                                        const float* __restrict__ y, const float* __restrict__ film,
                                                        int ld, int goff, int boff, float* __restrict__ dy,
@@ -57,13 +59,16 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P
     const long n = pl / C;
     const int c = (int)(pl % C);
     const float g = 1.f + film[n * ld + goff + c];
+    const float bt = FROM_H ? film[n * ld + boff + c] : 0.f;
+    const float rg = (FROM_H && g != 0.f) ? 1.f / g : 0.f;
     const float* d = dh + pl * P;
     const float* src = y + pl * P;
     float* dst = dy + pl * P;
     float sg = 0.f, sb = 0.f;
     for (int p = lane; p < P; p += 64) {
       const float v = d[p];
-      sg = fmaf(v, src[p], sg);
+      const float yy = FROM_H ? (v != 0.f ? (src[p] - bt) * rg : 0.f) : src[p];
+      sg = fmaf(v, yy, sg);
       sb += v;
       dst[p] = v * g;
     }
@@ -73,6 +78,30 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P
       dfilm[n * ld + goff + c] = sg;
       dfilm[n * ld + boff + c] = sb;
     }
+  }
+}
+
+// ------------------------------------------------------------------ FiLM tables (REPO_EPI_FILM_RELU's aux)
+struct FilmTabArgs {
+  int nl, ch[4], off[4], total;   // off[l] = sum ch[:l]
+};
+__global__ __launch_bounds__(256) void film_tables_kernel(long nimg, FilmTabArgs a, const float* __restrict__ film, int ld,
+                                                          float* __restrict__ tab) {
+  const long per = 2L * a.total;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nimg * per; i += (long)gridDim.x * 256) {
+    // flat order of `tab`: [layer][n][2][C_l]
+    long r = i;
+    int l = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (l + 1 < a.nl && r >= nimg * 2L * a.ch[l]) {
+        r -= nimg * 2L * a.ch[l];
+        ++l;
+      }
+    const int C = a.ch[l];
+    const long n = r / (2 * C);
+    const int w = (int)(r % (2 * C)), half = w / C, c = w % C;
+    tab[i] = half ? film[n * ld + a.total + a.off[l] + c] : 1.f + film[n * ld + a.off[l] + c];
   }
 }
 
@@ -209,8 +238,46 @@ extern "C" int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh
   const long planes = nimg * C;
   long blocks = (planes + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(film_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, y,
+  hipLaunchKernelGGL(film_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, y,
                      film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* h, const float* film,
+                               int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm,
+                               hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(film_args_ok(nimg, C, P, ldfilm, gamma_off, beta_off), REPO_E_SHAPE);
+  REPO_REQUIRE(dh && h && film && dy && dfilm, REPO_E_BADARG);
+  const long planes = nimg * C;
+  long blocks = (planes + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(film_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, h,
+                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+extern "C" int repo_film_tables(int64_t nimg, int nlayers, const int* channels, const float* film, int64_t ldfilm,
+                                float* tables, hipStream_t stream) {
+  REPO_ARCH_GUARD();
+  REPO_REQUIRE(nimg > 0 && nlayers >= 1 && nlayers <= 4 && channels, REPO_E_SHAPE);
+  REPO_REQUIRE(film && tables, REPO_E_BADARG);
+  FilmTabArgs a{};
+  a.nl = nlayers;
+  int tot = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    REPO_REQUIRE(channels[l] > 0, REPO_E_SHAPE);
+    a.ch[l] = channels[l];
+    a.off[l] = tot;
+    tot += channels[l];
+  }
+  a.total = tot;
+  REPO_REQUIRE(ldfilm >= 2 * tot && nimg * 2L * tot < kMaxIdx, REPO_E_SHAPE);
+  long blocks = (nimg * 2L * tot + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(film_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long)nimg, a, film, (int)ldfilm, tables);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }

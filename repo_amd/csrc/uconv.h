@@ -292,6 +292,11 @@ __device__ __forceinline__ void uconv_drain(const UScatArgs& p, float* planes, i
 #pragma unroll
           for (int e = 0; e < 4; ++e) msk[u][i][e] = (word >> (8 * e + i)) & 1u ? 1.f : 0.f;
       }
+      if (p.epi == REPO_EPI_FILM_RELU && nv[u] > 0) {   // the item's image and four channels: (scale, shift) in msk[.][0..1]
+        const float* tb = p.aux + (size_t)(2 * (img0 + il)) * G::CB + cb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) msk[u][i] = f32x4acc{tb[i], tb[G::CB + i], 0.f, 0.f};
+      }
       if (p.epi == REPO_EPI_MUL_DRELU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -317,6 +322,7 @@ __device__ __forceinline__ void uconv_drain(const UScatArgs& p, float* planes, i
           float x = w[u][e][i] + bv[i];
           if (p.epi == REPO_EPI_RELU) x = fmaxf(x, 0.f);
           else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_CMASK) x = msk[u][i][e] > 0.f ? x : 0.f;
+          else if (p.epi == REPO_EPI_FILM_RELU) x = fmaxf(fmaf(msk[u][i][0], x, msk[u][i][1]), 0.f);   // (scale, shift)
           t[e] = x;
         }
         const unsigned o = gofs[u] + (unsigned)i * PB;
@@ -374,6 +380,11 @@ __device__ __forceinline__ void uconv_drain1(const UScatArgs& p, float* planes, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) msk[u][i] = p.aux[gofs[u] + (size_t)i * PB];
       }
+      if (p.epi == REPO_EPI_FILM_RELU && act[u]) {   // scales in msk, shifts folded below
+        const float* tb = p.aux + (size_t)(2 * (img0 + il)) * G::CB + cb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) msk[u][i] = tb[i];
+      }
       if (p.epi == REPO_EPI_MUL_CMASK && act[u]) {  // one byte: the item's four channels (64 lanes: 64 contiguous bytes)
         const unsigned b = reinterpret_cast<const unsigned char*>(p.aux)[((size_t)(img0 + il) * (G::CB / 4) + (cb >> 2)) * PB + f];
 #pragma unroll
@@ -388,6 +399,8 @@ __device__ __forceinline__ void uconv_drain1(const UScatArgs& p, float* planes, 
         float t = val[u][i] + bv[i];
         if (p.epi == REPO_EPI_RELU) t = fmaxf(t, 0.f);
         else if (p.epi == REPO_EPI_MUL_DRELU || p.epi == REPO_EPI_MUL_CMASK) t = msk[u][i] > 0.f ? t : 0.f;
+        else if (p.epi == REPO_EPI_FILM_RELU)   // the shift: same image as the scale loaded above
+          t = fmaxf(fmaf(msk[u][i], t, p.aux[(size_t)(2 * (gofs[u] / ((size_t)G::CB * PB)) + 1) * G::CB + cb + i]), 0.f);
         p.out[gofs[u] + (size_t)i * PB] = t;
       }
     }

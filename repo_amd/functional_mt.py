@@ -6,12 +6,16 @@ ConditionalVisualObservationModel.forward (models/decoder.py:111-123):
     gammas, betas = film(condition).chunk(2, dim=1)        # one Linear(C -> 2 * sum(channels))
     h_l = relu((1 + gamma_l) * conv_l(h_{l-1}) + beta_l)   # per (frame, channel); the decoder's conv4 is not modulated
 
-Here a modulated layer is the conv kernel with its BIAS-ONLY epilogue (y_l, saved) followed by repo_film_fwd (h_l,
-saved); backwards the data-gradient kernel of layer l+1 delivers d h_l already masked by ReLU (its MUL_DRELU epilogue
-on h_l), repo_film_bwd turns it into d y_l and the (frame, channel) gradients of gamma / beta, and the conv's weight /
-data gradients consume d y_l.  Parameter lists are the unconditioned stack's (functional.py) followed by
+Round 5: a modulated layer is the conv kernel with the FiLM + ReLU EPILOGUE (REPO_EPI_FILM_RELU: the layer's (frame, channel)
+table [1 + gamma | beta] is read once per output quad; h_l is the only tensor written -- the pre-FiLM y_l is never
+materialised, two streaming passes per layer less than conv + repo_film_fwd); backwards the data-gradient kernel of layer
+l+1 delivers d h_l already masked by ReLU (its MUL_DRELU epilogue on h_l), repo_film_bwd_h turns it into d y_l and the
+(frame, channel) gradients of gamma / beta with y_l recovered from h_l where d h_l != 0, and the conv's weight / data
+gradients consume d y_l.  REPO_FILM_FUSED=0 restores the two-kernel form (y_l saved, repo_film_fwd / repo_film_bwd).  Parameter lists are the unconditioned stack's (functional.py) followed by
 [film.weight, film.bias]; gradients are written in place into `g` (same order).
 """
+import os
+
 import torch
 
 from . import ops
@@ -33,10 +37,21 @@ def _film_grads(dfilm, cond, g_w, g_b, accumulate):
 
 
 # ----------------------------------------------------------------------------- encoder
+def _fused():
+    return os.environ.get("REPO_FILM_FUSED", "1") == "1"
+
+
 def cond_encoder_fwd(p, obs, cond):
     """p = [conv1.w, conv1.b, ..., conv4.w, conv4.b, film.w, film.b]; obs (n,3,64,64) uint8 | float32 in [-1,1];
     cond (n, C).  Returns (embeds (n, 1024), saved)."""
     film = _film(p[8], p[9], cond)
+    if _fused():
+        tabs = ops.film_tables(film, ENC_CHANNELS)
+        x, hs = obs, []
+        for l in range(4):
+            x = ops.conv_down(_ENC_L[l], x, p[2 * l], p[2 * l + 1], epi=ops.EPI_FILM_RELU, aux=tabs[l])
+            hs.append(x)
+        return x.view(x.shape[0], -1), (film, None, hs)
     x, ys, hs = obs, [], []
     for l in range(4):
         y = ops.conv_down(_ENC_L[l], x, p[2 * l], p[2 * l + 1], epi=ops.EPI_NONE)
@@ -54,7 +69,8 @@ def cond_encoder_bwd(p, obs, cond, saved, dembeds, g, accumulate=False, side=Non
     packs = [None] + [ops.conv_up_pack(_ENC_L[l], p[2 * l]) for l in (1, 2, 3)]
     dh = ops.relu_mask(dembeds.reshape(hs[3].shape).contiguous(), hs[3])
     for l in (3, 2, 1, 0):
-        dy = ops.film_bwd(dh, ys[l], film, *_ENC_OFF[l], dfilm)
+        dy = (ops.film_bwd_h(dh, hs[l], film, *_ENC_OFF[l], dfilm) if ys is None
+              else ops.film_bwd(dh, ys[l], film, *_ENC_OFF[l], dfilm))
         below = hs[l - 1] if l > 0 else obs
         fk.run(lambda l=l, dy=dy, below=below: ops.conv_wgrad(_ENC_L[l], dy, below, dw=g[2 * l], db=g[2 * l + 1],
                                                              accumulate=accumulate))
@@ -74,6 +90,12 @@ def _cond_decoder_trunk(p, feat, cond):
     pk2, pk3 = ops.conv_up_pack(ops.DEC2, p[4]), ops.conv_up_pack(ops.DEC3, p[6])
     h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
     w1 = p[2].view(p[2].shape[0], -1)
+    if _fused() and rows > 8:   # (a handful of rows -- the acting path's reconstruction -- takes the vector path: two kernels)
+        tabs = ops.film_tables(film, DEC_CHANNELS)
+        h1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_FILM_RELU, aux=tabs[0].view(rows, -1)).view(rows, 128, 5, 5)
+        h2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_FILM_RELU, aux=tabs[1], pack=pk2)
+        h3 = ops.conv_up(ops.DEC3, h2, p[6], p[7], epi=ops.EPI_FILM_RELU, aux=tabs[2], pack=pk3)
+        return film, h0, None, (h1, h2, h3)
     y1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_NONE).view(rows, 128, 5, 5)
     h1 = ops.film_fwd(y1, film, *_DEC_OFF[0])
     y2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_NONE, pack=pk2)
@@ -101,8 +123,14 @@ def cond_decoder_fwd_nll(p, feat, cond, target, grad_scale):
 def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None):
     """From d recon (saved) to the twelve decoder tensors (into g) and, if dfeat (rows, ld >= D+S) is given (Dreamer's
     attached decoder), to the [belief | state] input (written into its first D+S columns)."""
-    film, h0, (y1, y2, y3), (h1, h2, h3), d4, mask3 = saved
+    film, h0, ys, (h1, h2, h3), d4, mask3 = saved
     rows = feat.shape[0]
+
+    def fbwd(dh, l):   # the FiLM backward of decoder layer l (0 .. 2): from y_l if it was saved, else from h_l
+        if ys is None:
+            return ops.film_bwd_h(dh, (h1, h2, h3)[l], film, *_DEC_OFF[l], dfilm)
+        return ops.film_bwd(dh, ys[l], film, *_DEC_OFF[l], dfilm)
+
     fk = _Fork(side)
     dfilm = torch.empty_like(film)
 
@@ -112,7 +140,7 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
 
     fk.run(w4)
     dh3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_MASK4, aux=mask3)
-    dy3 = ops.film_bwd(dh3, y3, film, *_DEC_OFF[2], dfilm)
+    dy3 = fbwd(dh3, 2)
 
     def w3():
         ops.conv_wgrad(ops.DEC3, h2, dy3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
@@ -120,7 +148,7 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
 
     fk.run(w3)
     dh2 = ops.conv_down(ops.DEC3, dy3, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h2)
-    dy2 = ops.film_bwd(dh2, y2, film, *_DEC_OFF[1], dfilm)
+    dy2 = fbwd(dh2, 1)
 
     def w2():
         ops.conv_wgrad(ops.DEC2, h1, dy2, dw=g[4], db=None, accumulate=accumulate, want_bias=False)
@@ -128,7 +156,7 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
 
     fk.run(w2)
     dh1 = ops.conv_down(ops.DEC2, dy2, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h1)
-    dy1 = ops.film_bwd(dh1, y1, film, *_DEC_OFF[0], dfilm)
+    dy1 = fbwd(dh1, 0)
     d1f = dy1.view(rows, 128 * 25)
     w1 = p[2].view(p[2].shape[0], -1)
 

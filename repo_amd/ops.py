@@ -11,7 +11,7 @@ import torch
 
 from ._lib import check, lib
 
-EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU, EPI_MUL_MASK4, EPI_MUL_CMASK = 0, 1, 2, 3, 4, 5, 6
+EPI_NONE, EPI_ELU, EPI_RELU, EPI_MUL_DELU, EPI_MUL_DRELU, EPI_MUL_MASK4, EPI_MUL_CMASK, EPI_FILM_RELU = 0, 1, 2, 3, 4, 5, 6, 7
 
 # layer ids of repo_conv_* (include/repo_hip.h): 0..6 the reference's 64 x 64 stack, 7..12 the build-defined 128 x 128 one
 ENC1, ENC2, ENC3, ENC4, DEC2, DEC3, DEC4 = range(7)
@@ -791,6 +791,32 @@ def film_fwd(y, film, gamma_off, beta_off, out=None):
     check(lib().repo_film_fwd(n, C, P, _ptr(y), _ptr(film), film.shape[1], gamma_off, beta_off, _ptr(out), _stream()),
           "repo_film_fwd")
     return out
+
+
+def film_tables(film, channels):
+    """The FiLM tables of one conv stack's modulated layers (EPI_FILM_RELU's aux) in one launch: film (n, 2 * sum(channels))
+    -> a list of (n, 2, C_l) tensors [1 + gamma | beta] (views of one buffer)."""
+    n = film.shape[0]
+    assert film.shape[1] >= 2 * sum(channels) and film.is_contiguous() and 1 <= len(channels) <= 4
+    buf = torch.empty(n * 2 * sum(channels), dtype=torch.float32, device=film.device)
+    arr = (ctypes.c_int * len(channels))(*channels)
+    check(lib().repo_film_tables(n, len(channels), arr, _ptr(film), film.shape[1], _ptr(buf), _stream()), "repo_film_tables")
+    out, o = [], 0
+    for c in channels:
+        out.append(buf[o : o + n * 2 * c].view(n, 2, c))
+        o += n * 2 * c
+    return out
+
+
+def film_bwd_h(dh, h, film, gamma_off, beta_off, dfilm, dy=None):
+    """film_bwd for a layer that ran with EPI_FILM_RELU: only its output h exists, y is recovered from it."""
+    n, C = h.shape[:2]
+    P = h.numel() // (n * C)
+    if dy is None:
+        dy = torch.empty_like(h)
+    check(lib().repo_film_bwd_h(n, C, P, _ptr(dh), _ptr(h), _ptr(film), film.shape[1], gamma_off, beta_off, _ptr(dy),
+                                _ptr(dfilm), _stream()), "repo_film_bwd_h")
+    return dy
 
 
 def film_bwd(dh, y, film, gamma_off, beta_off, dfilm, dy=None):

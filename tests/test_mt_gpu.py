@@ -72,6 +72,65 @@ def test_film_fwd_bwd_match_torch(n, C, hw):
     assert bool((dfilm[mask] == 7.0).all())
 
 
+def test_film_epilogue_equals_conv_then_film():
+    """REPO_EPI_FILM_RELU (the FiLM + ReLU epilogue of the conv / dense kernels, repo_film_tables) against the two-kernel form
+    it replaces -- conv with a bias-only epilogue, then repo_film_fwd -- on every modulated layer of both stacks (uint8
+    and float frames for the first), and repo_film_bwd_h (y recovered from the output) against repo_film_bwd on the saved y."""
+    from repo_amd import ops
+    from repo_amd.algorithms.repo.models.conditional import DEC_CHANNELS, ENC_CHANNELS, film_offsets
+
+    rs = np.random.RandomState(11)
+    n = 9
+    f = lambda *s_, sc=1.0: torch.from_numpy((rs.standard_normal(s_) * sc).astype(np.float32)).cuda()  # noqa: E731
+    # ---- encoder
+    film = f(n, 2 * sum(ENC_CHANNELS), sc=0.5)
+    tabs = ops.film_tables(film, ENC_CHANNELS)
+    offs = film_offsets(ENC_CHANNELS)
+    for l, (g, b) in enumerate(offs):
+        C = ENC_CHANNELS[l]
+        assert torch.equal(tabs[l][:, 0], 1 + film[:, g : g + C]) and torch.equal(tabs[l][:, 1], film[:, b : b + C])
+    layers = (ops.ENC1, ops.ENC2, ops.ENC3, ops.ENC4)
+    x8 = torch.from_numpy(rs.randint(0, 256, (n, 3, 64, 64)).astype(np.uint8)).cuda()
+    for first in (x8, ((x8.float() / 255) * 2) - 1):
+        x = first
+        for l, layer in enumerate(layers):
+            (cb, hb, _), (cs, hs_, _) = ops.conv_shapes(layer)
+            w, bias = f(cs, cb, 4, 4, sc=0.1), f(cs)
+            y = ops.conv_down(layer, x, w, bias, epi=ops.EPI_NONE)
+            want = ops.film_fwd(y, film, *offs[l])
+            got = ops.conv_down(layer, x, w, bias, epi=ops.EPI_FILM_RELU, aux=tabs[l])
+            assert relerr(got, want) < 2e-6, (l, float(relerr(got, want)))
+            assert float((got == 0).float().mean()) > 0.2          # the ReLU is live
+            dh = ops.relu_mask(f(*want.shape), want)
+            dfa, dfb = torch.zeros_like(film), torch.zeros_like(film)
+            dya = ops.film_bwd(dh, y, film, *offs[l], dfa)
+            dyb = ops.film_bwd_h(dh, want, film, *offs[l], dfb)
+            assert torch.equal(dya, dyb)
+            g, b = offs[l]
+            assert relerr(dfb[:, g : g + cs], dfa[:, g : g + cs]) < 2e-5 and torch.equal(dfb[:, b : b + cs], dfa[:, b : b + cs])
+            x = want
+    # ---- decoder: the 1024 -> 128 x 5 x 5 layer as a dense product, then the two scatter-kernel layers
+    film = f(n * 40, 2 * sum(DEC_CHANNELS), sc=0.5)
+    rows = film.shape[0]
+    tabs = ops.film_tables(film, DEC_CHANNELS)
+    offs = film_offsets(DEC_CHANNELS)
+    h0, w1, b1 = f(rows, 1024, sc=0.3), f(1024, 3200, sc=0.05), f(128)
+    y1 = ops.gemm(h0, w1, bias=b1, bias_div=25).view(rows, 128, 5, 5)
+    want = ops.film_fwd(y1, film, *offs[0])
+    got = ops.gemm(h0, w1, bias=b1, bias_div=25, epi=ops.EPI_FILM_RELU, aux=tabs[0].view(rows, -1)).view(rows, 128, 5, 5)
+    assert relerr(got, want) < 2e-6
+    x = want
+    for l, layer in ((1, ops.DEC2), (2, ops.DEC3)):
+        (cb, hb, _), (cs, hs_, _) = ops.conv_shapes(layer)
+        ks = ops.CONV_GEO[layer][3]
+        w, bias = f(cs, cb, ks, ks, sc=0.1), f(cb)
+        y = ops.conv_up(layer, x, w, bias, epi=ops.EPI_NONE)
+        want = ops.film_fwd(y, film, *offs[l])
+        got = ops.conv_up(layer, x, w, bias, epi=ops.EPI_FILM_RELU, aux=tabs[l])
+        assert relerr(got, want) < 2e-6, (layer, float(relerr(got, want)))
+        x = want
+
+
 @pytest.mark.parametrize("rows,C", [(1, 1), (37, 3), (2450, 3), (500, 13)])
 def test_kl_balance_tasks_and_dual_step_match_torch(rows, C):
     """repo_kl_balance_tasks + repo_dual_step_tasks against repo_mt.py:75-99 written with autograd + torch.optim.Adam."""
