@@ -30,6 +30,8 @@ pairs = [
     ("r05_gemm_isolated.txt", "r05_gemm_isolated.txt"),
     ("r05_rollout_engines.txt", "r05_rollout_engines.txt"),
     ("r05_ab_vs_round4.txt", "r05_ab_vs_round4.txt"),
+    ("r05_gpu_tests.txt", "r05_gpu_tests.txt"),
+    ("r05_smoke.txt", "r05_smoke.txt"),
 ]
 for src, dst in pairs:
     s = os.path.join(G, src)
