@@ -811,7 +811,12 @@ def test_one_rank_rccl_group_is_bit_identical_to_no_dp_over_many_updates():
     from repo_amd.parallel import DataParallel
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:   # a free port of this box, not a fixed one another process may hold
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     L, B, H, A, n_updates = 50, 7, 15, 6, 120     # one rank's shard of the strong-scaling job at 8 GPUs
     created = not dist.is_initialized()
