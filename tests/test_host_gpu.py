@@ -417,6 +417,71 @@ def test_data_parallel_two_shards_equal_full_batch():
     assert abs(float(agents[0].log_beta) - float(full.log_beta)) < 1e-6
 
 
+def test_data_parallel_rank_local_scan_fault_skips_and_raises_on_every_rank():
+    """VERDICT r4 #5b on the GPU: two row shards ("ranks" in host threads behind ThreadDP), the scans of ONE of them time
+    out (the debug spin limit is thread-local: only that rank's launches carry 0).  The update's status copy is MAX-reduced
+    before the first optimiser step, so BOTH ranks skip every step -- parameters, moments and log_beta bit-unchanged on both,
+    although the faulted rank's NaN gradients were summed into both -- and BOTH raise RepoHipError from the same update;
+    the next (clean) update runs on both and the replicas stay identical."""
+    import threading
+    from fractions import Fraction
+
+    from repo_amd import ops
+    from repo_amd._lib import RepoHipError, lib
+    from repo_amd.parallel import shard_rows
+
+    L, B, H, A, world = 6, 6, 4, 6, 2
+    ops.scan_status(torch.device("cuda", 0)).zero_()
+    batch, _ = dev_batch(L, B, A, 31)
+    bounds = [shard_rows(B, world, r) for r in range(world)]
+    shared = {"slot": [None] * world, "barrier": threading.Barrier(world)}
+    agents, before, raised, errs, finite = [None] * world, [None] * world, [None] * world, [], [None] * world
+    for r, (lo, hi) in enumerate(bounds):
+        torch.manual_seed(5)
+        agents[r], _ = make_agent("repo", L, hi - lo, H, A)
+        agents[r].dp = ThreadDP(r, world, shared, Fraction(B, hi - lo))
+        agents[r].seed_noise(77 + r)
+
+    def state(ag):
+        return [t.clone() for o in (ag.model_optimizer, ag.actor_optimizer, ag.value_optimizer)
+                for t in (o.flat, o.exp_avg, o.exp_avg_sq)] + [ag.log_beta.clone()]
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = bounds[r]
+            shard = tuple(x[:, lo:hi].contiguous() for x in batch)
+            before[r] = state(agents[r])
+            if r == 1:
+                lib().repo_debug_scan_spin_limit(0)     # this thread's launches only
+            try:
+                agents[r].update(shard)
+            finally:
+                lib().repo_debug_scan_spin_limit(-1)
+            try:
+                agents[r].last_scalars
+                raised[r] = False
+            except RepoHipError:
+                raised[r] = True
+            same = all(torch.equal(a, b) for a, b in zip(before[r], state(agents[r])))
+            agents[r].update(shard)                      # a clean update: both ranks step
+            finite[r] = (same, all(v == v for v in agents[r].last_scalars.values()))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            shared["barrier"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs, errs
+    assert raised == [True, True], raised                # the clean rank raised too
+    assert finite == [(True, True), (True, True)], finite  # nothing was written by the faulted update; the next one is finite
+    for a, b in zip(state(agents[0]), state(agents[1])):
+        assert torch.equal(a, b)                         # replicas identical after the clean update
+
+
 def test_bucketed_model_exchange_equals_single_bucket():
     """The model gradient leaves as two buckets -- decoder + reward head (begun when the decoder backward joins),
     then encoder + RSSM -- and actor + critic as one: parameters after the update are bit-identical to the
