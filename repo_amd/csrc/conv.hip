@@ -28,6 +28,7 @@
 #include "buconv.h"
 #include "bwgrad.h"
 #include "bdec4.h"
+#include "twgrad.h"
 
 
 namespace repo {
@@ -254,7 +255,9 @@ __global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, int spli
 // each: 70-80 us inside the update for 3.8 MB of slabs.)
 __global__ __launch_bounds__(1024) void conv_slab_reduce_wave_kernel(const float* __restrict__ slab, int splits, int Mrows,
                                                                      int Ncols, float* __restrict__ dw,
-                                                                     float* __restrict__ db, int accumulate) {
+                                                                     float* __restrict__ db, int accumulate, int tkk,
+                                                                     int tcb) {
+  // tkk > 0: the slabs are twgrad.h's [tap][row][channel] (+ db[row] at the end) instead of [row][channel * tkk + tap | db]
   __shared__ float red[16][64];
   const int total = Mrows * (Ncols + 1);
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -276,7 +279,12 @@ __global__ __launch_bounds__(1024) void conv_slab_reduce_wave_kernel(const float
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += red[q][o];
-    const int m = i / (Ncols + 1), n = i % (Ncols + 1);
+    int m = i / (Ncols + 1), n = i % (Ncols + 1);
+    if (tkk > 0) {
+      const int body = Mrows * Ncols;
+      if (i < body) m = (i / tcb) % Mrows, n = (i % tcb) * tkk + i / (tcb * Mrows);
+      else m = i - body, n = Ncols;
+    }
     if (n < Ncols) {
       float* p = dw + (size_t)m * Ncols + n;
       *p = accumulate ? *p + s : s;
@@ -594,7 +602,7 @@ static void launch_conv_slab_reduce(const float* ws, int splits, int cs, int nw,
   const int total = cs * (nw + 1);
   if (splits >= 64 && total <= 65536) {
     hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(total, 64)), dim3(1024), 0, s, ws, splits, cs, nw, dw, db,
-                       accumulate);
+                       accumulate, 0, 0);
   } else {
     const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
     hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, splits, cs, nw, dw, db, accumulate);
@@ -612,15 +620,45 @@ template <> struct BWgradFor<GEnc3> { using type = WTile<64, 256, 1, 4, 1, 6>; }
 // elements) is not hidden behind 12 MFMAs
 template <class G> constexpr bool kBWgrad = !std::is_same<typename BWgradFor<G>::type, NoBTile>::value;
 
+// twgrad.h (both operands split at staging, `big` read through the LDS's transposing load): k-blocks per chunk, 0 = not
+// on this engine.  One workgroup owns the whole dw of its images: images per split = ceil(nimg / 256), one slab each.
+template <class G> constexpr int kTWgradNBK = 0;
+template <> constexpr int kTWgradNBK<GDec3> = 4;
+template <> constexpr int kTWgradNBK<GEnc2> = 4;
+static int twgrad_ips(int64_t nimg) { return (int)((nimg + 255) / 256); }
+static int twgrad_splits(int64_t nimg) { return (int)((nimg + twgrad_ips(nimg) - 1) / twgrad_ips(nimg)); }
+
+template <class G>
+static size_t wgrad_ws_total(int64_t nimg) {   // the larger of the engines' slab sets (the engine is a thread-local switch)
+  size_t b = wgrad_ws_bytes<G>(nimg);
+  if constexpr (kTWgradNBK<G> > 0) {
+    const size_t t = (size_t)twgrad_splits(nimg) * G::CS * (G::CB * G::KK + 1) * sizeof(float);
+    if (t > b) b = t;
+  }
+  return b;
+}
+
 template <class G, class BigT>
 static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float* dw, float* db, int accumulate,
                         void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
-  if (!ws || ws_bytes < wgrad_ws_bytes<G>(nimg)) return REPO_E_WS_TOO_SMALL;
+  if (!ws || ws_bytes < wgrad_ws_total<G>(nimg)) return REPO_E_WS_TOO_SMALL;
   const int dips = dwgrad_ips<G>(nimg), dsplits = dwgrad_splits<G>(nimg);
   WgradArgs a{small, big, (float*)ws, (int)nimg, dips, db != nullptr,
               (unsigned)(nimg * G::CS * G::PS * sizeof(float)), (unsigned)(nimg * G::CB * G::PB * sizeof(BigT))};
   int rc;
+  if constexpr (kTWgradNBK<G> > 0 && std::is_same<BigT, float>::value) {
+    if (t_bconv_enabled) {
+      const int tsplits = twgrad_splits(nimg);
+      a.imgs_per_split = twgrad_ips(nimg);
+      rc = launch_tconv_wgrad<G, kTWgradNBK<G>>(a, tsplits, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(G::CS * (G::CB * G::KK + 1), 64)), dim3(1024), 0, s,
+                         (const float*)ws, tsplits, G::CS, G::CB * G::KK, dw, db, accumulate, G::KK, G::CB);
+      REPO_CHECK_LAUNCH();
+      return REPO_OK;
+    }
+  }
   if constexpr (kBWgrad<G> && std::is_same<BigT, float>::value) {
     static_assert(DTileFor<G>::Wgrad::GI % BWgradFor<G>::type::GI == 0, "images per split: a multiple of both kernels' chunks");
     if (t_bconv_enabled) rc = launch_bconv_wgrad<G, typename BWgradFor<G>::type>(a, dsplits, s);
@@ -720,7 +758,7 @@ extern "C" int repo_conv_up(int layer, int64_t nimg, const float* small, const f
 
 extern "C" size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg) {
   if (nimg <= 0) return 0;
-  REPO_LAYER_SWITCH(layer, return (wgrad_ws_bytes<G>(nimg)))
+  REPO_LAYER_SWITCH(layer, return (wgrad_ws_total<G>(nimg)))
 }
 
 extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big, int big_is_u8,

@@ -237,7 +237,7 @@ def test_conv_up(ops, layer, nimg):
 
 
 @pytest.mark.parametrize("layer,kind", [(5, "down"), (1, "down"), (2, "down"), (3, "down"), (4, "down"), (5, "up"), (1, "up"), (2, "up"),
-                                        (3, "up"), (4, "up"), (5, "wgrad"), (2, "wgrad")])
+                                        (3, "up"), (4, "up"), (5, "wgrad"), (2, "wgrad"), (1, "wgrad")])
 def test_bf16x6_conv_kernels_match_fp64_and_the_fp32_kernels(ops, layer, kind):
     """The bf16x6 conv kernels (csrc/bconv.h: decoder conv3 / conv2 data gradients, encoder conv2 / conv3 / conv4 forward;
     csrc/buconv.h: decoder conv3 / conv2 forward, encoder conv2 / conv3 / conv4 data gradients; csrc/bwgrad.h: decoder conv3
