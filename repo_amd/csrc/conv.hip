@@ -621,11 +621,17 @@ template <> struct BWgradFor<GEnc3> { using type = WTile<64, 256, 1, 4, 1, 6>; }
 template <class G> constexpr bool kBWgrad = !std::is_same<typename BWgradFor<G>::type, NoBTile>::value;
 
 // twgrad.h (both operands split at staging, `big` read through the LDS's transposing load): k-blocks per chunk, 0 = not
-// on this engine.  One workgroup owns the whole dw of its images: images per split = ceil(nimg / 256), one slab each.
+// on this engine.  A PAIR of workgroups (the two row parities of the taps) owns the whole dw of its images: images per
+// split = ceil(nimg / 128), one slab per pair.
 template <class G> constexpr int kTWgradNBK = 0;
-template <> constexpr int kTWgradNBK<GDec3> = 4;
-template <> constexpr int kTWgradNBK<GEnc2> = 4;
-static int twgrad_ips(int64_t nimg) { return (int)((nimg + 255) / 256); }
+#ifndef TW_DISABLE   // A/B builds (tools/build_variant.sh): the previous engines
+template <> constexpr int kTWgradNBK<GDec3> = 2;
+template <> constexpr int kTWgradNBK<GEnc2> = 2;
+#endif
+// staging waves: 8 where the multiplying waves (4 taps: 64 accumulator registers) fit three waves per SIMD
+template <class G> constexpr int kTWgradNPW = 4;
+template <> constexpr int kTWgradNPW<GEnc2> = 8;
+static int twgrad_ips(int64_t nimg) { return (int)((nimg + 127) / 128); }
 static int twgrad_splits(int64_t nimg) { return (int)((nimg + twgrad_ips(nimg) - 1) / twgrad_ips(nimg)); }
 
 template <class G>
@@ -651,7 +657,7 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
     if (t_bconv_enabled) {
       const int tsplits = twgrad_splits(nimg);
       a.imgs_per_split = twgrad_ips(nimg);
-      rc = launch_tconv_wgrad<G, kTWgradNBK<G>>(a, tsplits, s);
+      rc = launch_tconv_wgrad<G, kTWgradNBK<G>, kTWgradNPW<G>>(a, tsplits, s);
       if (rc) return rc;
       hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(G::CS * (G::CB * G::KK + 1), 64)), dim3(1024), 0, s,
                          (const float*)ws, tsplits, G::CS, G::CB * G::KK, dw, db, accumulate, G::KK, G::CB);

@@ -440,6 +440,7 @@ struct WgradArgs {
   float* slab;
   int nimg, imgs_per_split, want_db;
   unsigned small_bytes, big_bytes;
+  int nsplits_tw = 0;   // twgrad.h: splits (its grid is padded to whole XCD rounds)
 };
 
 // SPREAD: 0 = the next chunk's global loads are issued back to back in front of the MFMA loop; n > 0 = one at a
