@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void tconv_wgrad_kernel(WgradArgs p
       constexpr int j = decltype(jc)::value, S = decltype(sc)::value;
       constexpr int k0 = KC * j, s0 = TG::sy0(j), NI = TG::nrows(j);
       const unsigned dead_img = img < img_end ? 0u : ~0u;
-      const int t_ = otid() - 256;
+      const int t_ = (TPW <= 4 ? tid : otid()) - 256;   // k4: registers to spare, the lane constants may be hoisted (enc2 215 -> 199 us; dec3 309 -> 350)
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) {
         const int a_e4 = (t_ + NP * i) % AQ, a_cs = (t_ + NP * i) / AQ;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void tconv_wgrad_kernel(WgradArgs p
     auto lstore = [&](auto jc, auto sc, char* Bl, char* Al) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value, S = decltype(sc)::value;
       constexpr int k0 = KC * j, NI = TG::nrows(j);
-      const int t_ = otid() - 256;
+      const int t_ = (TPW <= 4 ? tid : otid()) - 256;   // k4: registers to spare, the lane constants may be hoisted (enc2 215 -> 199 us; dec3 309 -> 350)
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) {
         const int a_e4 = (t_ + NP * i) % AQ, a_cs = (t_ + NP * i) / AQ;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void tconv_wgrad_kernel(WgradArgs p
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = e < R ? rav[S][i][(4 - R + e) & 3] : 0.f;
         }
-        dbs[i] += (x[0] + x[1]) + (x[2] + x[3]);
+        if (p.want_db) dbs[i] += (x[0] + x[1]) + (x[2] + x[3]);
         unsigned a1, a2, a3, b1, b2, b3;
         tw_split3(x[0], x[1], a1, a2, a3);
         tw_split3(x[2], x[3], b1, b2, b3);
