@@ -33,7 +33,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define REPO_ABI_VERSION 6
+#define REPO_ABI_VERSION 7
 
 #define REPO_OK 0
 #define REPO_E_BADARG (-1)
@@ -179,10 +179,13 @@ int repo_conv_up_pack(int layer, const float* w, void* ws, size_t ws_bytes, hipS
 int repo_conv_up(int layer, int64_t nimg, const float* small, const float* w, const float* bias,
                  float* big, int epi, const float* aux, int ws_is_packed, void* ws, size_t ws_bytes,
                  hipStream_t stream);
-/* dw (+)= ..., dbias_small[small_ch] (+)= sum over images and pixels of `small` (NULL to skip). */
+/* dw (+)= ..., dbias_small[small_ch] (+)= sum over images and pixels of `small` (NULL to skip); dbias_big[big_ch] (+)=
+ * the same of `big` (NULL to skip; f32 `big` only) -- the bias gradient of a transposed conv, whose output gradient is
+ * the `big` operand here (models/decoder.py:43-47).  Where the weight-gradient engine stages every element of `big`
+ * exactly once (decoder conv3) the sums ride along; elsewhere they are the channel-sum pass of repo_channel_sum. */
 size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg);
 int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big, int big_is_u8,
-                    float* dw, float* dbias_small, int accumulate, void* ws, size_t ws_bytes,
+                    float* dw, float* dbias_small, float* dbias_big, int accumulate, void* ws, size_t ws_bytes,
                     hipStream_t stream);
 
 /* ------------------------------------------------------------------ replay batch gather (HOST memory, no GPU work)

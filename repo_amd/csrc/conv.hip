@@ -256,10 +256,11 @@ __global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, int spli
 __global__ __launch_bounds__(1024) void conv_slab_reduce_wave_kernel(const float* __restrict__ slab, int splits, int Mrows,
                                                                      int Ncols, float* __restrict__ dw,
                                                                      float* __restrict__ db, int accumulate, int tkk,
-                                                                     int tcb) {
+                                                                     int tcb, float* __restrict__ dbig) {
   // tkk > 0: the slabs are twgrad.h's [tap][row][channel] (+ db[row] at the end) instead of [row][channel * tkk + tap | db]
+  // and, behind them, the two row-parity halves of the channel sums of `big` (2 x tcb: one aligned block of 64 outputs)
   __shared__ float red[16][64];
-  const int total = Mrows * (Ncols + 1);
+  const int total = Mrows * (Ncols + 1) + (tkk > 0 ? 2 * tcb : 0);
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -282,6 +283,16 @@ __global__ __launch_bounds__(1024) void conv_slab_reduce_wave_kernel(const float
     int m = i / (Ncols + 1), n = i % (Ncols + 1);
     if (tkk > 0) {
       const int body = Mrows * Ncols;
+      if (i >= body + Mrows) {   // channel sums of `big`: output c = half 0 + half 1 (both in this block's `red`)
+        const int c = i - body - Mrows;
+        if (dbig && c < tcb) {
+          float s2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) s2 += red[q][o + tcb];
+          dbig[c] = accumulate ? dbig[c] + (s + s2) : s + s2;
+        }
+        return;
+      }
       if (i < body) m = (i / tcb) % Mrows, n = (i % tcb) * tkk + i / (tcb * Mrows);
       else m = i - body, n = Ncols;
     }
@@ -602,7 +613,7 @@ static void launch_conv_slab_reduce(const float* ws, int splits, int cs, int nw,
   const int total = cs * (nw + 1);
   if (splits >= 64 && total <= 65536) {
     hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(total, 64)), dim3(1024), 0, s, ws, splits, cs, nw, dw, db,
-                       accumulate, 0, 0);
+                       accumulate, 0, 0, (float*)nullptr);
   } else {
     const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
     hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, splits, cs, nw, dw, db, accumulate);
@@ -634,19 +645,47 @@ template <> constexpr int kTWgradNPW<GEnc2> = 8;
 static int twgrad_ips(int64_t nimg) { return (int)((nimg + 127) / 128); }
 static int twgrad_splits(int64_t nimg) { return (int)((nimg + twgrad_ips(nimg) - 1) / twgrad_ips(nimg)); }
 
+static inline int chansum_splits(int64_t nimg, int64_t C, int64_t P) {
+  long want = (4096 + C - 1) / C;
+  long min_imgs = (8192 + P - 1) / P;
+  long maxs = (nimg + min_imgs - 1) / min_imgs;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  long ips = (nimg + want - 1) / want;
+  return (int)((nimg + ips - 1) / ips);
+}
+static int channel_sum_launch(int64_t nimg, int64_t C, int64_t P, const float* x, float* out, int accumulate, float* ws,
+                              hipStream_t stream) {
+  const int splits = chansum_splits(nimg, C, P);
+  const int ips = (int)((nimg + splits - 1) / splits);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C, (unsigned)splits), dim3(256), 0, stream, x, (int)nimg, (int)C,
+                     (int)P, ips, ws);
+  REPO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, splits, (int)C,
+                     out, accumulate);
+  REPO_CHECK_LAUNCH();
+  return REPO_OK;
+}
+
+// slabs of the weight gradient (the larger of the engines' sets: the engine is a thread-local switch), then the channel
+// sums' partials for dbias_big where the engine does not produce them
 template <class G>
-static size_t wgrad_ws_total(int64_t nimg) {   // the larger of the engines' slab sets (the engine is a thread-local switch)
+static size_t wgrad_ws_slabs(int64_t nimg) {
   size_t b = wgrad_ws_bytes<G>(nimg);
   if constexpr (kTWgradNBK<G> > 0) {
-    const size_t t = (size_t)twgrad_splits(nimg) * G::CS * (G::CB * G::KK + 1) * sizeof(float);
+    const size_t t = (size_t)twgrad_splits(nimg) * TWGeo<G, kTWgradNBK<G>, kTWgradNPW<G>>::SLAB * sizeof(float);
     if (t > b) b = t;
   }
-  return b;
+  return (b + 255) & ~(size_t)255;
+}
+template <class G>
+static size_t wgrad_ws_total(int64_t nimg) {
+  return wgrad_ws_slabs<G>(nimg) + (size_t)chansum_splits(nimg, G::CB, G::PB) * G::CB * sizeof(float);
 }
 
 template <class G, class BigT>
-static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float* dw, float* db, int accumulate,
-                        void* ws, size_t ws_bytes, hipStream_t s) {
+static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float* dw, float* db, float* dbig,
+                        int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   if (nimg * (int64_t)G::CB * G::PB >= kMaxBufElems || nimg * (int64_t)G::CS * G::PS >= kMaxBufElems) return REPO_E_SHAPE;
   if (!ws || ws_bytes < wgrad_ws_total<G>(nimg)) return REPO_E_WS_TOO_SMALL;
   const int dips = dwgrad_ips<G>(nimg), dsplits = dwgrad_splits<G>(nimg);
@@ -655,13 +694,20 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
   int rc;
   if constexpr (kTWgradNBK<G> > 0 && std::is_same<BigT, float>::value) {
     if (t_bconv_enabled) {
+      using TG = TWGeo<G, kTWgradNBK<G>, kTWgradNPW<G>>;
       const int tsplits = twgrad_splits(nimg);
       a.imgs_per_split = twgrad_ips(nimg);
+      // where the taps reach every row and column of `big` (decoder conv3; not the 31 x 31 planes of encoder conv2, whose
+      // last row and column no window touches) every element is staged exactly once and its channel sums ride along
+      constexpr bool covers = G::HB == 2 * (G::HS - 1) + G::KS;
+      a.want_dbig = covers && dbig != nullptr;
       rc = launch_tconv_wgrad<G, kTWgradNBK<G>, kTWgradNPW<G>>(a, tsplits, s);
       if (rc) return rc;
-      hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(G::CS * (G::CB * G::KK + 1), 64)), dim3(1024), 0, s,
-                         (const float*)ws, tsplits, G::CS, G::CB * G::KK, dw, db, accumulate, G::KK, G::CB);
+      hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(TG::SLAB, 64)), dim3(1024), 0, s, (const float*)ws, tsplits,
+                         G::CS, G::CB * G::KK, dw, db, accumulate, G::KK, G::CB, covers ? dbig : nullptr);
       REPO_CHECK_LAUNCH();
+      if (!covers && dbig)
+        return channel_sum_launch(nimg, G::CB, G::PB, big, dbig, accumulate, (float*)((char*)ws + wgrad_ws_slabs<G>(nimg)), s);
       return REPO_OK;
     }
   }
@@ -675,6 +721,12 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
   if (rc) return rc;
   launch_conv_slab_reduce((const float*)ws, dsplits, G::CS, G::CB * G::KK, dw, db, accumulate, s);
   REPO_CHECK_LAUNCH();
+  if (dbig) {
+    if constexpr (std::is_same<BigT, float>::value)
+      return channel_sum_launch(nimg, G::CB, G::PB, big, dbig, accumulate, (float*)((char*)ws + wgrad_ws_slabs<G>(nimg)), s);
+    else
+      return REPO_E_BADARG;
+  }
   return REPO_OK;
 }
 
@@ -768,20 +820,20 @@ extern "C" size_t repo_conv_wgrad_workspace_bytes(int layer, int64_t nimg) {
 }
 
 extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, const void* big, int big_is_u8,
-                               float* dw, float* dbias_small, int accumulate, void* ws, size_t ws_bytes,
-                               hipStream_t stream) {
+                               float* dw, float* dbias_small, float* dbias_big, int accumulate, void* ws,
+                               size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
   REPO_REQUIRE(small && big && dw, REPO_E_BADARG);
   if (big_is_u8) {
-    REPO_REQUIRE(layer == 0 || layer == 7, REPO_E_BADARG);
+    REPO_REQUIRE((layer == 0 || layer == 7) && !dbias_big, REPO_E_BADARG);
     if (layer == 7)
-      return conv_wgrad_t<GX1, uint8_t>(nimg, small, (const uint8_t*)big, dw, dbias_small, accumulate, ws, ws_bytes,
-                                        stream);
-    return conv_wgrad_t<GEnc1, uint8_t>(nimg, small, (const uint8_t*)big, dw, dbias_small, accumulate, ws, ws_bytes,
-                                        stream);
+      return conv_wgrad_t<GX1, uint8_t>(nimg, small, (const uint8_t*)big, dw, dbias_small, nullptr, accumulate, ws,
+                                        ws_bytes, stream);
+    return conv_wgrad_t<GEnc1, uint8_t>(nimg, small, (const uint8_t*)big, dw, dbias_small, nullptr, accumulate, ws,
+                                        ws_bytes, stream);
   }
-  REPO_LAYER_SWITCH(layer, return (conv_wgrad_t<G, float>(nimg, small, (const float*)big, dw, dbias_small,
+  REPO_LAYER_SWITCH(layer, return (conv_wgrad_t<G, float>(nimg, small, (const float*)big, dw, dbias_small, dbias_big,
                                                           accumulate, ws, ws_bytes, stream)))
 }
 
@@ -876,16 +928,6 @@ extern "C" int repo_conv_up_nll(int layer, int64_t nimg, const float* small, con
 #undef REPO_UPNLL
 }
 
-static inline int chansum_splits(int64_t nimg, int64_t C, int64_t P) {
-  long want = (4096 + C - 1) / C;
-  long min_imgs = (8192 + P - 1) / P;
-  long maxs = (nimg + min_imgs - 1) / min_imgs;
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
-  long ips = (nimg + want - 1) / want;
-  return (int)((nimg + ips - 1) / ips);
-}
-
 extern "C" size_t repo_channel_sum_workspace_bytes(int64_t nimg, int64_t C, int64_t P) {
   if (nimg <= 0 || C <= 0 || P <= 0) return 0;
   return (size_t)chansum_splits(nimg, C, P) * C * sizeof(float);
@@ -899,14 +941,7 @@ extern "C" int repo_channel_sum(int64_t nimg, int64_t C, int64_t P, const float*
   REPO_REQUIRE(C <= 65535, REPO_E_SHAPE);
   const int splits = chansum_splits(nimg, C, P);
   REPO_REQUIRE(ws && ws_bytes >= (size_t)splits * C * sizeof(float), REPO_E_WS_TOO_SMALL);
-  const int ips = (int)((nimg + splits - 1) / splits);
-  hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C, (unsigned)splits), dim3(256), 0, stream, x, (int)nimg, (int)C,
-                     (int)P, ips, (float*)ws);
-  REPO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, splits,
-                     (int)C, out, accumulate);
-  REPO_CHECK_LAUNCH();
-  return REPO_OK;
+  return channel_sum_launch(nimg, C, P, x, out, accumulate, (float*)ws, stream);
 }
 
 extern "C" int repo_relu_mask(int64_t n, const float* dy, const float* h, float* y, hipStream_t stream) {

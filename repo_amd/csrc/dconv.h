@@ -441,6 +441,7 @@ struct WgradArgs {
   int nimg, imgs_per_split, want_db;
   unsigned small_bytes, big_bytes;
   int nsplits_tw = 0;   // twgrad.h: splits (its grid is padded to whole XCD rounds)
+  int want_dbig = 0;    // twgrad.h: also the channel sums of `big`
 };
 
 // SPREAD: 0 = the next chunk's global loads are issued back to back in front of the MFMA loop; n > 0 = one at a

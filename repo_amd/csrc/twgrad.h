@@ -86,7 +86,10 @@ struct TWGeo {
   static_assert(A_NV % NP == 0, "every staging thread has its A items");
   static constexpr int QPR = (G::WB + 3) / 4;          // pixel quads per row (the last one ends WITH the row)
   static constexpr int B_NV = 8 * QPR * NIMAX, B_PER = (B_NV + NP - 1) / NP;
-  static constexpr int SLAB = G::CS * (G::CB * G::KK + 1);   // floats per split: [tap][cs][cb], then db[cs]
+  // floats per split: [tap][cs][cb], db[cs], then the two row-parity halves of the channel sums of `big`
+  static constexpr int SLAB = G::CS * (G::CB * G::KK + 1) + 2 * G::CB;
+  // rows of chunk j that chunk j - 1 has not staged: every element of `big` is counted once
+  static constexpr int own_from(int j) { return j == 0 ? 0 : cmax(0, sy0(j - 1) + nrows(j - 1) - sy0(j)); }
 };
 
 template <class G, int NBK, int NPW>
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void tconv_wgrad_kernel(WgradArgs p
       if constexpr (NCH > 6) body(std::integral_constant<int, 6>{});
       static_assert(NCH <= 7, "chunks per image");
     }
+    if (p.want_dbig) lds_barrier();   // the staging waves' channel sums meet in LDS
     // ---- slab[z][tap][cs][cb]: lane & 15 = channel of the wave's 16, accumulator register r = row 4 (lane >> 4) + r of
     // the 16 of its row tile
     const int lane = tid & 63;
@@ -229,6 +233,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void tconv_wgrad_kernel(WgradArgs p
     float dbs[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) dbs[i] = 0.f;
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f};   // want_dbig: this thread's channel quad (tid & 7), over the pixels it stages FIRST
     // A item i: v = ptid + 256 i -> (cs = v / AQ, quad of k = v % AQ); B item i: v -> (channel quad v % 8, pixel quad
     // (v / 8) % QPR of staged row v / (8 QPR))
     // two register sets: a chunk's loads are issued two barriers before its split
@@ -295,6 +300,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void tconv_wgrad_kernel(WgradArgs p
         const int cq = v & 7, q = (v >> 3) % QPR, ri = (v >> 3) / QPR;
         if (ri < NI) {
           const int x0 = min(4 * q, G::WB - 4);
+          if (p.want_dbig && ri >= TG::own_from(j)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dsum[c] += (x0 + e >= 4 * q) ? rbv[S][i][c][e] : 0.f;   // the row's last quad overlaps its neighbour
+          }
           // pixel x0 + e: column parity and x/2 -- immediates when every quad starts on an even column.  XH is odd: the
           // two channel blocks of a pixel are XH * 32 = 32 or 96 B (mod 128) apart, so the 16 lanes of a store group
           // (8 channel quads x 2 pixel quads, the pixels 64 B apart) hit 32 different banks
@@ -350,6 +361,18 @@ __global__ __launch_bounds__(256 + 64 * NPW) void tconv_wgrad_kernel(WgradArgs p
       if (NCH % 2 == 0 || par == 0) image(I0{});
       else image(I1{});
       par ^= NCH & 1;
+    }
+    if (p.want_dbig) {   // channel c: the NP / 8 threads of quad c >> 2, in thread order (bit-reproducible)
+      float* Dl = reinterpret_cast<float*>(tw_lds);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Dl[(tid - 256) * 4 + c] = dsum[c];
+      lds_barrier();
+      if (tid - 256 < G::CB) {
+        const int c = tid - 256;
+        float sum = 0.f;
+        for (int t = c >> 2; t < NP; t += 8) sum += Dl[t * 4 + (c & 3)];
+        sl[G::CS * (G::CB * G::KK + 1) + pky * G::CB + c] = sum;
+      }
     }
     if (p.want_db && pky == 0) {   // both row parities staged `small`: one of the pair writes its sums
 #pragma unroll

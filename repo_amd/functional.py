@@ -166,8 +166,8 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
         d3 = ops.conv_down(l4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
 
     def w3():
-        ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
-        ops.channel_sum(d3, out=g[7], accumulate=accumulate)
+        # conv3's bias gradient (the channel sums of d3) rides in the weight-gradient kernel, which stages d3 exactly once
+        ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False, dbig=g[7])
 
     fk.run(w3)
     _decoder_bwd_tail(p, feat, h0, h1, h2, d3, g, dfeat, accumulate_dfeat, accumulate, fk)
@@ -192,8 +192,8 @@ def _decoder_bwd_128(p, feat, saved, g, dfeat, accumulate_dfeat, accumulate, fk)
     d3 = ops.conv_down(ops.X_DEC4, d4, p[8], None, epi=ops.EPI_MUL_DRELU, aux=h3)
 
     def w3():
-        ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
-        ops.channel_sum(d3, out=g[7], accumulate=accumulate)
+        # conv3's bias gradient (the channel sums of d3) rides in the weight-gradient kernel, which stages d3 exactly once
+        ops.conv_wgrad(ops.DEC3, h2, d3, dw=g[6], db=None, accumulate=accumulate, want_bias=False, dbig=g[7])
 
     fk.run(w3)
     _decoder_bwd_tail(p, feat, h0, h1, h2, d3, g, dfeat, accumulate_dfeat, accumulate, fk)

@@ -143,8 +143,7 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
     dy3 = fbwd(dh3, 2)
 
     def w3():
-        ops.conv_wgrad(ops.DEC3, h2, dy3, dw=g[6], db=None, accumulate=accumulate, want_bias=False)
-        ops.channel_sum(dy3, out=g[7], accumulate=accumulate)
+        ops.conv_wgrad(ops.DEC3, h2, dy3, dw=g[6], db=None, accumulate=accumulate, want_bias=False, dbig=g[7])
 
     fk.run(w3)
     dh2 = ops.conv_down(ops.DEC3, dy3, p[6], None, epi=ops.EPI_MUL_DRELU, aux=h2)

@@ -204,7 +204,7 @@ def conv_up(layer, small, w, bias=None, epi=EPI_NONE, aux=None, out=None, pack=N
     return out
 
 
-def conv_wgrad(layer, small, big, dw=None, db=None, accumulate=False, want_bias=True):
+def conv_wgrad(layer, small, big, dw=None, db=None, accumulate=False, want_bias=True, dbig=None):
     nimg = small.shape[0]
     (cb, hb, _), (cs, hs, _) = conv_shapes(layer)
     ks = CONV_GEO[layer][3]
@@ -217,7 +217,7 @@ def conv_wgrad(layer, small, big, dw=None, db=None, accumulate=False, want_bias=
     nb = lib().repo_conv_wgrad_workspace_bytes(layer, nimg)
     ws = workspace(nb, small.device)
     check(
-        lib().repo_conv_wgrad(layer, nimg, _ptr(_f32c(small)), _ptr(big), int(is_u8), _ptr(dw), _ptr(db),
+        lib().repo_conv_wgrad(layer, nimg, _ptr(_f32c(small)), _ptr(big), int(is_u8), _ptr(dw), _ptr(db), _ptr(dbig),
                               int(accumulate), _ptr(ws), ws.numel(), _stream()),
         "repo_conv_wgrad",
     )

@@ -303,6 +303,29 @@ def test_conv_wgrad(ops, layer, nimg):
     assert relerr(dw2, wd.grad + 1) < TOL
 
 
+@pytest.mark.parametrize("layer", [1, 2, 4, 5, 6])
+@pytest.mark.parametrize("nimg", [3, 300])
+def test_conv_wgrad_channel_sums_of_big(ops, layer, nimg):
+    """repo_conv_wgrad's dbias_big: the channel sums of `big` (the bias gradient of a transposed conv) -- fused into the
+    weight-gradient kernel where it stages every element once (decoder conv3: 300 images are 3 per workgroup pair, ragged),
+    the channel-sum pass elsewhere; the same numbers from both engines, with and without accumulation."""
+    from repo_amd._lib import lib
+
+    big, small, w, rs = _layer_tensors(ops, layer, nimg, 700 + layer)
+    want = big.double().sum((0, 2, 3))
+    for engine in (1, 0):
+        prev = lib().repo_debug_bconv(engine)
+        try:
+            dbig = torch.full((big.shape[1],), 2.0, device="cuda")
+            dw, _ = ops.conv_wgrad(layer, dev(small), dev(big), want_bias=False, dbig=dbig, accumulate=False)
+            assert relerr(dbig, want) < TOL
+            dw2 = dw.clone()
+            ops.conv_wgrad(layer, dev(small), dev(big), dw=dw2, db=None, want_bias=False, dbig=dbig, accumulate=True)
+            assert relerr(dbig, 2 * want) < TOL and relerr(dw2, 2 * dw.double().cpu()) < TOL
+        finally:
+            lib().repo_debug_bconv(prev)
+
+
 def test_conv_wgrad_u8(ops):
     rs = np.random.RandomState(4)
     obs = torch.from_numpy(rs.randint(0, 256, size=(7, 3, 64, 64)).astype(np.uint8))
