@@ -699,7 +699,11 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
       a.imgs_per_split = twgrad_ips(nimg);
       // where the taps reach every row and column of `big` (decoder conv3; not the 31 x 31 planes of encoder conv2, whose
       // last row and column no window touches) every element is staged exactly once and its channel sums ride along
+#ifdef TW_NO_DBIG   // A/B builds: the separate channel-sum pass
+      constexpr bool covers = false;
+#else
       constexpr bool covers = G::HB == 2 * (G::HS - 1) + G::KS;
+#endif
       a.want_dbig = covers && dbig != nullptr;
       rc = launch_tconv_wgrad<G, kTWgradNBK<G>, kTWgradNPW<G>>(a, tsplits, s);
       if (rc) return rc;
