@@ -204,12 +204,14 @@ int repo_host_gather_rows(const void* src, int64_t src_rows, int64_t row_bytes, 
  * recon and dpre may each be NULL.  target is uint8 (target_is_u8) or fp32 in [-1,1].
  * relu_mask4 (nullable, nimg*32*900/4 bytes): the quad mask of h3 (REPO_EPI_MUL_MASK4) -- the kernel has every
  * element of h3 in registers on its way to LDS anyway, and the layer's data gradient (repo_conv_down, layer 6)
- * then needs h3 for nothing else. */
+ * then needs h3 for nothing else.
+ * dbias (nullable, 3 floats): (+)= the channel sums of dpre -- the output layer's bias gradient (accumulate_dbias != 0
+ * adds): the kernel has every d in registers; the separate pass re-read 120 MB of dpre at 2450 frames. */
 size_t repo_decoder_out_nll_workspace_bytes(int64_t nimg);
 int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* w, const float* bias,
                          const void* target, int target_is_u8, float grad_scale, float* recon,
-                         float* dpre, unsigned char* relu_mask4, float* loss_sum, void* ws, size_t ws_bytes,
-                         hipStream_t stream);
+                         float* dpre, unsigned char* relu_mask4, float* loss_sum, float* dbias,
+                         int accumulate_dbias, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* A 3-channel transposed conv fused with the pixel likelihood on the gather engine, any output size: layer 12 (the
  * 128 x 128 stack's output layer) or 6 (the reference's: repo_decoder_out_nll is the specialised kernel for it).

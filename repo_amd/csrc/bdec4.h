@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
       }
   };
 
-  float lsum = 0.f;
+  float lsum = 0.f, csum = 0.f;   // csum: sum of d = recon - target over this lane's channel (the output bias gradient / grad_scale)
   const int G = gridDim.x;
   int tile = blockIdx.x;
   if (tile < ntiles) gload(tile);
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
         }
         const float d0 = v0 - t0, d1 = v1 - t1, d2 = v2 - t2, d3 = v3 - t3;
         lsum += 0.5f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        csum += (d0 + d1) + (d2 + d3);
         if (p.dpre)
           *reinterpret_cast<float4*>(p.dpre + o) = make_float4(d0 * p.grad_scale, d1 * p.grad_scale, d2 * p.grad_scale, d3 * p.grad_scale);
         if (p.recon) *reinterpret_cast<float4*>(p.recon + o) = make_float4(v0, v1, v2, v3);
@@ -238,6 +239,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
   }
   const float s = block_sum(lsum, red);
   if (tid == 0) p.partials[blockIdx.x] = s;
+  if (p.chan_partials) {   // per channel, wave order then lane order inside block_sum: bit-reproducible
+    const int my_cb = lg < 3 ? (2 * lg + (lj & 1)) % 3 : -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float sc = block_sum(my_cb == c ? csum : 0.f, red);
+      if (tid == 0) p.chan_partials[c * gridDim.x + blockIdx.x] = sc;
+    }
+  }
 }
 
 }  // namespace repo

@@ -305,6 +305,17 @@ __global__ __launch_bounds__(1024) void conv_slab_reduce_wave_kernel(const float
   }
 }
 
+// out[c] (+)= scale * sum of parts[c][0 .. n): one workgroup per c
+__global__ void partial_sum_rows_kernel(const float* __restrict__ parts, int n, float* __restrict__ out, float scale,
+                                        int accumulate) {
+  __shared__ float red[16];
+  const float* row = parts + (size_t)blockIdx.x * n;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += row[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = accumulate ? out[blockIdx.x] + scale * s : scale * s;
+}
+
 __global__ void partial_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ out, int accumulate) {
   __shared__ float red[16];
   float s = 0.f;
@@ -841,34 +852,55 @@ extern "C" int repo_conv_wgrad(int layer, int64_t nimg, const float* small, cons
                                                           accumulate, ws, ws_bytes, stream)))
 }
 
+// loss partials, then either the kernel's per-channel partials or the channel-sum pass's (the fp32 twin)
+static size_t dec4_nll_ws_floats(int64_t nimg) {
+  const size_t n = (size_t)dec4_nll_grid(nimg);
+  const size_t cs = (size_t)chansum_splits(nimg, GDec4::CB, GDec4::PB) * GDec4::CB;
+  return n + (3 * n > cs ? 3 * n : cs);
+}
 extern "C" size_t repo_decoder_out_nll_workspace_bytes(int64_t nimg) {
-  return nimg <= 0 ? 0 : (size_t)dec4_nll_grid(nimg) * sizeof(float);
+  return nimg <= 0 ? 0 : dec4_nll_ws_floats(nimg) * sizeof(float);
 }
 
 template <class TgtT>
 static int decoder_out_nll_t(int64_t nimg, const float* h3, const float* w, const float* bias, const TgtT* target,
                              float grad_scale, float* recon, float* dpre, unsigned char* mask4, float* loss_sum,
-                             void* ws, hipStream_t stream) {
+                             float* dbias, int accumulate_dbias, void* ws, hipStream_t stream) {
   using G = GDec4;
   const int nparts = dec4_nll_grid(nimg);
+  float* chan = (float*)ws + nparts;
   NllArgs a{h3, w, bias, target, recon, dpre, mask4, (float*)ws, grad_scale, (int)nimg,
             (unsigned)(nimg * G::CS * G::PS * sizeof(float))};
   // the bf16x6 kernel (bdec4.h) unless repo_debug_bconv(0) asks for the fp32-MFMA twin
-  if (t_bconv_enabled) hipLaunchKernelGGL((bdec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
+  if (t_bconv_enabled) {
+    a.chan_partials = dbias ? chan : nullptr;
+    hipLaunchKernelGGL((bdec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((dconv_dec4_nll_kernel<TgtT>), dim3(nparts), dim3(256), 0, stream, a);
+  }
   REPO_CHECK_LAUNCH();
   if (loss_sum) {
     hipLaunchKernelGGL(partial_sum_kernel, dim3(1), dim3(1024), 0, stream, (const float*)ws, nparts,
                        loss_sum, 0);
     REPO_CHECK_LAUNCH();
   }
+  if (dbias) {   // the output layer's bias gradient = the channel sums of dpre
+    if (t_bconv_enabled) {
+      hipLaunchKernelGGL(partial_sum_rows_kernel, dim3(3), dim3(256), 0, stream, (const float*)chan, nparts, dbias, grad_scale,
+                         accumulate_dbias);
+      REPO_CHECK_LAUNCH();
+    } else {
+      if (!dpre) return REPO_E_BADARG;
+      return channel_sum_launch(nimg, G::CB, G::PB, dpre, dbias, accumulate_dbias, chan, stream);
+    }
+  }
   return REPO_OK;
 }
 
 extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* w, const float* bias,
                                     const void* target, int target_is_u8, float grad_scale, float* recon, float* dpre,
-                                    unsigned char* relu_mask4, float* loss_sum, void* ws, size_t ws_bytes,
-                                    hipStream_t stream) {
+                                    unsigned char* relu_mask4, float* loss_sum, float* dbias, int accumulate_dbias,
+                                    void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(nimg > 0, REPO_E_SHAPE);
   REPO_REQUIRE(h3 && w && target, REPO_E_BADARG);
@@ -876,9 +908,9 @@ extern "C" int repo_decoder_out_nll(int64_t nimg, const float* h3, const float* 
   REPO_REQUIRE(ws && ws_bytes >= repo_decoder_out_nll_workspace_bytes(nimg), REPO_E_WS_TOO_SMALL);
   if (target_is_u8)
     return decoder_out_nll_t<uint8_t>(nimg, h3, w, bias, (const uint8_t*)target, grad_scale, recon, dpre, relu_mask4,
-                                      loss_sum, ws, stream);
+                                      loss_sum, dbias, accumulate_dbias, ws, stream);
   return decoder_out_nll_t<float>(nimg, h3, w, bias, (const float*)target, grad_scale, recon, dpre, relu_mask4, loss_sum,
-                                  ws, stream);
+                                  dbias, accumulate_dbias, ws, stream);
 }
 
 // ---- a 3-channel transposed conv fused with the pixel likelihood on the gather engine (any output size): what the

@@ -738,6 +738,7 @@ struct NllArgs {
   float grad_scale;
   int nimg;
   unsigned h3_bytes;
+  float* chan_partials = nullptr;  // bdec4.h, nullable: [3][workgroups] sums of (recon - target) per channel
 };
 
 typedef float f32x4acc __attribute__((ext_vector_type(4)));

@@ -132,8 +132,10 @@ def decoder_fwd_nll(p, feat, target, grad_scale):
         h4 = ops.conv_up(ops.X_DEC4, h3, p[8], p[9], epi=ops.EPI_RELU)
         loss_sum, dpre5, _ = ops.conv_up_nll(ops.X_DEC5, h4, p[10], p[11], target, grad_scale)
         return loss_sum, (h0, h1, h2, h3, h4, dpre5)
-    loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(h3, p[8], p[9], target, grad_scale, want_mask=True)
-    return loss_sum, (h0, h1, h2, h3, dpre4, mask3)
+    # the output bias gradient (the channel sums of dpre4) comes out of the same kernel
+    db4 = torch.empty(3, dtype=torch.float32, device=h3.device)
+    loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(h3, p[8], p[9], target, grad_scale, want_mask=True, dbias=db4)
+    return loss_sum, (h0, h1, h2, h3, dpre4, mask3, db4)
 
 
 def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None, deferred=None):
@@ -148,14 +150,22 @@ def decoder_bwd(p, feat, saved, g, dfeat=None, accumulate_dfeat=False, accumulat
         return _decoder_bwd_128(p, feat, saved, g, dfeat, accumulate_dfeat, accumulate, fk)
     h0, h1, h2, h3, d4 = saved[:5]
     mask3 = saved[5] if len(saved) > 5 else None  # quad mask of h3 from the fused output layer (8.8 MB for 282)
+    db4 = saved[6] if len(saved) > 6 else None    # and its bias gradient (the channel sums of d4)
     l4 = ops.T_DEC4 if p[8].shape[1] == 6 else ops.DEC4
 
     def w4():
         ops.conv_wgrad(l4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
-        ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+        if db4 is None:
+            ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+        elif accumulate:
+            g[9].add_(db4)
+        else:
+            g[9].copy_(db4)
 
     fk.run(w4)
-    # The bias gradients of conv3 / conv2 / conv1 (g[7], g[5], g[3]) are the channel sums of d3 / d2 / d1.  They stay
+    # The bias gradients of conv3 / conv2 / conv1 (g[7], g[5], g[3]) are the channel sums of d3 / d2 / d1.  conv4's comes
+    # out of the fused output layer (its kernel has every d in registers) and conv3's out of its weight-gradient kernel
+    # (which stages d3 exactly once, off the critical chain: round 5); conv2's and conv1's stay
     # separate passes on the weight-gradient stream: taking them in the data-gradient kernels' epilogues
     # (ops.conv_down(dbias=), tested) saves 240 us of kernel time per update but puts the shuffles, one more
     # barrier per workgroup and a dependent reduction launch per layer ON the critical chain: 8.65 vs 8.55 ms per

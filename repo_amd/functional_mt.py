@@ -116,14 +116,15 @@ def cond_decoder_fwd_nll(p, feat, cond, target, grad_scale):
     """Decoder forward fused with the unit-variance pixel NLL (dreamer_mt.py:189-195).
     Returns (sum 0.5*(recon-target)^2 (1,), saved incl. d loss / d recon * grad_scale)."""
     film, h0, ys, hs = _cond_decoder_trunk(p, feat, cond)
-    loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(hs[2], p[8], p[9], target, grad_scale, want_mask=True)
-    return loss_sum, (film, h0, ys, hs, dpre4, mask3)
+    db4 = torch.empty(3, dtype=torch.float32, device=feat.device)   # the output bias gradient, out of the same kernel
+    loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(hs[2], p[8], p[9], target, grad_scale, want_mask=True, dbias=db4)
+    return loss_sum, (film, h0, ys, hs, dpre4, mask3, db4)
 
 
 def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False, accumulate=False, side=None):
     """From d recon (saved) to the twelve decoder tensors (into g) and, if dfeat (rows, ld >= D+S) is given (Dreamer's
     attached decoder), to the [belief | state] input (written into its first D+S columns)."""
-    film, h0, ys, (h1, h2, h3), d4, mask3 = saved
+    film, h0, ys, (h1, h2, h3), d4, mask3, db4 = saved
     rows = feat.shape[0]
 
     def fbwd(dh, l):   # the FiLM backward of decoder layer l (0 .. 2): from y_l if it was saved, else from h_l
@@ -136,7 +137,10 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
 
     def w4():
         ops.conv_wgrad(ops.DEC4, h3, d4, dw=g[8], db=None, accumulate=accumulate, want_bias=False)
-        ops.channel_sum(d4, out=g[9], accumulate=accumulate)
+        if accumulate:
+            g[9].add_(db4)
+        else:
+            g[9].copy_(db4)
 
     fk.run(w4)
     dh3 = ops.conv_down(ops.DEC4, d4, p[8], None, epi=ops.EPI_MUL_MASK4, aux=mask3)

@@ -224,10 +224,12 @@ def conv_wgrad(layer, small, big, dw=None, db=None, accumulate=False, want_bias=
     return dw, db
 
 
-def decoder_out_nll(h3, w, bias, target, grad_scale, want_recon=False, want_dpre=True, want_mask=False):
+def decoder_out_nll(h3, w, bias, target, grad_scale, want_recon=False, want_dpre=True, want_mask=False, dbias=None,
+                    accumulate_dbias=False):
     """Final transposed conv fused with 0.5*(recon-target)^2 summed over everything.
     Returns (loss_sum (1,), dpre or None, recon or None) and, with want_mask, the quad mask of h3
-    (uint8, numel/4: EPI_MUL_MASK4 of the layer's data gradient) as a fourth element."""
+    (uint8, numel/4: EPI_MUL_MASK4 of the layer's data gradient) as a fourth element.
+    dbias (3,): (+)= the channel sums of dpre, the layer's bias gradient."""
     nimg = h3.shape[0]
     is_u8 = target.dtype == torch.uint8
     assert target.is_contiguous() and target.numel() == nimg * 3 * 64 * 64
@@ -240,8 +242,8 @@ def decoder_out_nll(h3, w, bias, target, grad_scale, want_recon=False, want_dpre
     ws = workspace(nb, dev)
     check(
         lib().repo_decoder_out_nll(nimg, _ptr(_f32c(h3)), _ptr(_f32c(w)), _ptr(bias), _ptr(target), int(is_u8),
-                                   float(grad_scale), _ptr(recon), _ptr(dpre), _ptr(mask), _ptr(loss), _ptr(ws),
-                                   ws.numel(), _stream()),
+                                   float(grad_scale), _ptr(recon), _ptr(dpre), _ptr(mask), _ptr(loss), _ptr(dbias),
+                                   int(accumulate_dbias), _ptr(ws), ws.numel(), _stream()),
         "repo_decoder_out_nll",
     )
     return (loss, dpre, recon, mask) if want_mask else (loss, dpre, recon)

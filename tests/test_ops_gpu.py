@@ -359,6 +359,18 @@ def test_decoder_out_nll(ops, u8, nimg):
     want = bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)
     assert torch.equal(mask.cpu(), want)
     assert torch.equal(dpre2, dpre) and loss2.item() == loss.item()
+    # dbias: the channel sums of dpre (the output layer's bias gradient), both engines, overwrite and accumulate
+    from repo_amd._lib import lib
+    for engine in (1, 0):
+        prev = lib().repo_debug_bconv(engine)
+        try:
+            db = torch.full((3,), 5.0, device="cuda")
+            ops.decoder_out_nll(dev(h3), dev(w), dev(b), dev(obs if u8 else tgt), 0.25, dbias=db)
+            assert relerr(db, (d * 0.25).sum((0, 2, 3))) < 2e-5
+            ops.decoder_out_nll(dev(h3), dev(w), dev(b), dev(obs if u8 else tgt), 0.25, dbias=db, accumulate_dbias=True)
+            assert relerr(db, 2 * (d * 0.25).sum((0, 2, 3))) < 2e-5
+        finally:
+            lib().repo_debug_bconv(prev)
     # ... and the data gradient that reads it equals the one that reads h3 itself, bit for bit
     d4 = dev(rnd(rs, nimg, 3, 64, 64))
     a = ops.conv_down(rops.DEC4, d4, dev(w), None, epi=rops.EPI_MUL_DRELU, aux=dev(h3))
