@@ -183,7 +183,8 @@ def kernel_spec(name, nimg, horizon_rows):
     layer = _CONV_GEO.get(geo)
     conv = {"buconv_scatter_kernel": ("conv_up", "bf16x6"), "uconv_scatter_kernel": ("conv_up", "fp32"),
             "bconv_down_kernel": ("conv_down", "bf16x6"), "dconv_down_kernel": ("conv_down", "fp32"),
-            "bconv_wgrad_kernel": ("conv_wgrad", "bf16x6"), "dconv_wgrad_kernel": ("conv_wgrad", "fp32")}
+            "tconv_wgrad_kernel": ("conv_wgrad", "bf16x6"), "bconv_wgrad_kernel": ("conv_wgrad", "bf16x6"),
+            "dconv_wgrad_kernel": ("conv_wgrad", "fp32")}
     for k, (op, pipe) in conv.items():
         if k in name and layer is not None:
             cb, cs, hb, ks = geo

@@ -253,6 +253,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, i
 
 }  // namespace repo
 #include "wgrad_direct.h"
+#include "wgrad_tr.h"
 namespace repo {
 
 static int wgrad_splits(long rows, long N, long K) {
@@ -379,9 +380,18 @@ int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t
   VWgradGroupOp op{};
   WdJobs dj{};
   int ndirect = 0;
-  for (int i = 0; i < n; ++i) ndirect += wgrad_direct_ok(d[i].M, d[i].N, d[i].K, d[i].lddy, d[i].ldx) ? 1 : 0;
+  bool use_tr = t_bgemm_enabled != 0;   // wgrad_tr.h (bf16x6) if every direct job fits it, else wgrad_direct.h (fp32 MFMA)
+#ifdef WT_DISABLE   // A/B builds (tools/build_variant.sh)
+  use_tr = false;
+#endif
+  for (int i = 0; i < n; ++i) {
+    const bool dk = wgrad_direct_ok(d[i].M, d[i].N, d[i].K, d[i].lddy, d[i].ldx);
+    ndirect += dk ? 1 : 0;
+    use_tr = use_tr && (!dk || wgrad_tr_ok(d[i].M, d[i].N, d[i].K, d[i].lddy, d[i].ldx));
+  }
   if (ndirect > kWdMaxJobs) ndirect = kWdMaxJobs;
-  int dsplits = ndirect ? 256 / ndirect : 0;  // one workgroup per CU over all direct jobs of the launch
+  // one workgroup per CU over all direct jobs of the launch (the transposing kernel has two per row range)
+  int dsplits = ndirect ? (use_tr ? 128 : 256) / ndirect : 0;
   if (dsplits > kWdMaxSplits) dsplits = kWdMaxSplits;
   char* w = (char*)ws;
   long nblocks = 0;
@@ -422,8 +432,13 @@ int gemm_wgrad_group(const WgradDesc* d, int n, int accumulate, void* ws, size_t
   op.g.job[n].bstart = (int)nblocks;
   op.g.njobs = n;
   if (dj.njobs > 0) {
-    hipLaunchKernelGGL(wgrad_direct_kernel, dim3(dsplits, dj.njobs), dim3(512), 0, stream, dj);
-    REPO_CHECK_LAUNCH();
+    if (use_tr) {
+      const int rc = launch_wgrad_tr(dj, dsplits, stream);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(wgrad_direct_kernel, dim3(dsplits, dj.njobs), dim3(512), 0, stream, dj);
+      REPO_CHECK_LAUNCH();
+    }
   }
   if (nblocks > 0) {
     const int rc = launch_vgemm_flat<T64x64>(op, nblocks, stream);

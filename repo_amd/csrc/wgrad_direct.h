@@ -32,6 +32,7 @@ struct WdJob {
 struct WdJobs {
   WdJob job[kWdMaxJobs];
   int njobs;
+  int splits;   // wgrad_tr.h: row ranges per job (its grid is one-dimensional)
 };
 
 // what the kernel's n-tile cut and load widths assume
