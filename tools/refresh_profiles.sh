@@ -36,6 +36,10 @@ if [ -f .r4tree/bench.py ]; then
      echo -n "this tree: "; python3 bench.py --no-cpu-baseline --steps 60 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'updates/s', d['ms_per_step'], 'ms', 'resident', d['resident_batch_ms'])"
    done) > $O/r05_ab_vs_round4.txt 2>&1
 fi
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke" > $O/r05_smoke.txt
+python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed" > $O/r05_gpu_tests.txt
+python3 tools/layers_isolated.py "mlp_bwd" > $O/r05_heads_isolated.txt 2>&1
+bash tools/pmc.sh wtr "wgrad_tr|wgrad_direct" tools/run_micro_case.py "mlp_bwd value head weight" "mlp_bwd actor trunk weight" > /dev/null 2>&1
 python3 bench.py > $O/bench_full.log 2>&1
 grep '^{' $O/bench_full.log > $O/r05_bench_final.json
 tail -c 700 $O/r05_bench_final.json
