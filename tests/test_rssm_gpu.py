@@ -118,6 +118,40 @@ def test_mlp_fwd_bwd(ops, mod, L, rows):
         assert l2err(g, v.grad) < GTOL, k
 
 
+@pytest.mark.parametrize("mod,L,rows", [("value_model", 4, 20011), ("actor_model", 5, 9000)])
+def test_head_weight_gradients_on_the_bf16_pipe_match_fp64_and_the_fp32_engine(ops, mod, L, rows):
+    """The dense heads' weight gradients at update-like row counts (csrc/wgrad_tr.h: both operands staged as they lie, split
+    exactly into three bf16 each, fragments by the LDS's transposing read) against an fp64 backward of the same head -- and
+    against the fp32-MFMA kernel (csrc/wgrad_direct.h, repo_debug_bgemm(0)) on the SAME operands: the six-product split may
+    not be less accurate than fp32 arithmetic by more than 25 % (measured: at or below it).  20011 rows: 42 row ranges of
+    477 rows, the last block of every range ragged, the last range short."""
+    from repo_amd._lib import lib
+
+    A = 6
+    rs = np.random.RandomState(rows)
+    p = tparams(mod, A)
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in p.items()}
+    feat = rnd(rs, rows, 230)
+    feat[::5] *= 8.0
+    want = ro.mlp_head(p64, feat.double()[:, :200], feat.double()[:, 200:], L)
+    up = rnd(rs, *want.shape)
+    (want * up.double()).sum().backward()
+    _, hid = ops.mlp_fwd(cu(p), feat.cuda())
+    errs = {}
+    for engine in (1, 0):
+        prev = lib().repo_debug_bgemm(engine)
+        try:
+            dparams = [torch.zeros_like(v).cuda() for v in p.values()]
+            ops.mlp_bwd(cu(p), feat.cuda(), hid, up.cuda(), dparams=dparams, dx=None)
+        finally:
+            lib().repo_debug_bgemm(prev)
+        errs[engine] = max(l2err(g, v.grad) for (k, v), g in zip(p64.items(), dparams) if v.dim() == 2 and v.shape[0] == 200)
+        for (k, v), g in zip(p64.items(), dparams):
+            assert l2err(g, v.grad) < GTOL, (engine, k)
+    log(f"head weight gradients {mod} rows={rows}: max l2 err of the 200-wide layers  bf16x6 {errs[1]:.2e}  fp32 MFMA {errs[0]:.2e}")
+    assert errs[1] <= 1.25 * errs[0] + 1e-8, errs
+
+
 @pytest.mark.parametrize("case", ["odd_shape", "misaligned_hidden"])
 def test_mlp_layer_by_layer_path(ops, case):
     """Shapes outside the fused kernel's instantiation (csrc/mlp16.hip) and hidden buffers that are not 16-byte

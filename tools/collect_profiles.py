@@ -14,6 +14,7 @@ pairs = [
     ("pmc_c3/summary.txt", "r05_pmc_3channel_layers.txt"),
     ("pmc_mlp/summary.txt", "r05_pmc_mlp_heads.txt"),
     ("pmc_wtr/summary.txt", "r05_pmc_head_wgrad.txt"),
+    ("r05_heads_isolated.txt", "r05_heads_isolated.txt"),
     ("r05_bench_final.json", "r05_bench_final.json"),
     ("r05_bench_c4_c5.json", "r05_bench_c4_c5.json"),
     ("r05_bench_shards.json", "r05_bench_shards.json"),
