@@ -29,6 +29,7 @@
 #include "bwgrad.h"
 #include "bdec4.h"
 #include "twgrad.h"
+#include "tconv_up.h"
 
 
 namespace repo {
@@ -552,7 +553,7 @@ static bool buconv_on() {
 }
 
 template <class G>
-static size_t conv_up_ws_bytes() {
+static size_t conv_up_ws_scatter() {
   using C = typename UConf<G>::type;
   using BC = typename BUConf<G>::type;
   if constexpr (kUpDirect<G>) return UpGeo<G>::PACK_FLOATS * sizeof(float);
@@ -560,11 +561,30 @@ static size_t conv_up_ws_bytes() {
   else if constexpr (!std::is_void<BC>::value) return BC::PACK_BYTES > C::PACK_FLOATS * sizeof(float) ? BC::PACK_BYTES : C::PACK_FLOATS * sizeof(float);
   else return C::PACK_FLOATS * sizeof(float);
 }
+// encoder conv2's data gradient also has a gather-form kernel (tconv_up.h): its pack sits behind the scatter kernels'
+template <class G> constexpr bool kTconvUp = false;
+#ifndef TCU_DISABLE   // A/B builds (tools/build_variant.sh)
+template <> constexpr bool kTconvUp<GEnc2> = true;
+#endif
+template <class G>
+static size_t conv_up_tcu_off() { return (conv_up_ws_scatter<G>() + 255) & ~(size_t)255; }
+template <class G>
+static size_t conv_up_ws_bytes() {
+  if constexpr (kTconvUp<G>) return conv_up_tcu_off<G>() + kTcuPackBytes;
+  return conv_up_ws_scatter<G>();
+}
 
 template <class G>
 static int conv_up_pack_t(const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
   using UC = typename UConf<G>::type;
   using BC = typename BUConf<G>::type;
+  if constexpr (kTconvUp<G>) {   // both packs: which kernel a later call takes depends on its epilogue and batch
+    if (buconv_on<G>()) {
+      if (!ws || ws_bytes < conv_up_ws_bytes<G>()) return REPO_E_WS_TOO_SMALL;
+      const int rc = launch_tconv_up_pack(w, (char*)ws + conv_up_tcu_off<G>(), s);
+      if (rc) return rc;
+    }
+  }
   if constexpr (!std::is_void<BC>::value)
     if (buconv_on<G>()) return launch_buconv_pack<G, BC>(w, ws, ws_bytes, s);
   if constexpr (kUpDirect<G>) return launch_dconv_up_pack<G>(w, ws, ws_bytes, s);
@@ -581,6 +601,17 @@ static int conv_up_t(int64_t nimg, const float* small, const float* w, const flo
   // the channel-quad mask is what the scatter kernels' drain reads (a pixel's four channels per item)
   if (epi == REPO_EPI_MUL_CMASK && (kUpDirect<G> || std::is_void<UC>::value || G::CB % 4 != 0)) return REPO_E_BADARG;
   if (epi == REPO_EPI_FILM_RELU && (kUpDirect<G> || std::is_void<UC>::value)) return REPO_E_BADARG;   // the scatter kernels' drains
+  if constexpr (kTconvUp<G>) {
+    const bool epi_ok = epi == REPO_EPI_NONE || epi == REPO_EPI_MUL_DRELU || epi == REPO_EPI_MUL_CMASK;   // the encoder backward's forms; ReLU / FiLM: the scatter kernel
+    if (buconv_on<G>() && epi_ok && nimg >= 4 && ws && ws_bytes >= conv_up_ws_bytes<G>()) {
+      char* pack = (char*)ws + conv_up_tcu_off<G>();
+      if (!packed) {
+        const int rc = launch_tconv_up_pack(w, pack, s);
+        if (rc) return rc;
+      }
+      return launch_tconv_up(small, pack, bias, aux, big, nimg, epi, s);
+    }
+  }
   if constexpr (!std::is_void<BC>::value)
     if (buconv_on<G>()) return launch_buconv_scatter<G, BC>(small, w, bias, aux, big, nimg, epi, packed, ws, ws_bytes, s);
   if constexpr (kUpDirect<G>) {
