@@ -181,6 +181,9 @@ def kernel_spec(name, nimg, horizon_rows):
     m = re.search(r"Geo<(\d+), ?(\d+), ?(\d+), ?(\d+)>", name)
     geo = tuple(int(x) for x in m.groups()) if m else None
     layer = _CONV_GEO.get(geo)
+    if "tconv_up_kernel" in name:   # encoder conv2's data gradient in gather form (csrc/tconv_up.h): no Geo<> in its name
+        return {"op": "conv_up", "layer": 1, "pipe": "bf16x6", "flop": 2.0 * nimg * 64 * 14 * 14 * 32 * 16,
+                "label": "tconv_up_kernel (encoder conv2 data gradient, gather form)"}
     conv = {"buconv_scatter_kernel": ("conv_up", "bf16x6"), "uconv_scatter_kernel": ("conv_up", "fp32"),
             "bconv_down_kernel": ("conv_down", "bf16x6"), "dconv_down_kernel": ("conv_down", "fp32"),
             "tconv_wgrad_kernel": ("conv_wgrad", "bf16x6"), "bconv_wgrad_kernel": ("conv_wgrad", "bf16x6"),
