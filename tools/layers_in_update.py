@@ -18,6 +18,8 @@ NIMG = 2450   # --nimg N: frames per update of the traced config (c4 / c4x128: 1
 
 def conv_flop(name):
     m = re.search(r"Geo<(\d+), (\d+), (\d+), (\d+)>", name)
+    if not m and name.startswith("tconv_up_kernel"):   # encoder conv2's data gradient in gather form: no Geo<> in the name
+        m = re.search(r"(\d+), (\d+), (\d+), (\d+)", "32, 64, 31, 4")
     if not m:
         return None
     cb, cs, hb, ks = map(int, m.groups())
