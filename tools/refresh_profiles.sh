@@ -40,6 +40,8 @@ python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke" > $O/r05
 python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed" > $O/r05_gpu_tests.txt
 python3 tools/layers_isolated.py "mlp_bwd" > $O/r05_heads_isolated.txt 2>&1
 bash tools/pmc.sh wtr "wgrad_tr|wgrad_direct" tools/run_micro_case.py "mlp_bwd value head weight" "mlp_bwd actor trunk weight" > /dev/null 2>&1
+# the bench line names the trace's top kernel from profiles/dominant_kernel_*.json: bring them up to date first
+python3 tools/collect_profiles.py --write-json > /dev/null 2>&1
 python3 bench.py > $O/bench_full.log 2>&1
 grep '^{' $O/bench_full.log > $O/r05_bench_final.json
 tail -c 700 $O/r05_bench_final.json
