@@ -236,6 +236,29 @@ def test_conv_up(ops, layer, nimg):
     assert relerr(got, want) < TOL
 
 
+@pytest.mark.parametrize("nimg", [4, 600])
+def test_conv_up_gather_form_many_images_per_workgroup(ops, nimg):
+    """Encoder conv2's data gradient in gather form (csrc/tconv_up.h) where a workgroup walks SEVERAL images (600 images: three
+    per workgroup, the accumulators and the weight / relu-operand prefetch carried across images, the last workgroup ragged)
+    and at its smallest batch: all three of its epilogues against fp64, the mask and activation forms bit-identical."""
+    import repo_amd.ops as rops
+    layer = 1
+    big, small, w, rs = _layer_tensors(ops, layer, nimg, 321)
+    hb = big.shape[2]
+    r = F.conv_transpose2d(small.double(), w.double(), None, stride=2)
+    want = F.pad(r, (0, hb - r.shape[3], 0, hb - r.shape[2]))
+    bias = rnd(rs, big.shape[1])
+    got = ops.conv_up(layer, dev(small), dev(w), dev(bias))
+    assert relerr(got, want + bias.double().view(1, -1, 1, 1)) < TOL
+    h = F.relu(rnd(rs, *big.shape))
+    a = ops.conv_up(layer, dev(small), dev(w), None, epi=ops.EPI_MUL_DRELU, aux=dev(h))
+    assert relerr(a, want * (h > 0)) < TOL
+    bits = (h > 0).to(torch.uint8).view(nimg, -1, 4, hb * hb)   # channel-quad mask: byte (image, quad, pixel), bit = channel & 3
+    cmask = (bits[:, :, 0] | (bits[:, :, 1] << 1) | (bits[:, :, 2] << 2) | (bits[:, :, 3] << 3)).contiguous().view(-1)
+    m = ops.conv_up(layer, dev(small), dev(w), None, epi=rops.EPI_MUL_CMASK, aux=dev(cmask))
+    assert torch.equal(a, m)
+
+
 @pytest.mark.parametrize("layer,kind", [(5, "down"), (1, "down"), (2, "down"), (3, "down"), (4, "down"), (5, "up"), (1, "up"), (2, "up"),
                                         (3, "up"), (4, "up"), (5, "wgrad"), (2, "wgrad"), (1, "wgrad")])
 def test_bf16x6_conv_kernels_match_fp64_and_the_fp32_kernels(ops, layer, kind):
