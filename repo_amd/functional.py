@@ -29,7 +29,8 @@ def encoder_fwd(p, obs):
     # gradient of the layer above needs of it
     # (not h1's: since round 5 conv1 runs on the raw bytes at 100 us and its mask costs 40 us of byte stores, which is
     # what conv2's data gradient saves by reading 19 MB instead of 301: update 6.351 / 6.359 / 6.369 ms without against
-    # 6.360 / 6.371 / 6.382 with, alternating on one box)
+    # 6.360 / 6.371 / 6.382 with, alternating on one box; again with conv2's data gradient in gather form, which reads the
+    # operand ahead of its use: 6.071 / 6.078 / 6.153 without against 6.070 / 6.081 / 6.118 with)
     h1, m1 = ops.conv_down(L[0], obs, p[0], p[1], epi=ops.EPI_RELU), None
     h2, m2 = ops.conv_down(L[1], h1, p[2], p[3], epi=ops.EPI_RELU, want_cmask=True)
     h3, m3 = ops.conv_down(L[2], h2, p[4], p[5], epi=ops.EPI_RELU, want_cmask=True)
