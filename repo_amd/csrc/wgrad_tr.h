@@ -72,7 +72,10 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WdJobs g) {
     for (int i = 0; i < kWtNT; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool live = 2 * wid < nkt;   // the last wave of the upper half may own no tile
+    // the last wave of the upper half may own no tile; with an odd tile count the last live wave's second tile is the other
+    // half's first (or a column range past K): it is multiplied all the same -- no branch in the loop -- and stored only
+    // where k <= K, where both halves write the same bits
+    const bool live = 2 * wid < nkt;
 
     auto frag = [&](const char* base, int pitch8, int off) __attribute__((always_inline)) {
       const tw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(TW_LDS(base + off));
