@@ -330,10 +330,14 @@ __global__ __launch_bounds__(T::NT) void bconv_down_kernel(DownArgs p) {
   __syncthreads();
   for (int t = 0; t < NSL; ++t) {
     if (t + 1 < NSL) gload(t + 1);
+#ifndef BC_NO_COMPUTE   // ablation builds (profiles/r05_bconv_ablation.txt): results wrong, time meaningful
     compute();
+#endif
     __syncthreads();
     if (t + 1 < NSL) {
+#ifndef BC_NO_STAGE
       lstore();
+#endif
       __syncthreads();
     }
   }
