@@ -30,6 +30,7 @@
 #include "bdec4.h"
 #include "twgrad.h"
 #include "tconv_up.h"
+#include "tconv_down.h"
 
 
 namespace repo {
@@ -488,6 +489,15 @@ static int conv_down_t(int64_t nimg, const BigT* big, const float* w, const floa
   DownArgs a{big, w, bias, aux, small, (int)nimg, epi, (unsigned)(nimg * G::CB * G::PB * sizeof(BigT)),
              (unsigned)(G::CS * G::CB * G::KK * sizeof(float)), parts, cmask};
   int rc;
+#ifndef TCD_DISABLE
+  // decoder conv3's data gradient with specialised staging / multiplying waves (tconv_down.h); its pack takes the
+  // bf16x6 kernel's place in the workspace
+  if constexpr (std::is_same<G, GDec3>::value && std::is_same<BigT, float>::value) {
+    if (bf && (epi == REPO_EPI_NONE || epi == REPO_EPI_MUL_DRELU) && !bias && !dbias && !cmask && nimg >= 32 &&
+        pack_bytes >= kTcdPackBytes)
+      return launch_tconv_down(a, w, (char*)ws, s);
+  }
+#endif
   if constexpr (kBDownT<G, BigT>) {
     if (bf) rc = launch_bconv_down<G, BDownTile<G, BigT>, BigT>(a, w, (char*)ws, s);
     else rc = (nimg * (int64_t)G::PS <= 512) ? launch_dconv_down<G, BigT, typename DLatTile<G>::type>(a, s)

@@ -1,0 +1,343 @@
+// Decoder conv3's data gradient (the stride-2 "down" convolution 32 ch @ 30 x 30 -> 64 ch @ 13 x 13, k = 6) on the bf16
+// matrix pipe ("bf16x6", bgemm.h) with waves that ONLY stage beside waves that ONLY multiply.
+//
+//   small[img][cs][sy][sx] = sum_{cb,ky,kx} big[img][cb][2sy+ky][2sx+kx] w[cs][cb][ky][kx]
+//   M = cs (A = weights), N = the 169 pixels of ONE image (11 tiles of 16), K = (8 channels of a chunk) x (4 taps) per MFMA
+//
+// bconv.h stages, then multiplies, all waves in turn: a fifth of its time is staging that nothing hides
+// (profiles/r05_bconv_ablation.txt).  Here, as in twgrad.h / tconv_up.h:
+//   * `big` is staged CHANNEL-INNERMOST -- per image and 8-channel chunk three bf16 planes [row][column parity][x/2][8 ch],
+//     16 B per pixel (43 KB; two buffers) -- so the B fragment of v_mfma_f32_16x16x32_bf16 (column = pixel, a lane group's
+//     8 k = the chunk's 8 channels at ONE tap) is one ds_read_b128 per plane at
+//        base(pixel) + (ky * row + (kx & 1) * parity plane + (kx >> 1) * 16 B)(tap of the lane's group),
+//     stride 2 and the tap in the address, no gather, no vector arithmetic per use;
+//   * the weights arrive pre-split and fragment-ready from a pack (tconv_down_pack_kernel): per (chunk, 4 taps)
+//     [plane][cs][lane group = tap][8 ch] = 12 KB, streamed from L2 (all workgroups read the same 442 KB:
+//     profiles/r05_l2_weight_stream.txt) through an LDS ring of two 3-step groups by the staging waves;
+//   * a PERSISTENT workgroup per CU takes images b, b + grid, ...; 8 waves: waves 0-3 multiply -- wave = (32 cs) x (6 pixel
+//     tiles; the 12th tile is a phantom) -- waves 4-7 stage the next chunk's patch and the next group's weights; one
+//     LDS-only barrier per 3 MFMA steps (12 taps x 8 channels);
+//   * epilogue by the multiplying waves while the staging waves are already on the next image: 64-byte runs per channel
+//     (16 pixels of a tile), the ReLU operand loaded at the same addresses.
+// Reference: autograd's input gradient of nn.ConvTranspose2d(64, 32, 6, stride 2) (models/decoder.py:43-47).
+#pragma once
+#include "bgemm.h"
+#include "dconv.h"
+#include "twgrad.h"
+
+namespace repo {
+
+struct TcdGeo {
+  static constexpr int CB = 32, CS = 64, WB = 30, HB = 30, WS = 13, PS = 169, PB = 900, KS = 6, KK = 36;
+  static constexpr int CC = 8;                         // channels per chunk
+  static constexpr int NCH = CB / CC;                  // chunks per image
+  static constexpr int NST = KK / 4;                   // MFMA steps (4 taps x 8 channels) per chunk
+  static constexpr int GST = 3, NGR = NST / GST;       // steps per weight group (= per barrier), groups per chunk
+  static constexpr int XH = 15, PIXB = 16;
+  // a staged row: [column parity][x/2][8 ch], the odd columns 256 B behind the even ones -- the taps (ky, 2j) and (ky, 2j+1)
+  // of a lane-group pair then read the SAME banks, which is what ds_read_b128's lane groups (half of one lane group of
+  // 16, half of its neighbour: MI355X_MICROARCH.md, LDS) need to stay conflict-free
+  static constexpr int PO = 256, ROWB = PO + XH * PIXB;
+  // the lane group's tap at step s: pair 2 s + (kg >> 1) of the 18 (ky, j) pairs, column 2 j + (kg & 1)
+  static constexpr int tap_of(int s, int kg) { return ((2 * s + (kg >> 1)) / 3) * KS + 2 * ((2 * s + (kg >> 1)) % 3) + (kg & 1); }
+  static constexpr int PPLANE = HB * ROWB, PBUF = 3 * PPLANE;
+  static constexpr int WPL = CS * 4 * 16;              // one plane of one step: [cs][lane group][8 ch]
+  static constexpr int WSTEP = 3 * WPL, WGRP = GST * WSTEP;
+  static constexpr int LDS_BYTES = 2 * PBUF + 2 * WGRP;
+  static constexpr int NTL = 6;                        // pixel tiles per multiplying wave
+  static constexpr int W_PER = WGRP / 16 / 256;        // 16-byte vectors per staging thread and group
+  static constexpr int QPR = 8, P_PER = 2;             // pixel quads per row (the last ends WITH the row); items per thread
+  static_assert(WGRP % (16 * 256) == 0 && 2 * QPR * HB <= 256 * P_PER && NST % GST == 0, "staging shares");
+};
+constexpr size_t kTcdPackBytes = (size_t)TcdGeo::NCH * TcdGeo::NST * TcdGeo::WSTEP;
+
+// one thread per (chunk, step, cs, lane group): the 8 channels of one A fragment's lane, all three planes
+__global__ __launch_bounds__(256) void tconv_down_pack_kernel(const float* w, char* pack) {
+  typedef TcdGeo T;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T::NCH * T::NST * T::CS * 4) return;
+  const int kg = i & 3, cs = (i >> 2) % T::CS, st = (i >> 2) / T::CS;   // st = chunk * NST + step
+  const int c = st / T::NST, tap = T::tap_of(st % T::NST, kg);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = w[((size_t)cs * T::CB + T::CC * c + j) * T::KK + tap];
+  unsigned pl[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bg_split3(v[2 * e], v[2 * e + 1], pl[0][e], pl[1][e], pl[2][e]);
+  // per 16-row tile [lane group][row][8 ch]: the tile's A fragment is 1 KB read at 16 B x lane (conflict-free for ds_read_b128)
+  char* dst = pack + (size_t)st * T::WSTEP + ((cs >> 4) * 64 + kg * 16 + (cs & 15)) * 16;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4s*>(dst + q * T::WPL) = u32x4s{pl[q][0], pl[q][1], pl[q][2], pl[q][3]};
+}
+
+// KEPI: REPO_EPI_NONE or REPO_EPI_MUL_DRELU (aux = the fp32 activation whose ReLU the gradient passes through)
+template <int KEPI>
+__global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
+  typedef TcdGeo T;
+  extern __shared__ __attribute__((aligned(16))) char td_lds[];
+  char* const Pb = td_lds;
+  char* const Wr = td_lds + 2 * T::PBUF;
+  const int tid = threadIdx.x;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nloc = (p.nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // images of this workgroup
+  if (nloc <= 0) return;
+  const int nchunks = nloc * T::NCH;
+
+  if (wid < 4) {
+    // =================================================================== the multiplying waves
+    const int lane = tid & 63;
+    const int mh = wid & 1, nh = wid >> 1;
+    const int ln = lane & 15, kg = lane >> 4;
+    // Which pixel a lane holds in a tile.  A pixel's 16-byte slot in the 256-byte bank row is (2 sy ROWB / 16 + sx) mod 16 =
+    // (14 sy + sx) mod 16: sixteen CONSECUTIVE pixels never fill the sixteen slots (a row wrap jumps by two), and every one of
+    // ds_read_b128's four lane groups would take a second cycle.  Lane ln therefore takes the pixels of slot ln, one per
+    // tile in row order (9-12 pixels per slot: twelve tiles, 6 per wave; a lane without a pixel in a tile re-reads its first).
+    int pxs[T::NTL], pfirst = 0;
+#pragma unroll
+    for (int t = 0; t < T::NTL; ++t) pxs[t] = -1;
+    {
+      int cnt = 0;
+#pragma unroll
+      for (int sy = T::WS - 1; sy >= 0; --sy) {   // (descending: pfirst ends as the lowest row's)
+        const int sx = (ln + 2 * sy) & 15;
+        if (sx < T::WS) pfirst = T::WS * sy + sx;
+      }
+#pragma unroll
+      for (int sy = 0; sy < T::WS; ++sy) {
+        const int sx = (ln + 2 * sy) & 15;
+        const int idx = cnt - T::NTL * nh;
+#pragma unroll
+        for (int t = 0; t < T::NTL; ++t)
+          if (sx < T::WS && idx == t) pxs[t] = T::WS * sy + sx;
+        cnt += sx < T::WS ? 1 : 0;
+      }
+    }
+    int nbase[T::NTL];
+#pragma unroll
+    for (int t = 0; t < T::NTL; ++t) {
+      const int px = pxs[t] < 0 ? pfirst : pxs[t];
+      const int sy = px / T::WS, sx = px - sy * T::WS;
+      nbase[t] = 2 * sy * T::ROWB + sx * T::PIXB;
+    }
+    // per step: the lane group's tap
+    int toff[T::NST];
+#pragma unroll
+    for (int s = 0; s < T::NST; ++s) {
+      const int pr = 2 * s + (kg >> 1), ky = pr / 3, kx = 2 * (pr - 3 * ky) + (kg & 1);
+      toff[s] = ky * T::ROWB + (kx & 1) * T::PO + (kx >> 1) * T::PIXB;
+    }
+    const int abase = 2 * mh * 1024 + lane * 16;
+
+    f32x4 acc[2][T::NTL];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < T::NTL; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 4u * (unsigned)p.nimg * T::CS * T::PS);
+    const __amdgpu_buffer_rsrc_t raux = make_rsrc(KEPI == REPO_EPI_MUL_DRELU ? p.aux : p.out, 4u * (unsigned)p.nimg * T::CS * T::PS);
+
+    // the epilogue's byte offsets (image 0): cs = 32 mh + 16 m + 4 (lane >> 4) + r, px = 16 tile + (lane & 15); a pixel past
+    // the plane is out of the descriptors' range
+    unsigned eoff[T::NTL];
+#pragma unroll
+    for (int t = 0; t < T::NTL; ++t) {
+      eoff[t] = (4u * (unsigned)((32 * mh + 4 * kg) * T::PS + max(pxs[t], 0))) | ((unsigned)(pxs[t] >> 31) & kOobOffset);
+    }
+    float av[2][T::NTL][4];   // REPO_EPI_MUL_DRELU: the ReLU operand, requested a chunk before the image completes
+
+    lds_barrier();   // chunk 0 and weight group 0 are staged
+    int ph = 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+      const char* Pl = Pb + (cc & 1) * T::PBUF;
+      const unsigned ibase = 4u * (unsigned)(((int)blockIdx.x + (cc / T::NCH) * (int)gridDim.x) * T::CS * T::PS);
+      if (KEPI == REPO_EPI_MUL_DRELU && (cc & (T::NCH - 1)) == T::NCH - 1) {
+#pragma unroll
+        for (int t = 0; t < T::NTL; ++t)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              av[m][t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(raux, eoff[t] + ibase + 4u * (unsigned)((16 * m + r) * T::PS), 0, 0));
+      }
+      bg_bf16x8 fa[2][2][3], fb[3][3];
+#pragma unroll
+      for (int g = 0; g < T::NGR; ++g) {
+        const char* Wl = Wr + (ph & 1) * T::WGRP;
+        // one item = one (step, tile): its 12 MFMAs (two row tiles x six products) run while the next item's three reads
+        // (and, at a step's first tile, the next step's six weight reads) are in flight
+        auto load_a = [&](bg_bf16x8(&fa)[2][3], int k) __attribute__((always_inline)) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              fa[m][q] = *reinterpret_cast<const bg_bf16x8*>(Wl + k * T::WSTEP + q * T::WPL + abase + m * 1024);
+        };
+        auto load_b = [&](bg_bf16x8(&fb)[3], int s, int t) __attribute__((always_inline)) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bg_bf16x8*>(Pl + q * T::PPLANE + nbase[t] + toff[s]);
+        };
+        // (the patch does not change inside a chunk: the first two items' B fragments of groups 1, 2 were requested in
+        // front of the barrier that ended the group before)
+        load_a(fa[0], 0);
+        if (g == 0) {
+          load_b(fb[0], 0, 0);
+          load_b(fb[1], 0, 1);
+        }
+        constexpr int NIT = T::GST * T::NTL;
+        static_assert(NIT % 3 == 0, "the B ring restarts at slot 0 in every group");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int k = it / T::NTL, t = it % T::NTL;
+          if (it + 2 < NIT) load_b(fb[(it + 2) % 3], g * T::GST + (it + 2) / T::NTL, (it + 2) % T::NTL);
+          if (t == 0 && k + 1 < T::GST) load_a(fa[(k + 1) & 1], k + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          // per accumulator the smallest terms first; the two row tiles interleaved
+          constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+          for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#ifdef TCD_NO_MFMA
+              acc[m][t][0] += __builtin_bit_cast(float, (int)fa[k & 1][m][PA[pr]][0] + (int)fb[it % 3][PB[pr]][0]);
+#else
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[k & 1][m][PA[pr]], fb[it % 3][PB[pr]], acc[m][t], 0, 0, 0);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + 1 < T::NGR) {
+          load_b(fb[0], (g + 1) * T::GST, 0);
+          load_b(fb[1], (g + 1) * T::GST, 1);
+        }
+        lds_barrier();
+        ++ph;
+      }
+#ifndef TCD_NO_EPI
+      if ((cc & (T::NCH - 1)) == T::NCH - 1)
+#else
+      if (cc == nchunks - 1)
+#endif
+      {
+        // ---- the image is complete: 64-byte runs per channel (16 pixels of a tile)
+#pragma unroll
+        for (int t = 0; t < T::NTL; ++t)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[m][t][r];
+              if (KEPI == REPO_EPI_MUL_DRELU) x = av[m][t][r] > 0.f ? x : 0.f;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rout, eoff[t] + ibase + 4u * (unsigned)((16 * m + r) * T::PS), 0, 0);
+              acc[m][t][r] = 0.f;
+            }
+      }
+    }
+  } else {
+    // =================================================================== the staging waves
+    const int t_ = tid - 256;
+    const __amdgpu_buffer_rsrc_t rbg = make_rsrc(p.big, p.big_bytes), rw = make_rsrc(p.w, (unsigned)kTcdPackBytes);
+    f32x4 rwv[T::W_PER], rpv[T::P_PER][4];
+    // weight group gi (of this workgroup's sequence): the pack is walked linearly, once per image
+    auto wload = [&](int gi) __attribute__((always_inline)) {
+      const unsigned base = (unsigned)(gi % (T::NCH * T::NGR)) * (unsigned)T::WGRP;
+#pragma unroll
+      for (int i = 0; i < T::W_PER; ++i) rwv[i] = VecLoad<4>::load(rw, base + 16u * (unsigned)(t_ + 256 * i));
+    };
+    auto wstore = [&](int gi) __attribute__((always_inline)) {
+      char* Wl = Wr + (gi & 1) * T::WGRP;
+#pragma unroll
+      for (int i = 0; i < T::W_PER; ++i) *reinterpret_cast<f32x4*>(Wl + 16 * (t_ + 256 * i)) = rwv[i];
+    };
+    // patch item i of chunk cc: v = t_ + 256 i -> channel quad v & 1, pixel quad q, row; a ds_write_b64 lane group (16
+    // consecutive lanes) is [row & 1][q & 3][channel quad]: 8 B at 32 q + 8 cq of two rows 496 = 112 (mod 128) B apart --
+    // every one of the 32 store banks once
+    auto pload = [&](int cc) __attribute__((always_inline)) {
+      const int img = (int)blockIdx.x + (cc / T::NCH) * (int)gridDim.x, c = cc & (T::NCH - 1);
+      const unsigned dead_c = (unsigned)((nchunks - 1 - cc) >> 31);
+#pragma unroll
+      for (int i = 0; i < T::P_PER; ++i) {
+        const int v = t_ + 256 * i, cq = v & 1, q = ((v >> 1) & 3) | (((v >> 4) & 1) << 2), row = ((v >> 3) & 1) | ((v >> 5) << 1);
+        const unsigned dead = ((unsigned)((T::HB - 1 - row) >> 31) | dead_c) & kOobOffset;
+        const int x0 = min(4 * q, T::WB - 4);   // the row's last quad ends WITH the row (it re-stages two pixels)
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+          rpv[i][ch] = VecLoad<4>::load(rbg, (4u * (unsigned)((img * T::CB + T::CC * c + 4 * cq + ch) * T::PB + row * T::WB + x0)) | dead);
+      }
+    };
+    auto pstore = [&](int cc, int i) __attribute__((always_inline)) {
+      char* Pl = Pb + (cc & 1) * T::PBUF;
+      const int v = t_ + 256 * i, cq = v & 1, q = ((v >> 1) & 3) | (((v >> 4) & 1) << 2), row = ((v >> 3) & 1) | ((v >> 5) << 1);
+      if (row < T::HB) {
+        const int x0 = min(4 * q, T::WB - 4);   // even: pixel x0 + e has column parity e & 1, x/2 = x0/2 + (e >> 1)
+        char* base = Pl + row * T::ROWB + (x0 >> 1) * T::PIXB + cq * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned a1, a2, a3, b1, b2, b3;
+          tw_split3(rpv[i][0][e], rpv[i][1][e], a1, a2, a3);
+          tw_split3(rpv[i][2][e], rpv[i][3][e], b1, b2, b3);
+          char* dst = base + (e & 1) * T::PO + (e >> 1) * T::PIXB;
+          *reinterpret_cast<bg_u32x2*>(dst) = bg_u32x2{a1, b1};
+          *reinterpret_cast<bg_u32x2*>(dst + T::PPLANE) = bg_u32x2{a2, b2};
+          *reinterpret_cast<bg_u32x2*>(dst + 2 * T::PPLANE) = bg_u32x2{a3, b3};
+        }
+      }
+    };
+
+    // prologue: chunk 0's patch and weight group 0 in LDS; chunk 1's patch and group 1 in registers
+    pload(0);
+    wload(0);
+    pstore(0, 0);
+    pstore(0, 1);
+    wstore(0);
+    wload(1);
+    pload(1);
+    lds_barrier();
+    int gi = 0;   // the group the multiplying waves are on
+    for (int cc = 0; cc < nchunks; ++cc) {
+      // group g of chunk cc is being multiplied: group gi + 1 goes to the other ring slot (free since the last barrier),
+      // chunk cc + 1's patch to the other patch buffer (free since chunk cc - 1 ended), one item per phase; the loads
+      // of chunk cc + 2 are issued in the chunk's last phase
+#pragma unroll
+      for (int g = 0; g < T::NGR; ++g) {
+#ifndef TCD_NO_STAGE   // ablation builds (tools/build_variant.sh): results wrong, time meaningful
+        wstore(gi + 1);
+        wload(gi + 2);
+        if (g < T::P_PER) pstore(cc + 1, g);
+        if (g == T::P_PER - 1) pload(cc + 2);   // as soon as the registers are free: a phase and a half ahead of its first store
+#endif
+        lds_barrier();
+        ++gi;
+      }
+    }
+  }
+}
+
+template <int KEPI>
+inline int launch_tconv_down_k(const DownArgs& a, int grid, hipStream_t s) {
+  static_assert(TcdGeo::LDS_BYTES <= 160 * 1024, "tconv_down: LDS");
+  hipError_t e = hipFuncSetAttribute((const void*)tconv_down_kernel<KEPI>, hipFuncAttributeMaxDynamicSharedMemorySize, TcdGeo::LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((tconv_down_kernel<KEPI>), dim3((unsigned)grid), dim3(512), TcdGeo::LDS_BYTES, s, a);
+  e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+
+// pack (>= kTcdPackBytes) is written here: the weights change once per optimiser step, the pack is one small launch per call
+inline int launch_tconv_down(const DownArgs& a, const float* w, char* pack, hipStream_t s) {
+  typedef TcdGeo T;
+  hipLaunchKernelGGL(tconv_down_pack_kernel, dim3((T::NCH * T::NST * T::CS * 4 + 255) / 256), dim3(256), 0, s, w, pack);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  DownArgs b = a;
+  b.w = reinterpret_cast<const float*>(pack);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  const int grid = a.nimg < cus ? a.nimg : cus;
+  return a.epi == REPO_EPI_MUL_DRELU ? launch_tconv_down_k<REPO_EPI_MUL_DRELU>(b, grid, s) : launch_tconv_down_k<REPO_EPI_NONE>(b, grid, s);
+}
+
+}  // namespace repo

@@ -197,6 +197,26 @@ def test_conv_down(ops, layer, nimg):
     assert relerr(got, F.conv2d(big.double(), w.double(), None, stride=2) * (h > 0)) < TOL
 
 
+@pytest.mark.parametrize("nimg", [37, 600])   # 600: workgroups that take two or three images each (persistent grid), ragged
+def test_conv_down_decoder_conv3_staging_and_multiplying_waves(ops, nimg):
+    """Decoder conv3's data gradient from 32 images up runs on csrc/tconv_down.h (one persistent workgroup per CU: four waves
+    stage image b + 1's channel chunks and the weight ring while four multiply image b): against fp64, without and with the
+    ReLU mask of the saved activation, and the images must not leak into each other (an image's result is the same alone)."""
+    layer = 5
+    big, small, w, rs = _layer_tensors(ops, layer, nimg, 4100 + nimg)
+    big[::7] *= 20.0
+    want = F.conv2d(big.double(), w.double(), None, stride=2)
+    got = ops.conv_down(layer, dev(big), dev(w), None, epi=ops.EPI_NONE)
+    assert relerr(got, want) < TOL
+    h = F.relu(rnd(rs, *small.shape))
+    got_m = ops.conv_down(layer, dev(big), dev(w), None, epi=ops.EPI_MUL_DRELU, aux=dev(h))
+    assert relerr(got_m, want * (h > 0)) < TOL
+    assert torch.equal(got_m.cpu(), torch.where(h > 0, got.cpu(), torch.zeros(())))   # the mask selects, bit for bit
+    sub = [0, 1, nimg // 2, nimg - 1] + list(range(3, 3 + 32))    # >= 32 images: the same kernel, other workgroup <-> image map
+    got_s = ops.conv_down(layer, dev(big[sub]), dev(w), None, epi=ops.EPI_NONE)
+    assert torch.equal(got_s.cpu(), got.cpu()[sub])
+
+
 def test_conv_down_u8(ops):
     rs = np.random.RandomState(3)
     obs = torch.from_numpy(rs.randint(0, 256, size=(6, 3, 64, 64)).astype(np.uint8))
