@@ -2,23 +2,31 @@
 // matrix pipe ("bf16x6", bgemm.h) with waves that ONLY stage beside waves that ONLY multiply.
 //
 //   small[img][cs][sy][sx] = sum_{cb,ky,kx} big[img][cb][2sy+ky][2sx+kx] w[cs][cb][ky][kx]
-//   M = cs (A = weights), N = the 169 pixels of ONE image (11 tiles of 16), K = (8 channels of a chunk) x (4 taps) per MFMA
+//   M = cs (A = weights), N = the 169 pixels of ONE image (12 tiles of <= 16), K = (8 channels of a chunk) x (4 taps) per MFMA
 //
 // bconv.h stages, then multiplies, all waves in turn: a fifth of its time is staging that nothing hides
 // (profiles/r05_bconv_ablation.txt).  Here, as in twgrad.h / tconv_up.h:
 //   * `big` is staged CHANNEL-INNERMOST -- per image and 8-channel chunk three bf16 planes [row][column parity][x/2][8 ch],
-//     16 B per pixel (43 KB; two buffers) -- so the B fragment of v_mfma_f32_16x16x32_bf16 (column = pixel, a lane group's
-//     8 k = the chunk's 8 channels at ONE tap) is one ds_read_b128 per plane at
-//        base(pixel) + (ky * row + (kx & 1) * parity plane + (kx >> 1) * 16 B)(tap of the lane's group),
+//     16 B per pixel, the odd columns 256 B behind the even ones (44 KB; two buffers) -- so the B fragment of
+//     v_mfma_f32_16x16x32_bf16 (column = pixel, a lane group's 8 k = the chunk's 8 channels at ONE tap) is one
+//     ds_read_b128 per plane at
+//        base(pixel) + (ky * row + (kx & 1) * 256 + (kx >> 1) * 16 B)(tap of the lane's group),
 //     stride 2 and the tap in the address, no gather, no vector arithmetic per use;
+//   * conflict-free by construction (ds_read_b128 is served in four groups of sixteen NON-contiguous lanes, each holding
+//     all sixteen pixels of a tile and two neighbouring lane groups): neighbouring lane groups take the taps (ky, 2j) and
+//     (ky, 2j+1) (256 B apart: the same banks), and lane ln of a tile takes a pixel of bank slot ln = (14 sy + sx) mod 16,
+//     one per tile in row order -- twelve tiles of at most sixteen pixels (sixteen CONSECUTIVE pixels of 13-pixel rows never
+//     fill the sixteen slots);
 //   * the weights arrive pre-split and fragment-ready from a pack (tconv_down_pack_kernel): per (chunk, 4 taps)
-//     [plane][cs][lane group = tap][8 ch] = 12 KB, streamed from L2 (all workgroups read the same 442 KB:
-//     profiles/r05_l2_weight_stream.txt) through an LDS ring of two 3-step groups by the staging waves;
-//   * a PERSISTENT workgroup per CU takes images b, b + grid, ...; 8 waves: waves 0-3 multiply -- wave = (32 cs) x (6 pixel
-//     tiles; the 12th tile is a phantom) -- waves 4-7 stage the next chunk's patch and the next group's weights; one
-//     LDS-only barrier per 3 MFMA steps (12 taps x 8 channels);
-//   * epilogue by the multiplying waves while the staging waves are already on the next image: 64-byte runs per channel
-//     (16 pixels of a tile), the ReLU operand loaded at the same addresses.
+//     [plane][16-row tile][lane group = tap][row][8 ch] = 12 KB (a tile's A fragment = 1 KB at 16 B x lane), streamed from
+//     L2 (all workgroups read the same 442 KB: profiles/r05_l2_weight_stream.txt) through an LDS ring of two 3-step groups
+//     by the staging waves;
+//   * a PERSISTENT workgroup per CU takes images b, b + grid, ...; 8 waves: waves 0-3 multiply -- wave = (32 cs) x (6 of
+//     the 12 pixel tiles), B fragments requested two (step, tile) items ahead -- waves 4-7 stage the next chunk's patch and
+//     the next group's weights; one LDS-only barrier per 3 MFMA steps (12 taps x 8 channels);
+//   * epilogue by the multiplying waves while the staging waves are already on the next image; the ReLU operand is
+//     requested a chunk before the image completes, the stores are not waited for.
+// Versions, ablations and counters: profiles/r05_tconv_down.txt.
 // Reference: autograd's input gradient of nn.ConvTranspose2d(64, 32, 6, stride 2) (models/decoder.py:43-47).
 #pragma once
 #include "bgemm.h"
@@ -41,7 +49,7 @@ struct TcdGeo {
   // the lane group's tap at step s: pair 2 s + (kg >> 1) of the 18 (ky, j) pairs, column 2 j + (kg & 1)
   static constexpr int tap_of(int s, int kg) { return ((2 * s + (kg >> 1)) / 3) * KS + 2 * ((2 * s + (kg >> 1)) % 3) + (kg & 1); }
   static constexpr int PPLANE = HB * ROWB, PBUF = 3 * PPLANE;
-  static constexpr int WPL = CS * 4 * 16;              // one plane of one step: [cs][lane group][8 ch]
+  static constexpr int WPL = CS * 4 * 16;              // one plane of one step: [16-row tile][lane group][row][8 ch]
   static constexpr int WSTEP = 3 * WPL, WGRP = GST * WSTEP;
   static constexpr int LDS_BYTES = 2 * PBUF + 2 * WGRP;
   static constexpr int NTL = 6;                        // pixel tiles per multiplying wave
@@ -138,8 +146,8 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out, 4u * (unsigned)p.nimg * T::CS * T::PS);
     const __amdgpu_buffer_rsrc_t raux = make_rsrc(KEPI == REPO_EPI_MUL_DRELU ? p.aux : p.out, 4u * (unsigned)p.nimg * T::CS * T::PS);
 
-    // the epilogue's byte offsets (image 0): cs = 32 mh + 16 m + 4 (lane >> 4) + r, px = 16 tile + (lane & 15); a pixel past
-    // the plane is out of the descriptors' range
+    // the epilogue's byte offsets (image 0): cs = 32 mh + 16 m + 4 (lane >> 4) + r, the lane's pixel of the tile; a lane
+    // without one is out of the descriptors' range
     unsigned eoff[T::NTL];
 #pragma unroll
     for (int t = 0; t < T::NTL; ++t) {
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
       if (cc == nchunks - 1)
 #endif
       {
-        // ---- the image is complete: 64-byte runs per channel (16 pixels of a tile)
+        // ---- the image is complete
 #pragma unroll
         for (int t = 0; t < T::NTL; ++t)
 #pragma unroll
