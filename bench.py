@@ -184,9 +184,12 @@ def kernel_spec(name, nimg, horizon_rows):
     if "tconv_up_kernel" in name:   # encoder conv2's data gradient in gather form (csrc/tconv_up.h): no Geo<> in its name
         return {"op": "conv_up", "layer": 1, "pipe": "bf16x6", "flop": 2.0 * nimg * 64 * 14 * 14 * 32 * 16,
                 "label": "tconv_up_kernel (encoder conv2 data gradient, gather form)"}
-    if "tconv_down_kernel" in name:   # decoder conv3's data gradient with specialised waves (csrc/tconv_down.h): no Geo<> either
-        return {"op": "conv_down", "layer": 5, "pipe": "bf16x6", "flop": 2.0 * nimg * 64 * 13 * 13 * 32 * 36,
-                "label": "tconv_down_kernel (decoder conv3 data gradient, staging + multiplying waves)"}
+    if "tconv_down_kernel" in name:   # staging + multiplying waves (csrc/tconv_down.h): TcdGeoT<KS, WB, WS, ..>, no Geo<>
+        t = re.search(r"TcdGeoT<(\d+), ?(\d+), ?(\d+)", name)
+        ks, _, ws = (int(x) for x in t.groups()) if t else (6, 30, 13)
+        lay, what = (1, "encoder conv2 forward") if ks == 4 else (5, "decoder conv3 data gradient")
+        return {"op": "conv_down", "layer": lay, "pipe": "bf16x6", "flop": 2.0 * nimg * 64 * ws * ws * 32 * ks * ks,
+                "label": f"tconv_down_kernel ({what}, staging + multiplying waves)"}
     conv = {"buconv_scatter_kernel": ("conv_up", "bf16x6"), "uconv_scatter_kernel": ("conv_up", "fp32"),
             "bconv_down_kernel": ("conv_down", "bf16x6"), "dconv_down_kernel": ("conv_down", "fp32"),
             "tconv_wgrad_kernel": ("conv_wgrad", "bf16x6"), "bconv_wgrad_kernel": ("conv_wgrad", "bf16x6"),

@@ -35,33 +35,44 @@
 
 namespace repo {
 
-struct TcdGeo {
-  static constexpr int CB = 32, CS = 64, WB = 30, HB = 30, WS = 13, PS = 169, PB = 900, KS = 6, KK = 36;
+// KS: kernel (even), WB: width = height of `big`, WS: of `small`; GST: MFMA steps per weight group (= per barrier); NTL: pixel
+// tiles per multiplying wave (2 NTL tiles of <= 16 pixels must hold every bank slot's pixels: see the kernel)
+template <int KS_, int WB_, int WS_, int GST_, int NTL_>
+struct TcdGeoT {
+  static constexpr int CB = 32, CS = 64, WB = WB_, HB = WB_, WS = WS_, PS = WS_ * WS_, PB = WB_ * WB_, KS = KS_, KK = KS_ * KS_;
+  static_assert(KS % 2 == 0 && WS == (WB - KS) / 2 + 1 && HB <= 32, "even kernel, stride 2, at most 32 rows (the staging items)");
   static constexpr int CC = 8;                         // channels per chunk
   static constexpr int NCH = CB / CC;                  // chunks per image
   static constexpr int NST = KK / 4;                   // MFMA steps (4 taps x 8 channels) per chunk
-  static constexpr int GST = 3, NGR = NST / GST;       // steps per weight group (= per barrier), groups per chunk
-  static constexpr int XH = 15, PIXB = 16;
+  static constexpr int GST = GST_, NGR = NST / GST;    // steps per weight group (= per barrier), groups per chunk
+  static constexpr int XH = (WB + 1) / 2, PIXB = 16;
   // a staged row: [column parity][x/2][8 ch], the odd columns 256 B behind the even ones -- the taps (ky, 2j) and (ky, 2j+1)
   // of a lane-group pair then read the SAME banks, which is what ds_read_b128's lane groups (half of one lane group of
   // 16, half of its neighbour: MI355X_MICROARCH.md, LDS) need to stay conflict-free
   static constexpr int PO = 256, ROWB = PO + XH * PIXB;
-  // the lane group's tap at step s: pair 2 s + (kg >> 1) of the 18 (ky, j) pairs, column 2 j + (kg & 1)
-  static constexpr int tap_of(int s, int kg) { return ((2 * s + (kg >> 1)) / 3) * KS + 2 * ((2 * s + (kg >> 1)) % 3) + (kg & 1); }
+  static_assert(XH * PIXB <= PO, "a column-parity plane of a row fits 256 B");
+  // the lane group's tap at step s: pair 2 s + (kg >> 1) of the KS * KS / 2 (ky, j) pairs, column 2 j + (kg & 1)
+  static constexpr int KP = KS / 2;
+  static constexpr int tap_of(int s, int kg) { return ((2 * s + (kg >> 1)) / KP) * KS + 2 * ((2 * s + (kg >> 1)) % KP) + (kg & 1); }
+  // a pixel's 16-byte slot in the 256-byte bank row: (SLOTSTEP sy + sx) mod 16
+  static constexpr int SLOTSTEP = (2 * ROWB / PIXB) % 16;
   static constexpr int PPLANE = HB * ROWB, PBUF = 3 * PPLANE;
   static constexpr int WPL = CS * 4 * 16;              // one plane of one step: [16-row tile][lane group][row][8 ch]
   static constexpr int WSTEP = 3 * WPL, WGRP = GST * WSTEP;
   static constexpr int LDS_BYTES = 2 * PBUF + 2 * WGRP;
-  static constexpr int NTL = 6;                        // pixel tiles per multiplying wave
+  static constexpr int NTL = NTL_;                     // pixel tiles per multiplying wave
   static constexpr int W_PER = WGRP / 16 / 256;        // 16-byte vectors per staging thread and group
-  static constexpr int QPR = 8, P_PER = 2;             // pixel quads per row (the last ends WITH the row); items per thread
-  static_assert(WGRP % (16 * 256) == 0 && 2 * QPR * HB <= 256 * P_PER && NST % GST == 0, "staging shares");
+  static constexpr int QPR = (WB + 3) / 4, P_PER = 2;  // pixel quads per row; items per staging thread
+  static_assert(WGRP % (16 * 256) == 0 && QPR == 8 && NST % GST == 0 && NCH % 2 == 0 && NGR <= 3 && NGR >= P_PER, "staging shares");
+  static constexpr size_t PACK_BYTES = (size_t)NCH * NST * WSTEP;
 };
-constexpr size_t kTcdPackBytes = (size_t)TcdGeo::NCH * TcdGeo::NST * TcdGeo::WSTEP;
+using TcdGeo = TcdGeoT<6, 30, 13, 3, 6>;     // decoder conv3's data gradient
+using TcdGeoE2 = TcdGeoT<4, 31, 14, 2, 7>;   // encoder conv2's forward
+constexpr size_t kTcdPackBytes = TcdGeo::PACK_BYTES;
 
 // one thread per (chunk, step, cs, lane group): the 8 channels of one A fragment's lane, all three planes
+template <class T>
 __global__ __launch_bounds__(256) void tconv_down_pack_kernel(const float* w, char* pack) {
-  typedef TcdGeo T;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= T::NCH * T::NST * T::CS * 4) return;
   const int kg = i & 3, cs = (i >> 2) % T::CS, st = (i >> 2) / T::CS;   // st = chunk * NST + step
@@ -78,10 +89,10 @@ __global__ __launch_bounds__(256) void tconv_down_pack_kernel(const float* w, ch
   for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x4s*>(dst + q * T::WPL) = u32x4s{pl[q][0], pl[q][1], pl[q][2], pl[q][3]};
 }
 
-// KEPI: REPO_EPI_NONE or REPO_EPI_MUL_DRELU (aux = the fp32 activation whose ReLU the gradient passes through)
-template <int KEPI>
+// KEPI: REPO_EPI_NONE, REPO_EPI_MUL_DRELU (aux = the fp32 activation whose ReLU the gradient passes through) or
+// REPO_EPI_RELU (+ bias; + the output's channel-quad mask when p.cmask: a lane's four accumulator rows ARE one channel quad)
+template <class T, int KEPI>
 __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
-  typedef TcdGeo T;
   extern __shared__ __attribute__((aligned(16))) char td_lds[];
   char* const Pb = td_lds;
   char* const Wr = td_lds + 2 * T::PBUF;
@@ -97,10 +108,11 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
     const int lane = tid & 63;
     const int mh = wid & 1, nh = wid >> 1;
     const int ln = lane & 15, kg = lane >> 4;
-    // Which pixel a lane holds in a tile.  A pixel's 16-byte slot in the 256-byte bank row is (2 sy ROWB / 16 + sx) mod 16 =
-    // (14 sy + sx) mod 16: sixteen CONSECUTIVE pixels never fill the sixteen slots (a row wrap jumps by two), and every one of
-    // ds_read_b128's four lane groups would take a second cycle.  Lane ln therefore takes the pixels of slot ln, one per
-    // tile in row order (9-12 pixels per slot: twelve tiles, 6 per wave; a lane without a pixel in a tile re-reads its first).
+    // Which pixel a lane holds in a tile.  A pixel's 16-byte slot in the 256-byte bank row is (2 sy ROWB / 16 + sx) mod 16
+    // (decoder conv3: (14 sy + sx) mod 16): sixteen CONSECUTIVE pixels never fill the sixteen slots (a row wrap jumps by two),
+    // and every one of ds_read_b128's four lane groups would take a second cycle.  Lane ln therefore takes the pixels of slot
+    // ln, one per tile in row order (decoder conv3: 9-12 pixels per slot, twelve tiles, 6 per wave; encoder conv2, rows 512 B
+    // apart: slot = sx, 14 pixels in each of 14 slots, fourteen tiles; a lane without a pixel in a tile re-reads its first).
     int pxs[T::NTL], pfirst = 0;
 #pragma unroll
     for (int t = 0; t < T::NTL; ++t) pxs[t] = -1;
@@ -108,12 +120,12 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
       int cnt = 0;
 #pragma unroll
       for (int sy = T::WS - 1; sy >= 0; --sy) {   // (descending: pfirst ends as the lowest row's)
-        const int sx = (ln + 2 * sy) & 15;
+        const int sx = (ln - T::SLOTSTEP * sy) & 15;
         if (sx < T::WS) pfirst = T::WS * sy + sx;
       }
 #pragma unroll
       for (int sy = 0; sy < T::WS; ++sy) {
-        const int sx = (ln + 2 * sy) & 15;
+        const int sx = (ln - T::SLOTSTEP * sy) & 15;
         const int idx = cnt - T::NTL * nh;
 #pragma unroll
         for (int t = 0; t < T::NTL; ++t)
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
     int toff[T::NST];
 #pragma unroll
     for (int s = 0; s < T::NST; ++s) {
-      const int pr = 2 * s + (kg >> 1), ky = pr / 3, kx = 2 * (pr - 3 * ky) + (kg & 1);
+      const int pr = 2 * s + (kg >> 1), ky = pr / T::KP, kx = 2 * (pr - T::KP * ky) + (kg & 1);
       toff[s] = ky * T::ROWB + (kx & 1) * T::PO + (kx >> 1) * T::PIXB;
     }
     const int abase = 2 * mh * 1024 + lane * 16;
@@ -154,6 +166,11 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
       eoff[t] = (4u * (unsigned)((32 * mh + 4 * kg) * T::PS + max(pxs[t], 0))) | ((unsigned)(pxs[t] >> 31) & kOobOffset);
     }
     float av[2][T::NTL][4];   // REPO_EPI_MUL_DRELU: the ReLU operand, requested a chunk before the image completes
+    float bv[2][4];           // REPO_EPI_RELU: the bias of the lane's channels
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[m][r] = (KEPI == REPO_EPI_RELU && p.bias) ? p.bias[32 * mh + 16 * m + 4 * kg + r] : 0.f;
 
     lds_barrier();   // chunk 0 and weight group 0 are staged
     int ph = 0;
@@ -194,7 +211,6 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
           load_b(fb[1], 0, 1);
         }
         constexpr int NIT = T::GST * T::NTL;
-        static_assert(NIT % 3 == 0, "the B ring restarts at slot 0 in every group");
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           const int k = it / T::NTL, t = it % T::NTL;
@@ -228,62 +244,84 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
 #endif
       {
         // ---- the image is complete
+        const int img = (int)blockIdx.x + (cc / T::NCH) * (int)gridDim.x;
 #pragma unroll
         for (int t = 0; t < T::NTL; ++t)
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+          for (int m = 0; m < 2; ++m) {
+            unsigned bits = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float x = acc[m][t][r];
               if (KEPI == REPO_EPI_MUL_DRELU) x = av[m][t][r] > 0.f ? x : 0.f;
+              if (KEPI == REPO_EPI_RELU) {
+                x = fmaxf(x + bv[m][r], 0.f);
+                bits |= (x > 0.f ? 1u : 0u) << r;
+              }
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rout, eoff[t] + ibase + 4u * (unsigned)((16 * m + r) * T::PS), 0, 0);
               acc[m][t][r] = 0.f;
             }
+            // the channel-quad mask of the output (repo_hip.h REPO_EPI_MUL_CMASK): byte (image, quad, pixel), bit = channel & 3
+            if (KEPI == REPO_EPI_RELU && p.cmask && pxs[t] >= 0)
+              p.cmask[((size_t)img * (T::CS / 4) + 8 * mh + 4 * m + kg) * T::PS + pxs[t]] = (unsigned char)bits;
+          }
       }
     }
   } else {
     // =================================================================== the staging waves
     const int t_ = tid - 256;
-    const __amdgpu_buffer_rsrc_t rbg = make_rsrc(p.big, p.big_bytes), rw = make_rsrc(p.w, (unsigned)kTcdPackBytes);
-    f32x4 rwv[T::W_PER], rpv[T::P_PER][4];
+    const __amdgpu_buffer_rsrc_t rbg = make_rsrc(p.big, p.big_bytes), rw = make_rsrc(p.w, (unsigned)T::PACK_BYTES);
+    // TWO register sets each (group gi in set gi & 1, chunk cc's patch in set cc & 1): a weight group is requested two
+    // phases before it is stored, a chunk's patch a whole chunk before (with two phases per chunk -- encoder conv2 -- one
+    // set would put a load and its store either side of ONE barrier; on decoder conv3 the second set measured neutral)
+    f32x4 rwv[2][T::W_PER], rpv[2][T::P_PER][4];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
     // weight group gi (of this workgroup's sequence): the pack is walked linearly, once per image
-    auto wload = [&](int gi) __attribute__((always_inline)) {
+    auto wload = [&](auto sc, int gi) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value;
       const unsigned base = (unsigned)(gi % (T::NCH * T::NGR)) * (unsigned)T::WGRP;
 #pragma unroll
-      for (int i = 0; i < T::W_PER; ++i) rwv[i] = VecLoad<4>::load(rw, base + 16u * (unsigned)(t_ + 256 * i));
+      for (int i = 0; i < T::W_PER; ++i) rwv[S][i] = VecLoad<4>::load(rw, base + 16u * (unsigned)(t_ + 256 * i));
     };
-    auto wstore = [&](int gi) __attribute__((always_inline)) {
+    auto wstore = [&](auto sc, int gi) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value;
       char* Wl = Wr + (gi & 1) * T::WGRP;
 #pragma unroll
-      for (int i = 0; i < T::W_PER; ++i) *reinterpret_cast<f32x4*>(Wl + 16 * (t_ + 256 * i)) = rwv[i];
+      for (int i = 0; i < T::W_PER; ++i) *reinterpret_cast<f32x4*>(Wl + 16 * (t_ + 256 * i)) = rwv[S][i];
     };
     // patch item i of chunk cc: v = t_ + 256 i -> channel quad v & 1, pixel quad q, row; a ds_write_b64 lane group (16
     // consecutive lanes) is [row & 1][q & 3][channel quad]: 8 B at 32 q + 8 cq of two rows 496 = 112 (mod 128) B apart --
-    // every one of the 32 store banks once
-    auto pload = [&](int cc) __attribute__((always_inline)) {
+    // every one of the 32 store banks once (decoder conv3; rows of 512 B: two-way).  Pixel quad q starts at column 4 q; on an
+    // even width the last quad ends WITH the row (it re-stages two pixels), on an odd one it runs one column past the row:
+    // that element lands in a slot no tap reads (x/2 = 15 of the odd plane)
+    auto x0_of = [](int q) { return T::WB % 2 == 0 ? min(4 * q, T::WB - 4) : 4 * q; };
+    auto pload = [&](auto sc, int cc) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value;
       const int img = (int)blockIdx.x + (cc / T::NCH) * (int)gridDim.x, c = cc & (T::NCH - 1);
       const unsigned dead_c = (unsigned)((nchunks - 1 - cc) >> 31);
 #pragma unroll
       for (int i = 0; i < T::P_PER; ++i) {
         const int v = t_ + 256 * i, cq = v & 1, q = ((v >> 1) & 3) | (((v >> 4) & 1) << 2), row = ((v >> 3) & 1) | ((v >> 5) << 1);
         const unsigned dead = ((unsigned)((T::HB - 1 - row) >> 31) | dead_c) & kOobOffset;
-        const int x0 = min(4 * q, T::WB - 4);   // the row's last quad ends WITH the row (it re-stages two pixels)
+        const int x0 = x0_of(q);
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch)
-          rpv[i][ch] = VecLoad<4>::load(rbg, (4u * (unsigned)((img * T::CB + T::CC * c + 4 * cq + ch) * T::PB + row * T::WB + x0)) | dead);
+          rpv[S][i][ch] = VecLoad<4>::load(rbg, (4u * (unsigned)((img * T::CB + T::CC * c + 4 * cq + ch) * T::PB + row * T::WB + x0)) | dead);
       }
     };
-    auto pstore = [&](int cc, int i) __attribute__((always_inline)) {
+    auto pstore = [&](auto sc, int cc, int i) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value;
       char* Pl = Pb + (cc & 1) * T::PBUF;
       const int v = t_ + 256 * i, cq = v & 1, q = ((v >> 1) & 3) | (((v >> 4) & 1) << 2), row = ((v >> 3) & 1) | ((v >> 5) << 1);
       if (row < T::HB) {
-        const int x0 = min(4 * q, T::WB - 4);   // even: pixel x0 + e has column parity e & 1, x/2 = x0/2 + (e >> 1)
+        const int x0 = x0_of(q);   // even: pixel x0 + e has column parity e & 1, x/2 = x0/2 + (e >> 1)
         char* base = Pl + row * T::ROWB + (x0 >> 1) * T::PIXB + cq * 8;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned a1, a2, a3, b1, b2, b3;
-          tw_split3(rpv[i][0][e], rpv[i][1][e], a1, a2, a3);
-          tw_split3(rpv[i][2][e], rpv[i][3][e], b1, b2, b3);
+          tw_split3(rpv[S][i][0][e], rpv[S][i][1][e], a1, a2, a3);
+          tw_split3(rpv[S][i][2][e], rpv[S][i][3][e], b1, b2, b3);
           char* dst = base + (e & 1) * T::PO + (e >> 1) * T::PIXB;
           *reinterpret_cast<bg_u32x2*>(dst) = bg_u32x2{a1, b1};
           *reinterpret_cast<bg_u32x2*>(dst + T::PPLANE) = bg_u32x2{a2, b2};
@@ -292,49 +330,59 @@ __global__ __launch_bounds__(512) void tconv_down_kernel(DownArgs p) {
       }
     };
 
-    // prologue: chunk 0's patch and weight group 0 in LDS; chunk 1's patch and group 1 in registers
-    pload(0);
-    wload(0);
-    pstore(0, 0);
-    pstore(0, 1);
-    wstore(0);
-    wload(1);
-    pload(1);
+    // prologue: chunk 0's patch and weight group 0 in LDS; groups 1, 2 and the patches of chunks 1, 2 in registers
+    pload(I0{}, 0);
+    wload(I0{}, 0);
+    pstore(I0{}, 0, 0);
+    pstore(I0{}, 0, 1);
+    wstore(I0{}, 0);
+    wload(I1{}, 1);
+    wload(I0{}, 2);
+    pload(I1{}, 1);
+    pload(I0{}, 2);
     lds_barrier();
-    int gi = 0;   // the group the multiplying waves are on
-    for (int cc = 0; cc < nchunks; ++cc) {
-      // group g of chunk cc is being multiplied: group gi + 1 goes to the other ring slot (free since the last barrier),
-      // chunk cc + 1's patch to the other patch buffer (free since chunk cc - 1 ended), one item per phase; the loads
-      // of chunk cc + 2 are issued in the chunk's last phase
-#pragma unroll
-      for (int g = 0; g < T::NGR; ++g) {
+    // phase g of chunk cc (its group gi = NGR cc + g is being multiplied): group gi + 1 goes to the other ring slot (free since
+    // the last barrier) and its registers take group gi + 3; chunk cc + 1's patch goes to the other patch buffer (free since
+    // chunk cc - 1 ended), one item per phase, and its registers take chunk cc + 3
+    auto phase = [&](auto pc, auto gc, int cc) __attribute__((always_inline)) {
+      constexpr int P = decltype(pc)::value, g = decltype(gc)::value;   // P = cc & 1
+      constexpr int SW = (T::NGR * P + g + 1) & 1, SP = (P + 1) & 1;    // (gi + 1) & 1;  (cc + 1) & 1
+      const int gi = T::NGR * cc + g;
 #ifndef TCD_NO_STAGE   // ablation builds (tools/build_variant.sh): results wrong, time meaningful
-        wstore(gi + 1);
-        wload(gi + 2);
-        if (g < T::P_PER) pstore(cc + 1, g);
-        if (g == T::P_PER - 1) pload(cc + 2);   // as soon as the registers are free: a phase and a half ahead of its first store
+      wstore(std::integral_constant<int, SW>{}, gi + 1);
+      wload(std::integral_constant<int, SW>{}, gi + 3);
+      if constexpr (g < T::P_PER) pstore(std::integral_constant<int, SP>{}, cc + 1, g);
+      if constexpr (g == T::P_PER - 1) pload(std::integral_constant<int, SP>{}, cc + 3);
 #endif
-        lds_barrier();
-        ++gi;
-      }
+      lds_barrier();
+    };
+    auto chunk = [&](auto pc, int cc) __attribute__((always_inline)) {
+      phase(pc, std::integral_constant<int, 0>{}, cc);
+      if constexpr (T::NGR > 1) phase(pc, std::integral_constant<int, 1>{}, cc);
+      if constexpr (T::NGR > 2) phase(pc, std::integral_constant<int, 2>{}, cc);
+    };
+    for (int cc = 0; cc < nchunks; cc += 2) {   // (NCH is even: whole pairs)
+      chunk(I0{}, cc);
+      chunk(I1{}, cc + 1);
     }
   }
 }
 
-template <int KEPI>
+template <class T, int KEPI>
 inline int launch_tconv_down_k(const DownArgs& a, int grid, hipStream_t s) {
-  static_assert(TcdGeo::LDS_BYTES <= 160 * 1024, "tconv_down: LDS");
-  hipError_t e = hipFuncSetAttribute((const void*)tconv_down_kernel<KEPI>, hipFuncAttributeMaxDynamicSharedMemorySize, TcdGeo::LDS_BYTES);
+  static_assert(T::LDS_BYTES <= 160 * 1024, "tconv_down: LDS");
+  hipError_t e = hipFuncSetAttribute((const void*)tconv_down_kernel<T, KEPI>, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((tconv_down_kernel<KEPI>), dim3((unsigned)grid), dim3(512), TcdGeo::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((tconv_down_kernel<T, KEPI>), dim3((unsigned)grid), dim3(512), T::LDS_BYTES, s, a);
   e = hipGetLastError();
   return e == hipSuccess ? REPO_OK : (int)e;
 }
 
-// pack (>= kTcdPackBytes) is written here: the weights change once per optimiser step, the pack is one small launch per call
+// pack (>= T::PACK_BYTES) is written here: the weights change once per optimiser step, the pack is one small launch per call.
+// T = TcdGeo: a.epi NONE / MUL_DRELU, no bias;  T = TcdGeoE2: a.epi RELU (+ a.bias, + a.cmask)
+template <class T>
 inline int launch_tconv_down(const DownArgs& a, const float* w, char* pack, hipStream_t s) {
-  typedef TcdGeo T;
-  hipLaunchKernelGGL(tconv_down_pack_kernel, dim3((T::NCH * T::NST * T::CS * 4 + 255) / 256), dim3(256), 0, s, w, pack);
+  hipLaunchKernelGGL(tconv_down_pack_kernel<T>, dim3((T::NCH * T::NST * T::CS * 4 + 255) / 256), dim3(256), 0, s, w, pack);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   DownArgs b = a;
@@ -346,7 +394,8 @@ inline int launch_tconv_down(const DownArgs& a, const float* w, char* pack, hipS
       cus = 256;
   }
   const int grid = a.nimg < cus ? a.nimg : cus;
-  return a.epi == REPO_EPI_MUL_DRELU ? launch_tconv_down_k<REPO_EPI_MUL_DRELU>(b, grid, s) : launch_tconv_down_k<REPO_EPI_NONE>(b, grid, s);
+  if (a.epi == REPO_EPI_RELU) return launch_tconv_down_k<T, REPO_EPI_RELU>(b, grid, s);
+  return a.epi == REPO_EPI_MUL_DRELU ? launch_tconv_down_k<T, REPO_EPI_MUL_DRELU>(b, grid, s) : launch_tconv_down_k<T, REPO_EPI_NONE>(b, grid, s);
 }
 
 }  // namespace repo

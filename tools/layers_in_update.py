@@ -20,8 +20,9 @@ def conv_flop(name):
     m = re.search(r"Geo<(\d+), (\d+), (\d+), (\d+)>", name)
     if not m and name.startswith("tconv_up_kernel"):   # encoder conv2's data gradient in gather form: no Geo<> in the name
         m = re.search(r"(\d+), (\d+), (\d+), (\d+)", "32, 64, 31, 4")
-    if not m and name.startswith("tconv_down_kernel"):   # decoder conv3's data gradient with specialised waves: likewise
-        m = re.search(r"(\d+), (\d+), (\d+), (\d+)", "32, 64, 30, 6")
+    if not m and name.startswith("tconv_down_kernel"):   # TcdGeoT<KS, WB, WS, ..>: decoder conv3's data gradient / encoder conv2's forward
+        t = re.search(r"TcdGeoT<(\d+), (\d+)", name)
+        m = re.search(r"(\d+), (\d+), (\d+), (\d+)", "32, 64, %s, %s" % ((t.group(2), t.group(1)) if t else ("30", "6")))
     if not m:
         return None
     cb, cs, hb, ks = map(int, m.groups())

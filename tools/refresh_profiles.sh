@@ -11,7 +11,7 @@ bash tools/prof_bench.sh r05_bench_join --join > /dev/null 2>&1
 python3 tools/layers_in_update.py $O/r05_bench_pipelined_kernel_stats.csv --json $O/dominant_kernel_rocprof.json --csv-name profiles/r05_bench_kernel_stats_pipelined.csv > $O/r05_layers_in_update.txt 2>&1
 python3 tools/launch_count.py $O/r05_bench_pipelined_kernel_stats.csv > $O/r05_launch_count.txt 2>&1
 bash tools/pmc.sh dec3 "buconv_scatter|uconv_scatter|tconv_down|bconv_down|dconv_down|tconv_wgrad|bconv_wgrad|dconv_wgrad|conv_slab_reduce" tools/run_micro_case.py "conv dec3" > /dev/null 2>&1
-bash tools/pmc.sh convs "buconv_scatter|uconv_scatter|tconv_up|bconv_down|dconv_down|tconv_wgrad|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv enc2" "conv enc3" "conv enc4" "conv dec2" > /dev/null 2>&1
+bash tools/pmc.sh convs "buconv_scatter|uconv_scatter|tconv_up|tconv_down|bconv_down|dconv_down|tconv_wgrad|bconv_wgrad|dconv_wgrad" tools/run_micro_case.py "conv enc2" "conv enc3" "conv enc4" "conv dec2" > /dev/null 2>&1
 bash tools/pmc.sh scan_rollout "observe_|imagine" tools/run_scan_rollout.py > /dev/null 2>&1
 bash tools/pmc.sh c3 "dconv_dec4|bdec4|Geo<3, 32|Geo<3,32" tools/run_micro_case.py "conv enc1" "conv dec4" "dec4 forward" > /dev/null 2>&1
 bash tools/pmc.sh mlp "mlp_(fwd|bwd)_kernel|wgrad_direct" tools/run_micro_case.py "mlp_fwd value" "mlp_bwd value head" "mlp_bwd actor" > /dev/null 2>&1
