@@ -750,26 +750,18 @@ class Dreamer:
         if g is None:
             g = self._capture_act_graph(belief, posterior_state, action, obs, bool(explore))
             self._act_graphs[key] = g
-        graph, sin, sout = g
+        graph, sin, sout, _scratch = g
         for dst, src in zip(sin, (belief, posterior_state, action, obs)):
             dst.copy_(src)
         graph.replay()
         return tuple(t.clone() for t in sout)
 
     def _capture_act_graph(self, belief, posterior_state, action, obs, explore):
-        dev = self.device
-        sin = tuple(t.detach().to(dev).clone().contiguous() for t in (belief, posterior_state, action, obs))
-        cur = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):  # warm-up: workspaces, lazy module state
-                self._act_eager(*sin, explore)
-        cur.wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
-            sout = self._act_eager(*sin, explore)
-        return graph, sin, tuple(sout)
+        """-> (graph, static inputs, static outputs, scratch): the graph OWNS the scratch its kernels were captured with
+        (ops.capture_graph) -- the process-wide per-stream workspaces never enter a captured region."""
+        sin = tuple(t.detach().to(self.device).clone().contiguous() for t in (belief, posterior_state, action, obs))
+        graph, sout, scratch = ops.capture_graph(lambda: self._act_eager(*sin, explore), device=self.device)
+        return graph, sin, sout, scratch
 
     def _dump_log(self):
         self.logger.record("train/step", self.step)

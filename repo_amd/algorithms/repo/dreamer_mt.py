@@ -226,26 +226,17 @@ class MultitaskDreamer(Dreamer):
         if g is None:
             g = self._capture_mt_act_graph(belief, posterior_state, action, obs, task, bool(explore))
             self._act_graphs[key] = g
-        graph, sin, sout = g
+        graph, sin, sout, _scratch = g
         for dst, src in zip(sin, (belief, posterior_state, action, obs, task)):
             dst.copy_(src)
         graph.replay()
         return tuple(t.clone() for t in sout)
 
     def _capture_mt_act_graph(self, belief, posterior_state, action, obs, task, explore):
-        dev = self.device
-        sin = tuple(t.detach().to(dev).clone().contiguous() for t in (belief, posterior_state, action, obs, task))
-        cur = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):
-                self._act_eager(*sin, explore)
-        cur.wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
-            sout = self._act_eager(*sin, explore)
-        return graph, sin, tuple(sout)
+        """As Dreamer._capture_act_graph: the graph owns its scratch."""
+        sin = tuple(t.detach().to(self.device).clone().contiguous() for t in (belief, posterior_state, action, obs, task))
+        graph, sout, scratch = ops.capture_graph(lambda: self._act_eager(*sin, explore), device=self.device)
+        return graph, sin, sout, scratch
 
     def _step_env(self, env, latent, obs, explore):
         """Filter on `obs` under env's current task, act, step once -> (latent, transition pieces)."""

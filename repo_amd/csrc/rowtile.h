@@ -27,9 +27,19 @@ struct PackArgs {
   PackJob job[kMaxJobs];
   int njobs;
 };
+// A FILL job (src == nullptr): dst[0 .. 16 N) = the 32-bit pattern `sn`.  The scans arm their exchange buffers this way,
+// inside the pack launch they issue anyway (see fill_job).
+static inline PackJob fill_job(void* dst, size_t words, unsigned pattern) {   // words % 16 == 0
+  return PackJob{nullptr, (float*)dst, (int)(words / 16), 16, (int)pattern, 0};
+}
 static __global__ __launch_bounds__(256) void pack16_kernel(PackArgs a) {
   const PackJob j = a.job[blockIdx.y];
   const int total = pad16(j.K) * j.N;
+  if (!j.src) {
+    const float v = __builtin_bit_cast(float, j.sn);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) j.dst[i] = v;
+    return;
+  }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int u = i & 3, q = i >> 2;
     const int n = q % j.N, k = 4 * (q / j.N) + u;

@@ -415,12 +415,24 @@ int scan_cs_fwd(const ScanCsFwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
   pa.job[pa.njobs++] = PackJob{P[3], Whh, 3 * d, d, d, 1};
   pa.job[pa.njobs++] = PackJob{P[10], Wbq, h, d, (int)(q.D + q.E), 1};
   pa.job[pa.njobs++] = PackJob{P[12], Wsq, s2, h, h, 1};
+  // the exchange state is armed by two FILL jobs of the same launch (flags + error word = 0, every cell of the exchange
+  // buffer = the sentinel), NOT by hipMemsetAsync: inside a captured HIP graph (the acting path) the memset nodes did not
+  // reliably take effect before the scan kernel that follows them -- replays gathered the PREVIOUS replay's cells as if
+  // they were this step's (round 6: tools/act_graph_debug.py, tools/probe/graph_memset.hip)
+  hipError_t he = hipSuccess;
+#ifdef CS_MEMSET_NODES   // (the round 3-5 form, for A/B)
   int rc = launch_pack(pa, s);
   if (rc) return rc;
-  hipError_t he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
+  he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
   if (he != hipSuccess) return (int)he;
   he = hipMemsetAsync(xbuf, 0xff, (size_t)(G * 8 * KP * 16) * sizeof(float), s);  // every cell = the sentinel
   if (he != hipSuccess) return (int)he;
+#else
+  pa.job[pa.njobs++] = fill_job(flags, (size_t)(G * NW * 32 + 32), 0u);
+  pa.job[pa.njobs++] = fill_job(xbuf, (size_t)(G * 8 * KP * 16), 0xFFFFFFFFu);
+  int rc = launch_pack(pa, s);
+  if (rc) return rc;
+#endif
   if (q.T == 0) return REPO_OK;
   CsFwdArgs a;
   a.T = (int)q.T; a.B = (int)q.B; a.A = (int)q.A; a.D = d; a.Hd = h; a.S = (int)q.S;
@@ -807,12 +819,20 @@ int scan_cs_bwd(const ScanCsBwd& q, void* ws, size_t ws_bytes, hipStream_t s) {
     pa.job[pa.njobs++] = PackJob{P[2] + (size_t)g * d * d, WihT + g * pack_floats(d, d), d, d, 1, d};
   }
   pa.job[pa.njobs++] = PackJob{P[0], WsaT, (int)q.S, d, 1, X};
+  hipError_t he = hipSuccess;
+#ifdef CS_MEMSET_NODES
   int rc = launch_pack(pa, s);
   if (rc) return rc;
-  hipError_t he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
+  he = hipMemsetAsync(flags, 0, (size_t)(G * NW * 32 + 32) * sizeof(unsigned), s);
   if (he != hipSuccess) return (int)he;
   he = hipMemsetAsync(xbuf, 0xff, (size_t)(G * 20 * KP * 16) * sizeof(float), s);  // every cell = the sentinel
   if (he != hipSuccess) return (int)he;
+#else   // armed inside the pack launch (see scan_cs_fwd)
+  pa.job[pa.njobs++] = fill_job(flags, (size_t)(G * NW * 32 + 32), 0u);
+  pa.job[pa.njobs++] = fill_job(xbuf, (size_t)(G * 20 * KP * 16), 0xFFFFFFFFu);
+  int rc = launch_pack(pa, s);
+  if (rc) return rc;
+#endif
   CsBwdArgs a;
   a.T = (int)q.T; a.B = (int)q.B; a.A = (int)q.A; a.D = d; a.Hd = h; a.S = (int)q.S;
   a.WsqT = WsqT; a.WbqT = WbqT; a.WhhT = WhhT; a.WihT = WihT; a.WsaT = WsaT;

@@ -68,9 +68,13 @@ def cond_encoder_bwd(p, obs, cond, saved, dembeds, g, accumulate=False, side=Non
     dfilm = torch.empty_like(film)
     packs = [None] + [ops.conv_up_pack(_ENC_L[l], p[2 * l]) for l in (1, 2, 3)]
     dh = ops.relu_mask(dembeds.reshape(hs[3].shape).contiguous(), hs[3])
+    dys = []   # every d y_l stays alive until fk.join(): the side stream's weight-gradient kernel of layer l still reads
+    #            d y_l while this stream moves on, and a block freed here is handed to this stream's NEXT allocation
+    #            (the caching allocator orders reuse on the allocating stream only)
     for l in (3, 2, 1, 0):
         dy = (ops.film_bwd_h(dh, hs[l], film, *_ENC_OFF[l], dfilm) if ys is None
               else ops.film_bwd(dh, ys[l], film, *_ENC_OFF[l], dfilm))
+        dys.append(dy)
         below = hs[l - 1] if l > 0 else obs
         fk.run(lambda l=l, dy=dy, below=below: ops.conv_wgrad(_ENC_L[l], dy, below, dw=g[2 * l], db=g[2 * l + 1],
                                                              accumulate=accumulate))
@@ -78,6 +82,7 @@ def cond_encoder_bwd(p, obs, cond, saved, dembeds, g, accumulate=False, side=Non
             dh = ops.conv_up(_ENC_L[l], dy, p[2 * l], None, epi=ops.EPI_MUL_DRELU, aux=hs[l - 1], pack=packs[l])
     _film_grads(dfilm, cond, g[8], g[9], accumulate)
     fk.join()
+    del dys
 
 
 # ----------------------------------------------------------------------------- decoder

@@ -5,7 +5,9 @@ and the current HIP stream to librepo_hip.so, and returns the output tensor.  Py
 used for device memory and streams only -- there is no eager/CPU fallback here: a missing
 library or a CPU tensor raises.
 """
+import contextlib
 import os
+import threading
 
 import torch
 
@@ -59,18 +61,66 @@ def _stream():
 
 
 _ws = {}
+_scope = threading.local()   # .pool: the scratch dict of the innermost scratch_scope() of this thread, if any
 
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, current stream): reuse is stream-ordered, and work
-    running concurrently on a side stream never shares scratch with the main stream."""
+    running concurrently on a side stream never shares scratch with the main stream.
+
+    The buffers live in a process-wide dict -- except inside `scratch_scope()`, whose dict the caller owns.  A HIP
+    graph bakes the POINTERS of the scratch its kernels were captured with, so a captured region must never see the
+    process-wide dict: a later, larger request on a stream with the same raw handle (PyTorch hands out 32 handles
+    round-robin) replaces that entry, the old block returns to the allocator, and every replay of the graph then
+    scribbles (the scans start with a 0xFF fill = NaN) over whatever tensor has been given the block since.  Use
+    `capture_graph()`, which owns its scratch for the graph's lifetime."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, _raw_stream(idx))
-    buf = _ws.get(key)
+    pool = getattr(_scope, "pool", None)
+    if pool is None:
+        pool = _ws
+    buf = pool.get(key)
     if buf is None or buf.numel() < nbytes:
+        if pool is _ws and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("repo_amd.ops: scratch requested under stream capture outside ops.scratch_scope(); "
+                               "capture through ops.capture_graph() so that the graph owns its scratch")
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws[key] = buf
+        pool[key] = buf
     return buf
+
+
+@contextlib.contextmanager
+def scratch_scope(pool=None):
+    """Every workspace() request of this thread inside the block is served from `pool` (a dict the caller keeps alive
+    for as long as anything launched inside may still run -- a graph: for as long as it can be replayed)."""
+    pool = {} if pool is None else pool
+    prev = getattr(_scope, "pool", None)
+    _scope.pool = pool
+    try:
+        yield pool
+    finally:
+        _scope.pool = prev
+
+
+def capture_graph(fn, device=None, warmup=2):
+    """Capture `fn()` (a no-grad launch sequence over STATIC input tensors that returns a tuple of output tensors) into
+    a HIP graph.  Returns (graph, outputs, keep): replay with graph.replay(); `keep` owns every scratch buffer the
+    captured kernels hold pointers to and must live as long as the graph.  Warm-up (lazy state, scratch sizing) runs
+    on a side stream, as torch asks for before a capture; warm-up and capture see ONLY the graph's own scratch."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    keep = {}
+    with scratch_scope(keep), torch.no_grad():
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = tuple(fn())
+    return graph, outs, keep
 
 
 def _f32c(t):

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "loops: an end-to-end environment-loop / checkpoint test (ordered last under -x)")
 
 
 @pytest.fixture(scope="session")
@@ -17,14 +18,78 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+# Order of the GPU suite under `-x`: the hot path is judged FIRST -- op-level parity of every kernel, then the scans and
+# the rollout, then the plain-path reference goldens, then the full-size oracle comparisons, then the sibling
+# algorithms; the end-to-end environment loops / checkpoint round trips (anything marked `loops`) run last, so a failure
+# there can never hide the parity evidence of the kernels.
+_FILE_RANK = {"test_ops_gpu.py": 0, "test_rssm_gpu.py": 1, "test_update_gpu.py": 2, "test_host_gpu.py": 3,
+              "test_tia_gpu.py": 4, "test_mt_gpu.py": 5}
+
+
+def _rank(item):
+    fname = os.path.basename(str(item.fspath))
+    late = item.get_closest_marker("loops") is not None
+    return (1 if late else 0, _FILE_RANK.get(fname, 6))
+
+
 def pytest_collection_modifyitems(config, items):
-    """`gpu`-marked tests need a HIP device: skip (not fail) them where there is none, so a plain
-    `pytest tests` on a CPU-only box runs the host-side suite to the end."""
+    """Sort (stable) by _rank; `gpu`-marked tests need a HIP device: skip (not fail) them where there is none, so a
+    plain `pytest tests` on a CPU-only box runs the host-side suite to the end."""
     import torch
 
+    items.sort(key=_rank)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="needs a real MI355X (no HIP device visible)")
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NaN poison (REPO_TEST_POISON=0 turns it off).  Fresh device memory reads as zeros and recycled memory mostly holds old
+# finite floats, so a kernel that reads a byte nobody wrote usually gets away with it -- until a box hands it a block
+# that last held 0xFF bytes (the scans' exchange buffers, byte masks).  Under `-m gpu`:
+#   (1) every torch.empty / torch.empty_like of a HIP tensor made during a test (the package allocates outputs and
+#       scratch with nothing else) comes back filled with 0xFF bytes = NaN as float32, -1 as an integer;
+#   (2) before each test the allocator's cache is dropped and a large block is filled with 0xFF and handed back, so
+#       anything allocated behind torch's own operators starts from NaN too.
+_POISON = os.environ.get("REPO_TEST_POISON", "1") == "1"
+_POISON_BYTES = int(os.environ.get("REPO_TEST_POISON_GB", "16")) << 30
+
+
+def _poisoned(real):
+    import torch
+
+    def make(*args, **kwargs):
+        t = real(*args, **kwargs)
+        if t.is_cuda and t.numel() and t.is_contiguous() and kwargs.get("out") is None:
+            t.view(-1).view(torch.uint8).fill_(0xFF)
+        return t
+
+    make.__wrapped__ = real
+    return make
+
+
+@pytest.fixture(autouse=True)
+def _nan_poison(request, monkeypatch):
+    if not _POISON or "gpu" not in request.keywords:
+        yield
+        return
+    import torch
+
+    if not torch.cuda.is_available():
+        yield
+        return
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    nb = min(_POISON_BYTES, int(free * 0.5))
+    if nb > 0:
+        blk = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        blk.fill_(0xFF)
+        del blk   # stays in the allocator's cache: the test's large allocations are carved out of it
+    monkeypatch.setattr(torch, "empty", _poisoned(torch.empty))
+    monkeypatch.setattr(torch, "empty_like", _poisoned(torch.empty_like))
+    yield
+    torch.cuda.synchronize()

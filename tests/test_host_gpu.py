@@ -166,6 +166,7 @@ def test_offline_adoption_through_device_mirror_matches_reference_golden():
                     assert np.array_equal(g, w.astype(g.dtype)), (trunc, f, k)
 
 
+@pytest.mark.loops
 def test_train_agent_runs_from_buffer():
     agent, cfg = make_agent("repo", 8, 4, 5, 6)
     cfg.train_steps = 3
@@ -221,6 +222,7 @@ def test_acting_path_matches_oracle():
     np.testing.assert_allclose(b2.cpu().numpy(), ob.numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.loops
 def test_checkpoint_roundtrip_and_reference_layout(tmp_path):
     agent, cfg = make_agent("repo", 8, 4, 5, 6)
     batch, _ = dev_batch(8, 4, 6, 3)
@@ -645,6 +647,7 @@ def _describe(v):
     raise TypeError(type(v))
 
 
+@pytest.mark.loops
 @pytest.mark.parametrize("algo", ["dreamer", "repo"])
 def test_checkpoint_structure_equals_reference_manifest(golden_dir, algo):
     """get_param_dict() after one update has the structure the REFERENCE's has (tests/golden/
@@ -693,6 +696,7 @@ def test_checkpoint_structure_equals_reference_manifest(golden_dir, algo):
                 assert _describe(vv) == m["values"][kk], (k, kk)
 
 
+@pytest.mark.loops
 def test_load_reference_format_checkpoint():
     """A param dict in the REFERENCE's format (built from the manifest: plain state_dicts, torch.optim.Adam
     state with 0-dim float32 `step`, a requires-grad `log_beta` leaf) loads, and is returned value for value."""
@@ -781,6 +785,7 @@ class DumpLogger(Logger):
         self.dumps.append((step, dict(self.kv)))
 
 
+@pytest.mark.loops
 def test_train_and_eval_loops_on_fake_env(tmp_path):
     """Dreamer.train() / eval_agent() (reference dreamer.py:403-490) end to end on a fake environment:
     seed collection stops at an episode boundary, every environment step is stored, the periodic jobs
@@ -801,6 +806,15 @@ def test_train_and_eval_loops_on_fake_env(tmp_path):
     for name in ("train_agent", "eval_agent", "save_checkpoint"):
         orig = getattr(agent, name)
         setattr(agent, name, (lambda o, n: (lambda: (calls.append((n, agent.step)), o())[1]))(orig, name))
+    recons = []   # every reconstruction eval_agent() makes, before postprocess() clips it to bytes
+    orig_rec = agent._reconstruct
+
+    def rec(b, s_):
+        out = orig_rec(b, s_)
+        recons.append(out.float().cpu().numpy())
+        return out
+
+    agent._reconstruct = rec
     agent.train()
     # seed data: whole episodes only, at least `prefill` transitions
     n_seed = 27  # 3 episodes of 9 >= 20
@@ -823,6 +837,10 @@ def test_train_and_eval_loops_on_fake_env(tmp_path):
     # evaluation: deterministic policy, one episode, video of (observed, reconstructed) frames
     kv = agent.logger.kv
     assert "test/return" in kv and kv["test/success"] == 1.0
+    assert not agent.logger.nonfinite, agent.logger.nonfinite   # nothing the loops EVER logged may be garbage
+    assert all(np.isfinite(r).all() and np.abs(r).max() < 1e3 for r in recons), "eval_agent reconstructed garbage"
+    assert len(recons) == 2 * hor
+    assert np.isfinite(agent.buffer.actions[:len(agent.buffer)]).all()
     vid = kv["test/video"]
     assert vid.fps == 30 and vid.frames.shape == (2, hor, 3, 64, 64) and vid.frames.dtype == np.uint8
     assert ("test/video", "stdout") in agent.logger.history
@@ -837,6 +855,7 @@ def test_train_and_eval_loops_on_fake_env(tmp_path):
     assert agent2.step == 0 and len(agent2.buffer) == n_seed + 1     # written at step 0, after that step's push
 
 
+@pytest.mark.loops
 def test_load_offline_data_through_agent(tmp_path):
     """load_checkpoint() falls back to load_offline_data() when no buffer.npz exists and load_offline is set
     (dreamer.py:522-535); the adopted ring feeds train_agent()."""

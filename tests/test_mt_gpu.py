@@ -360,6 +360,7 @@ class FakeMtEnv:
         return self.rs.randint(0, 256, (3, 64, 64)).astype(np.uint8), float(self._ind), self._t >= 7, {"success": self._ind == 1}
 
 
+@pytest.mark.loops
 def test_mt_train_eval_loops_buffer_and_checkpoint(tmp_path):
     """train() / eval_agent() end to end on a fake multitask environment: seed data with task labels, batches from the
     HBM mirror of the five-field ring equal to host sampling, per-task logging in the reference's keys, acting path
@@ -380,6 +381,8 @@ def test_mt_train_eval_loops_buffer_and_checkpoint(tmp_path):
     agent.train()
     assert len(agent.buffer) >= 30 + 16
     assert set(np.unique(agent.buffer.tasks[: len(agent.buffer)].sum(1))) == {1.0}
+    assert not logger.nonfinite, logger.nonfinite     # nothing the loops EVER logged may be garbage
+    assert np.isfinite(agent.buffer.actions[: len(agent.buffer)]).all()
     for k in ("train/beta_0", "train/beta_2", "train/kl_div", "train/obs_loss", "train/actor_loss"):
         assert k in logger.kv and math.isfinite(logger.kv[k]), k
     assert any(k.startswith("test/return_") for k in logger.kv) and any(k.startswith("train/return_") for k in logger.kv)

@@ -188,6 +188,7 @@ def test_tia_full_size_b50_matches_oracle_scalars():
         assert abs(gn[name] - w) < 2e-3 * w
 
 
+@pytest.mark.loops
 def test_tia_checkpoint_roundtrip_and_reconstruct(tmp_path):
     L, B, H, A = 6, 3, 4, 6
     agent, cfg = make_tia(L, B, H, A, tia_reward_train_steps=2)
@@ -388,6 +389,7 @@ def test_finetuned_repo_matches_reference_golden_and_oracle(golden_dir):
     assert torch.equal(agent.model_optimizer.flat[: agent.encoder_optimizer.numel][: enc_flat.numel()][:32], enc_flat[:32])
 
 
+@pytest.mark.loops
 def test_finetuned_repo_train_agent_and_source_checkpoint(tmp_path):
     """train_agent() = encoder steps on replay batches; load_source_models() adopts a reference-layout models.pt."""
     L, B, H, A = 6, 3, 4, 6

@@ -7,6 +7,7 @@ replay batches; log_beta within 1e-5 absolute.  Latents after the first update a
 1e-4; after later updates at 2e-3 absolute (Adam's sign-like early steps amplify fp32 rounding;
 see tests/test_oracle_golden.py for the same effect between two CPU runs).
 """
+import math
 import os
 from types import SimpleNamespace
 
@@ -46,9 +47,12 @@ class Logger:
 
     def __init__(self):
         self.kv = {}
+        self.nonfinite = []
 
     def record(self, k, v, exclude=None):
         self.kv[k] = v
+        if isinstance(v, (float, np.floating)) and not math.isfinite(v):
+            self.nonfinite.append((k, float(v)))    # every non-finite scalar ever logged, not only the last value per key
 
     def dump(self, step=None):
         pass
