@@ -178,6 +178,15 @@ def kernel_spec(name, nimg, horizon_rows):
     `name` is a rocprofv3 kernel name (any prefix / template spelling)."""
     import re
 
+    spec = _kernel_spec(name, nimg, horizon_rows)
+    if spec is not None:
+        spec["kernel_name"] = name
+    return spec
+
+
+def _kernel_spec(name, nimg, horizon_rows):
+    import re
+
     m = re.search(r"Geo<(\d+), ?(\d+), ?(\d+), ?(\d+)>", name)
     geo = tuple(int(x) for x in m.groups()) if m else None
     layer = _CONV_GEO.get(geo)
@@ -332,7 +341,7 @@ def under_profiler():
 
 
 ROCPROF_SUMMARY = os.path.join(ROOT, "profiles", "dominant_kernel_rocprof.json")
-LARGEST_LAUNCH = "buconv_scatter_kernel<Geo<32, 64, 30, 6>>"   # decoder conv3 forward: the update's largest single product
+LARGEST_LAUNCH = "buconv_scatter_kernel<Geo<32, 64, 30, 6>, BSConf<Geo<32, 64, 30, 6>, 1, 4> >"   # decoder conv3 forward: the update's largest single product (full template spelling: the committed counters are matched on it)
 
 
 def trace_summary():
@@ -378,7 +387,10 @@ def _roofline_obj(timer, row, nimg):
         out["share_of_kernel_time"] = row.get("share_of_kernel_time")
     if os.path.exists(PMC_SUMMARY):
         pmc = json.load(open(PMC_SUMMARY)).get("kernels", {})
-        key = next((k for k in pmc if k.split("<")[0] in spec["label"] and _geo_of(k) == _geo_of(spec["label"])), None)
+        # the counters of THIS instantiation only: the full template spelling must agree (a name prefix or the Geo<>
+        # tuple alone would also match another tile / wave configuration of the same kernel)
+        want = _norm_kernel(spec.get("kernel_name", ""))
+        key = next((k for k in pmc if _norm_kernel(k) == want), None)
         if key and pmc[key].get("nimg") == nimg:
             out["traffic"] = pmc[key].get("traffic_bytes_per_launch")
             out["traffic_source"] = "profiles/dominant_kernel_pmc.json <- " + str(pmc[key].get("source"))
@@ -386,11 +398,13 @@ def _roofline_obj(timer, row, nimg):
     return out
 
 
-def _geo_of(name):
+def _norm_kernel(name):
+    """A rocprofv3 kernel name without return type, namespace, argument list and blanks."""
     import re
 
-    m = re.search(r"Geo<(\d+), ?(\d+), ?(\d+), ?(\d+)>", name)
-    return tuple(int(x) for x in m.groups()) if m else None
+    name = re.sub(r"^void\s+", "", name.strip())
+    name = re.sub(r"\(.*$", "", name)          # the demangled argument list, if any
+    return name.replace("repo::", "").replace(" ", "")
 
 
 def roofline(top_timer, big_timer, nimg):

@@ -33,7 +33,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define REPO_ABI_VERSION 7
+#define REPO_ABI_VERSION 8
 
 #define REPO_OK 0
 #define REPO_E_BADARG (-1)
@@ -86,6 +86,11 @@ int repo_take_status(unsigned* sticky, unsigned* taken, hipStream_t stream);
  * governs the launches that thread issues afterwards (it is read when an entry point is called, never by a kernel);
  * other threads -- e.g. the driver of another stream -- keep their own, default, settings.  The library therefore has
  * no process-global mutable state beyond the once-initialised per-device architecture cache.
+ * Consequence for callers that split a forward and its backward over host threads (torch.autograd runs a Function's
+ * backward on its own device thread): a setting made on the thread that ran the forward does NOT reach the backward.
+ * repo_amd's autograd wrappers (algorithms/repo/autograd.py) therefore record the four settings in forward and re-apply
+ * them around their backward (ops.debug_snapshot / ops.debug_scope); a workspace size queried under one setting must be
+ * consumed under the same one.
  *
  * Polls a spin-wait of the column-split scans makes before it gives up (default 1 << 22; `polls` < 0 restores it);
  * tests/test_rssm_gpu.py::test_scan_timeout_* set 0 to see the status word of repo_rssm_observe_fwd / _bwd raised;
@@ -331,14 +336,21 @@ size_t repo_mlp_fwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden
 int repo_mlp_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
                  const float* x, int64_t ldx, const float* const* params, float* const* hidden_out,
                  float* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t stream);
-/* dparams NULL: frozen weights (FreezeParameters, dreamer.py:306-317); dx NULL: detached input. */
+/* dparams NULL: frozen weights (FreezeParameters, dreamer.py:306-317); dx NULL: detached input.
+ * dout_w (ABI v8, nullable; out_dim == 1, lddout == 1, dparams and dx given): TWO upstream gradients through ONE reverse
+ * chain -- dx is the input gradient of `dout` over all rows, dparams the weight gradients of `dout_w` over the first
+ * rows_w <= rows rows.  A scalar head's reverse chain is, per row, the chain of a unit upstream times that row's scalar,
+ * so the chain runs once (on upstream 1) and its two products leave scaled by dout[row] / dout_w[row].  The
+ * actor-critic update differentiates the value head twice per update -- the actor's loss through the lambda-returns
+ * into the imagined states (dreamer.py:343-359, weights frozen) and the critic's own loss into its weights
+ * (dreamer.py:362-373, inputs detached): same rows, same activations, two scalars per row. */
 size_t repo_mlp_bwd_workspace_bytes(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
                                     int n_layers);
 int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int n_layers,
                  const float* x, int64_t ldx, const float* const* params,
                  const float* const* hidden_acts, const float* dout, int64_t lddout,
                  float* const* dparams, int accumulate_w, float* dx, int64_t lddx, int accumulate_dx,
-                 void* ws, size_t ws_bytes, hipStream_t stream);
+                 const float* dout_w, int64_t rows_w, void* ws, size_t ws_bytes, hipStream_t stream);
 
 /* Actor distribution head (models/actor_critic.py:84-87,89-102): raw (rows,2A) ->
  * mean = mean_scale*tanh(raw_m/mean_scale), std = softplus(raw_s+init_std)+min_std.
@@ -486,10 +498,21 @@ int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh, const flo
 int repo_film_tables(int64_t nimg, int nlayers, const int* channels, const float* film, int64_t ldfilm, float* tables,
                      hipStream_t stream);
 /* repo_film_bwd when the layer ran with REPO_EPI_FILM_RELU and only its OUTPUT h = relu((1 + gamma) y + beta) exists:
- * y = (h - beta) / (1 + gamma) wherever dh != 0 (there h > 0); a plane whose 1 + gamma is exactly 0 contributes no
- * gamma gradient.  Relative error of the recovered y: eps * |beta| / |(1 + gamma) y|. */
+ * y = (h - beta) / (1 + gamma) wherever dh != 0 (there h > 0) -- for planes with |1 + gamma| >= 1/16 (the recovered y
+ * then carries at most (1 + 32 |beta| / |y|) roundings).  A plane below that -- a channel the FiLM layer has (nearly)
+ * gated off for that image's task, where the recovery loses y -- RECOMPUTES its y exactly from the layer's own input,
+ * weights and bias (ABI v8), described by
+ *   conv_kind 1: the stride-2 convolution of repo_conv_down, geo = {CB, CS, HB, KS}, x = its `big` input (uint8 frames if
+ *                x_is_u8, normalised like repo_conv_down does), w (CS, CB, KS, KS), bias (CS); planes = small channels;
+ *   conv_kind 2: its transpose (repo_conv_up), x = the `small` input, same w, bias (CB); planes = big channels;
+ *   conv_kind 3: dense (the decoder's 1 x 1 -> 5 x 5 first layer), geo = {K}: y[n][c*P + p] = bias[c] + sum_k x[n][k] w[k][c*P + p];
+ *   conv_kind 0: no description (geo / x / w / bias unused): every plane is recovered, and one whose 1 + gamma is
+ *                exactly 0 contributes no gamma gradient -- the round-5 behaviour, kept for callers without the inputs.
+ * The reference differentiates the saved conv output itself (models/encoder.py:84-87, models/decoder.py:117-122). */
 int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* h, const float* film,
-                    int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm, hipStream_t stream);
+                    int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm, int conv_kind,
+                    const int64_t* geo, const void* x, int x_is_u8, const float* w, const float* bias,
+                    hipStream_t stream);
 /* MultitaskRePo's KL balance (repo_mt.py:75-93): the Lagrange multiplier is PER ROW, beta_row = exp(lb_row) with
  * lb_row = tasks[row] . log_beta (tasks (rows, C) one-hot, log_beta (C), C <= 13).  Gradients (nullable) of
  *   scale * sum_rows beta_row * (alpha*KL(sg q||p) + (1-alpha)*KL(q||sg p)),
@@ -516,6 +539,12 @@ int repo_dual_step_tasks(int64_t C, float* log_beta, float* exp_avg, float* exp_
  * activations -- torch's counterpart is the .t() view that at::mm resolves inside the BLAS call. */
 int repo_transpose(int64_t rows, int64_t cols, const float* src, int64_t lds, float* dst, int64_t ldd,
                    hipStream_t stream);
+/* 1 if a product of this size (C (M x N) over K) is one repo_gemm runs on the bf16x6 engine -- the engine whose NT form
+ * (both operands k-contiguous) is worth a transposing copy of an operand (ABI v8) -- under the calling thread's
+ * repo_debug_bgemm setting, else 0.  Sizes only: the caller still checks what the engine asks of the operands themselves
+ * (leading dimensions % 4 == 0, 16-byte aligned pointers) and leaves them as they are otherwise -- repo_gemm then takes
+ * the fp32-MFMA tile engines on the untransposed operands, as it did before the NT forms existed. */
+int repo_gemm_nt_pays(int64_t M, int64_t N, int64_t K);
 
 /* ------------------------------------------------------------------ optimiser
  * *sqnorm = sum g^2 over a flat, 16-byte aligned buffer (global norm of

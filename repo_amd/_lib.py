@@ -83,7 +83,7 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = [_ctype(t) for t, _ in params]
         fn.restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "constchar*": ctypes.c_char_p}[ret]
-    if L.repo_abi_version() != 7:
+    if L.repo_abi_version() != 8:
         raise RepoHipError("librepo_hip.so ABI version mismatch")
     _lib = L
     return L

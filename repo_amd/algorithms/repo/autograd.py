@@ -21,13 +21,14 @@ class _EncoderFn(torch.autograd.Function):
         p = _det(params)
         obs = obs.contiguous()
         embeds, saved = Fn.encoder_fwd(p, obs)
-        ctx.obs, ctx.p, ctx.saved = obs, p, saved
+        ctx.obs, ctx.p, ctx.saved, ctx.dbg = obs, p, saved, ops.debug_snapshot()
         return embeds
 
     @staticmethod
     def backward(ctx, dembeds):
         g = [torch.empty_like(t) for t in ctx.p]
-        Fn.encoder_bwd(ctx.p, ctx.obs, ctx.saved, dembeds.contiguous(), g)
+        with ops.debug_scope(ctx.dbg):
+            Fn.encoder_bwd(ctx.p, ctx.obs, ctx.saved, dembeds.contiguous(), g)
         return (None, *g)
 
 
@@ -40,14 +41,15 @@ class _DecoderFn(torch.autograd.Function):
     def forward(ctx, feat, *params):
         p = _det(params)
         recon, saved = Fn.decoder_fwd(p, feat)
-        ctx.feat, ctx.p, ctx.saved = feat, p, saved
+        ctx.feat, ctx.p, ctx.saved, ctx.dbg = feat, p, saved, ops.debug_snapshot()
         return recon
 
     @staticmethod
     def backward(ctx, drecon):
         g = [torch.empty_like(t) for t in ctx.p]
         dfeat = torch.empty_like(ctx.feat) if ctx.needs_input_grad[0] else None
-        Fn.decoder_bwd(ctx.p, ctx.feat, (*ctx.saved, drecon.contiguous()), g, dfeat=dfeat)
+        with ops.debug_scope(ctx.dbg):
+            Fn.decoder_bwd(ctx.p, ctx.feat, (*ctx.saved, drecon.contiguous()), g, dfeat=dfeat)
         return (dfeat, *g)
 
 
@@ -61,7 +63,7 @@ class _MlpFn(torch.autograd.Function):
     def forward(ctx, feat, *params):
         p = _det(params)
         out, hid = ops.mlp_fwd(p, feat)
-        ctx.feat, ctx.p, ctx.hid = feat, p, hid
+        ctx.feat, ctx.p, ctx.hid, ctx.dbg = feat, p, hid, ops.debug_snapshot()
         return out
 
     @staticmethod
@@ -69,7 +71,8 @@ class _MlpFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[1:])
         g = [torch.empty_like(t) for t in ctx.p] if need_w else None
         dfeat = torch.empty_like(ctx.feat) if ctx.needs_input_grad[0] else None
-        ops.mlp_bwd(ctx.p, ctx.feat, ctx.hid, dout.contiguous(), dparams=g, dx=dfeat)
+        with ops.debug_scope(ctx.dbg):
+            ops.mlp_bwd(ctx.p, ctx.feat, ctx.hid, dout.contiguous(), dparams=g, dx=dfeat)
         return (dfeat, *(g if g is not None else [None] * len(ctx.p)))
 
 
@@ -85,7 +88,7 @@ class _ObserveFn(torch.autograd.Function):
         sv = ops.rssm_observe_fwd(p, prev_belief.contiguous(), prev_state.contiguous(), actions.contiguous(),
                                   nonterms.contiguous(), embeds.contiguous(), eps_prior.contiguous(),
                                   eps_post.contiguous(), min_std)
-        ctx.p, ctx.sv, ctx.min_std = p, sv, min_std
+        ctx.p, ctx.sv, ctx.min_std, ctx.dbg = p, sv, min_std, ops.debug_snapshot()
         D = sv.D
         outs = (sv.featx[1:, :, :D], sv.prior_state, sv.prior_mean, sv.prior_std, sv.featx[1:, :, D:], sv.post_mean,
                 sv.post_std)
@@ -99,9 +102,10 @@ class _ObserveFn(torch.autograd.Function):
         dembeds = torch.empty_like(sv.embeds) if ctx.needs_input_grad[3] else None
         dpb = torch.empty_like(sv.featx[0, :, : sv.D]).contiguous() if ctx.needs_input_grad[0] else None
         dpst = torch.empty_like(sv.featx[0, :, sv.D :]).contiguous() if ctx.needs_input_grad[1] else None
-        ops.rssm_observe_bwd(ctx.p, sv, g, dfeat=dfeat, dprior_state=dps_.contiguous(), dpm=dpm.contiguous(),
-                             dps=dpsd.contiguous(), dqm=dqm.contiguous(), dqs=dqsd.contiguous(), dembeds=dembeds,
-                             dprev_belief=dpb, dprev_state=dpst, min_std=ctx.min_std)
+        with ops.debug_scope(ctx.dbg):   # the engine switches / spin limit of the thread that ran the forward
+            ops.rssm_observe_bwd(ctx.p, sv, g, dfeat=dfeat, dprior_state=dps_.contiguous(), dpm=dpm.contiguous(),
+                                 dps=dpsd.contiguous(), dqm=dqm.contiguous(), dqs=dqsd.contiguous(), dembeds=dembeds,
+                                 dprev_belief=dpb, dprev_state=dpst, min_std=ctx.min_std)
         return (dpb, dpst, None, dembeds, None, None, None, None, *g)
 
 

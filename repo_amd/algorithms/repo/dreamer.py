@@ -479,20 +479,30 @@ class Dreamer:
         returns, dr, dv, ret_sum = ops.lambda_return(r_pred.view(Hm, N), v_pred.view(Hm, N), c.gamma, c.gae_lambda,
                                                      gret)
         # -- backward: heads -> entropy path (input gradient only) -> reverse rollout
+        #    The value head is differentiated for TWO losses on the same rows and activations: the actor's objective
+        #    through the lambda-returns into the imagined states (dreamer.py:343-359, weights frozen) and the critic's
+        #    own loss on detached imag[:-1] against detached returns into its weights (dreamer.py:362-373).  A scalar
+        #    head's reverse chain is per row a unit chain times the row's scalar, so ONE chain serves both
+        #    (ops.mlp_bwd, dout_w): round 5 ran it twice -- the second time on a forked side stream, with its own weight
+        #    packs -- REPO_VALUE_ONE_CHAIN=0 restores that form.
         dfeat = torch.empty(Hm * N, Fw, device=dev)
-        ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat)
-        ops.mlp_bwd(pw, feats[:nr_], r_hid, dr.view(Hm * N, 1)[:nr_], dparams=None, dx=dfeat[:nr_], accumulate_dx=True)
-        # -- critic on detached imag[:-1] against detached returns (dreamer.py:362-373), forked onto a
-        #    side stream: it needs only `returns` and the value head's saved activations (the value
-        #    weights have not changed since v_pred was computed), so it runs while the reverse
-        #    rollout (which fills only ~77 CUs) and the actor backward proceed on the main stream.
+        nv = (Hm - 1) * N
         main = torch.cuda.current_stream(dev)
         side = self._ac_side_stream or main
-        side.wait_stream(main)  # after the value head's input-gradient pass above read the weights
-        nv = (Hm - 1) * N
-        with torch.cuda.stream(side):
+        one_chain = os.environ.get("REPO_VALUE_ONE_CHAIN", "1") == "1"
+        if one_chain:
             v_sums, dv2 = ops.scalar_nll(v_pred.view(-1)[:nv], returns.view(-1), None, 1.0 / ((Hm - 1) * gN))
-            ops.mlp_bwd(pv, feats[:nv], [h[:nv] for h in v_hid], dv2.view(nv, 1), dparams=gv, dx=None)
+            ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=gv, dx=dfeat, dout_w=dv2.view(nv, 1))
+        else:
+            ops.mlp_bwd(pv, feats, v_hid, dv.view(Hm * N, 1), dparams=None, dx=dfeat)
+        ops.mlp_bwd(pw, feats[:nr_], r_hid, dr.view(Hm * N, 1)[:nr_], dparams=None, dx=dfeat[:nr_], accumulate_dx=True)
+        # -- the critic's step (one chain: only the optimiser step is left of it), forked onto a side stream: it runs
+        #    while the reverse rollout (which fills only ~77 CUs) and the actor backward proceed on the main stream
+        side.wait_stream(main)  # after the value head's backward above read the weights
+        with torch.cuda.stream(side):
+            if not one_chain:
+                v_sums, dv2 = ops.scalar_nll(v_pred.view(-1)[:nv], returns.view(-1), None, 1.0 / ((Hm - 1) * gN))
+                ops.mlp_bwd(pv, feats[:nv], [h[:nv] for h in v_hid], dv2.view(nv, 1), dparams=gv, dx=None)
             if self.dp is None:
                 self.value_optimizer.clip_and_step(c.grad_clip_norm)
         # gradient at the actor trunk's output, all (Hm+1)*N rows: rollout path on steps 0..Hm-1

@@ -590,6 +590,11 @@ extern "C" int repo_transpose(int64_t rows, int64_t cols, const float* src, int6
   return REPO_OK;
 }
 
+extern "C" int repo_gemm_nt_pays(int64_t M, int64_t N, int64_t K) {
+  static float probe[4] __attribute__((aligned(16)));   // sizes only: an aligned operand with ld % 4 == 0 stands in
+  return t_bgemm_enabled && bgemm_ok(M, N, K, true, (K + 3) / 4 * 4, true, (K + 3) / 4 * 4, probe, probe) ? 1 : 0;
+}
+
 extern "C" int repo_debug_bgemm(int enable) {
   const int prev = t_bgemm_enabled;
   t_bgemm_enabled = enable ? 1 : 0;

@@ -233,7 +233,8 @@ int mlp_fused_fwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim,
                   hipStream_t stream);
 int mlp_fused_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int L, const float* const* params,
                   const float* const* hidden_acts, const float* dout, int64_t lddout, float* const* dsave, float* dx,
-                  int64_t lddx, int accumulate_dx, void* ws, hipStream_t stream);
+                  int64_t lddx, int accumulate_dx, void* ws, hipStream_t stream, const float* dout_w = nullptr,
+                  int64_t rows_w = 0);
 
 }  // namespace repo
 
@@ -327,12 +328,23 @@ extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
                             const float* x, int64_t ldx, const float* const* params,
                             const float* const* hidden_acts, const float* dout, int64_t lddout,
                             float* const* dparams, int accumulate_w, float* dx, int64_t lddx, int accumulate_dx,
-                            void* ws, size_t ws_bytes, hipStream_t stream) {
+                            const float* dout_w, int64_t rows_w, void* ws, size_t ws_bytes, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(rows > 0 && in_dim > 0 && hidden > 0 && out_dim > 0 && n_layers >= 1, REPO_E_SHAPE);
   REPO_REQUIRE(x && params && dout && (n_layers == 1 || hidden_acts), REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_mlp_bwd_workspace_bytes(rows, in_dim, hidden, out_dim, n_layers),
                REPO_E_WS_TOO_SMALL);
+  if (dout_w) {   // two upstream gradients: dx from dout (all rows), the weight gradients from dout_w (the first rows_w rows)
+    REPO_REQUIRE(out_dim == 1 && lddout == 1 && dparams && dx && rows_w > 0 && rows_w <= rows, REPO_E_BADARG);
+    if (!(mlp_fused_ok(rows, in_dim, hidden, out_dim, n_layers) && mlp_quads_aligned(n_layers, params, hidden_acts) &&
+          ((uintptr_t)ws & 15) == 0)) {
+      // no fused chain for this shape: the two passes the one-chain form replaces
+      REPO_RC(repo_mlp_bwd(rows, in_dim, hidden, out_dim, n_layers, x, ldx, params, hidden_acts, dout, lddout, nullptr, 0,
+                           dx, lddx, accumulate_dx, nullptr, 0, ws, ws_bytes, stream));
+      return repo_mlp_bwd(rows_w, in_dim, hidden, out_dim, n_layers, x, ldx, params, hidden_acts, dout_w, 1, dparams,
+                          accumulate_w, nullptr, 0, 0, nullptr, 0, ws, ws_bytes, stream);
+    }
+  }
   const bool shape_ok = mlp_fused_ok(rows, in_dim, hidden, out_dim, n_layers);
   const bool fused = shape_ok && mlp_quads_aligned(n_layers, params, hidden_acts) && ((uintptr_t)ws & 15) == 0;
   const size_t nd = shape_ok ? (size_t)(n_layers - 1) : 2;
@@ -345,11 +357,12 @@ extern "C" int repo_mlp_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_
     float* dsave[8];
     for (int l = 0; l < n_layers - 1; ++l) dsave[l] = d0 + (size_t)l * rows * hidden;
     REPO_RC(mlp_fused_bwd(rows, in_dim, hidden, out_dim, n_layers, params, hidden_acts, dout, lddout,
-                          dparams ? dsave : nullptr, dx, lddx, accumulate_dx, (void*)(sl + slab_bytes), stream));
+                          dparams ? dsave : nullptr, dx, lddx, accumulate_dx, (void*)(sl + slab_bytes), stream, dout_w,
+                          rows_w));
     if (!dparams) return REPO_OK;
     WgradDesc jobs[kMaxWgradGroup];
-    const int nj = mlp_wgrad_jobs(jobs, rows, in_dim, hidden, out_dim, n_layers, x, ldx, hidden_acts, dout, lddout,
-                                  dsave, dparams);
+    const int nj = mlp_wgrad_jobs(jobs, dout_w ? rows_w : rows, in_dim, hidden, out_dim, n_layers, x, ldx, hidden_acts,
+                                  dout_w ? dout_w : dout, lddout, dsave, dparams);
     return gemm_wgrad_group(jobs, nj, accumulate_w, slab, slab_bytes, stream);
   }
   float* d1 = d0 + (size_t)rows * hidden;

@@ -45,6 +45,13 @@ struct MlpBwdArgs {
   const float* hid[kMaxL - 1];
   float* dsave[kMaxL - 1];  // d pre-activation of hidden layer l (rows x hidden), or null
   float* dx;                // null: skip the input gradient
+  // TWO upstream gradients through ONE chain (out_dim == 1; null: off).  A scalar head's reverse chain is, per row, the
+  // chain of a UNIT upstream times that row's scalar, so one pass serves two losses that meet in the head: it runs on
+  // upstream 1, the input gradient leaves scaled by dout[row] and the saved pre-activation gradients (the weight
+  // gradients' operands) by dout_w[row] (rows >= rows_w: 0).  The actor-critic update used to run the value head's
+  // chain twice -- d returns / d v for the actor's loss (input gradient only), the critic's own loss (weights only).
+  const float* dout_w;
+  int rows_w;
 };
 
 // acc[rb][t] += (A_rb[16 x K] * column tile t of the stream)^T, for RB row blocks sharing every weight fragment.
@@ -259,9 +266,17 @@ __device__ __forceinline__ void mlp_bwd_tile(const MlpBwdArgs& p, float* T0, flo
   const int F = p.in_dim, Hd = p.hidden, O = p.out_dim;
   WWin w0, w1;
   dense_open<BO>(w0, rw, p.W[L - 1], Hd, vw, lane);
+  const bool dual = p.dout_w != nullptr;   // (uniform; out_dim == 1)
   for (int i = tid; i < RB * kR * O; i += 512) {
     const int row = i / O, f = i % O;
-    if (row < nr) T0[(row >> 4) * TS + ai(f, row & 15)] = p.dout[(size_t)(r0 + row) * p.lddout + f];
+    if (row < nr) T0[(row >> 4) * TS + ai(f, row & 15)] = dual ? 1.f : p.dout[(size_t)(r0 + row) * p.lddout + f];
+  }
+  float sxr[RB], swr[RB];   // this lane's rows: the scalars of the two upstream gradients
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int row = r0 + rb * kR + (lane & 15);
+    sxr[rb] = (dual && row < r0 + nr) ? p.dout[(size_t)row * p.lddout] : 1.f;
+    swr[rb] = dual ? (row < p.rows_w ? p.dout_w[row] : 0.f) : 1.f;
   }
   __syncthreads();
 #pragma unroll
@@ -307,7 +322,7 @@ __device__ __forceinline__ void mlp_bwd_tile(const MlpBwdArgs& p, float* T0, flo
                 float* d = p.dx + (size_t)(r0 + row) * p.lddx + n0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                  if (n0 + r < N) d[r] = p.accumulate_dx ? d[r] + acc[rb][t][r] : acc[rb][t][r];
+                  if (n0 + r < N) d[r] = p.accumulate_dx ? fmaf(acc[rb][t][r], sxr[rb], d[r]) : acc[rb][t][r] * sxr[rb];
               }
             } else {
               f32x4v g;
@@ -315,7 +330,7 @@ __device__ __forceinline__ void mlp_bwd_tile(const MlpBwdArgs& p, float* T0, flo
               for (int r = 0; r < 4; ++r) g[r] = acc[rb][t][r] * elu_grad_from_out(hv[rb][t][r]);
               *reinterpret_cast<f32x4v*>(dst + rb * TS + ai(n0, m)) = g;
               float* sv = p.dsave[l > 0 ? l - 1 : 0];
-              if (sv && row < nr) *reinterpret_cast<f32x4v*>(sv + (size_t)(r0 + row) * Hd + n0) = g;
+              if (sv && row < nr) *reinterpret_cast<f32x4v*>(sv + (size_t)(r0 + row) * Hd + n0) = g * swr[rb];
             }
           }
         }
@@ -429,8 +444,9 @@ static int launch_bwd(const MlpBwdArgs& a, hipStream_t s) {
 // dsave[l], l < L-1: where the pre-activation gradient of hidden layer l goes (null: not kept)
 int mlp_fused_bwd(int64_t rows, int64_t in_dim, int64_t hidden, int64_t out_dim, int L, const float* const* params,
                   const float* const* hidden_acts, const float* dout, int64_t lddout, float* const* dsave, float* dx,
-                  int64_t lddx, int accumulate_dx, void* ws, hipStream_t stream) {
+                  int64_t lddx, int accumulate_dx, void* ws, hipStream_t stream, const float* dout_w, int64_t rows_w) {
   MlpBwdArgs a;
+  a.dout_w = dout_w, a.rows_w = (int)rows_w;
   a.rows = (int)rows, a.in_dim = (int)in_dim, a.hidden = (int)hidden, a.out_dim = (int)out_dim;
   a.lddout = (int)lddout, a.lddx = (int)lddx, a.accumulate_dx = accumulate_dx;
   a.dout = dout, a.dx = dx;

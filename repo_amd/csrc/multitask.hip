@@ -47,12 +47,63 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(long planes, int C, int P
 // dh is the gradient at the ReLU's INPUT (the producer -- a data-gradient kernel with the MUL_DRELU epilogue, or
 // repo_relu_mask -- has applied the mask): dy = dh * (1 + gamma); d gamma[n][c] = sum_p dh * y; d beta[n][c] = sum_p dh.
 // One wave per plane, fixed summation order.  dfilm rows are written (each (n, c) slot is owned by one plane).
-// FROM_H: `y` is the layer's OUTPUT h (the conv ran with REPO_EPI_FILM_RELU): y = (h - beta) / (1 + gamma) where dh != 0.
+// FROM_H: `y` is the layer's OUTPUT h (the conv ran with REPO_EPI_FILM_RELU): y = (h - beta) / (1 + gamma) where dh != 0
+// -- for WELL-CONDITIONED planes.  The recovered y carries an error of eps * (|h| + |beta|) / |1 + gamma|, and a plane
+// whose 1 + gamma is 0 has lost y altogether (the reference keeps the exact y: models/encoder.py:84-87), so a plane with
+// |1 + gamma| < kFilmExactBelow RECOMPUTES its y from the layer's own input, weights and bias (FilmExact: a plain
+// fp32 dot product per output element, one lane per pixel) -- a channel a task has gated off costs its planes a slow
+// exact convolution instead of a wrong gamma gradient.  With 1 / 16 the recovery's amplification stays below
+// 1 + 32 |beta| / |y| roundings.
+constexpr float kFilmExactBelow = 0.0625f;
+struct FilmExact {
+  int kind;   // 0: none (recover everywhere; a plane with 1 + gamma == 0 contributes no gamma gradient),
+              // 1: stride-2 convolution big (CB,HB,HB) -> small (CS,HS,HS), the plane is a SMALL channel (encoder layers),
+              // 2: its transpose small -> big, the plane is a BIG channel (decoder conv2 / conv3),
+              // 3: dense, y[n][c * P + p] = bias[c] + sum_k x[n][k] w[k][c * P + p] (decoder conv1: 1 x 1 -> 5 x 5)
+  int CB, CS, HB, HS, KS, K;
+  const void* x;       // the layer's input activation (kind 1: big, uint8 frames if x_u8; kind 2: small; kind 3: (nimg, K))
+  int x_u8;
+  const float* w;      // (CS, CB, KS, KS) as repo_conv_down / repo_conv_up take it; kind 3: (K, C * P)
+  const float* bias;   // per output channel (nullable)
+};
+__device__ float film_exact_y(const FilmExact& e, long n, int c, int p, int C, int P) {
+  float acc = e.bias ? e.bias[c] : 0.f;
+  if (e.kind == 1) {
+    const int oy = p / e.HS, ox = p % e.HS;
+    for (int ci = 0; ci < e.CB; ++ci)
+      for (int ky = 0; ky < e.KS; ++ky)
+        for (int kx = 0; kx < e.KS; ++kx) {
+          const size_t xi = (((size_t)n * e.CB + ci) * e.HB + 2 * oy + ky) * e.HB + 2 * ox + kx;
+          const float xv = e.x_u8 ? pix_norm(((const uint8_t*)e.x)[xi]) : ((const float*)e.x)[xi];
+          acc = fmaf(e.w[(((size_t)c * e.CB + ci) * e.KS + ky) * e.KS + kx], xv, acc);
+        }
+  } else if (e.kind == 2) {
+    const int Y = p / e.HB, X = p % e.HB;
+    const float* xs = (const float*)e.x;
+    for (int cs = 0; cs < e.CS; ++cs)
+      for (int ky = Y & 1; ky < e.KS; ky += 2) {
+        const int iy = (Y - ky) >> 1;
+        if (Y - ky < 0 || iy >= e.HS) continue;
+        for (int kx = X & 1; kx < e.KS; kx += 2) {
+          const int ix = (X - kx) >> 1;
+          if (X - kx < 0 || ix >= e.HS) continue;
+          acc = fmaf(xs[(((size_t)n * e.CS + cs) * e.HS + iy) * e.HS + ix],
+                     e.w[(((size_t)cs * e.CB + c) * e.KS + ky) * e.KS + kx], acc);
+        }
+      }
+  } else {
+    const float* xs = (const float*)e.x + (size_t)n * e.K;
+    const size_t N = (size_t)C * P, j = (size_t)c * P + p;
+    for (int k = 0; k < e.K; ++k) acc = fmaf(xs[k], e.w[(size_t)k * N + j], acc);
+  }
+  return acc;
+}
+
 template <bool FROM_H>
 __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P, const float* __restrict__ dh,
                                                        const float* __restrict__ y, const float* __restrict__ film,
                                                        int ld, int goff, int boff, float* __restrict__ dy,
-                                                       float* __restrict__ dfilm) {
+                                                       float* __restrict__ dfilm, FilmExact ex) {
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   for (long pl = wave; pl < planes; pl += nwaves) {
@@ -61,13 +112,17 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P
     const float g = 1.f + film[n * ld + goff + c];
     const float bt = FROM_H ? film[n * ld + boff + c] : 0.f;
     const float rg = (FROM_H && g != 0.f) ? 1.f / g : 0.f;
+    const bool exact = FROM_H && ex.kind != 0 && fabsf(g) < kFilmExactBelow;   // (wave-uniform)
     const float* d = dh + pl * P;
     const float* src = y + pl * P;
     float* dst = dy + pl * P;
     float sg = 0.f, sb = 0.f;
     for (int p = lane; p < P; p += 64) {
       const float v = d[p];
-      const float yy = FROM_H ? (v != 0.f ? (src[p] - bt) * rg : 0.f) : src[p];
+      float yy;
+      if (!FROM_H) yy = src[p];
+      else if (v == 0.f) yy = 0.f;
+      else yy = exact ? film_exact_y(ex, n, c, p, C, P) : (src[p] - bt) * rg;
       sg = fmaf(v, yy, sg);
       sb += v;
       dst[p] = v * g;
@@ -239,22 +294,41 @@ extern "C" int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh
   long blocks = (planes + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(film_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, y,
-                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm);
+                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm, FilmExact{});
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }
 
 extern "C" int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* h, const float* film,
                                int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm,
-                               hipStream_t stream) {
+                               int conv_kind, const int64_t* geo, const void* x, int x_is_u8, const float* w,
+                               const float* bias, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(film_args_ok(nimg, C, P, ldfilm, gamma_off, beta_off), REPO_E_SHAPE);
   REPO_REQUIRE(dh && h && film && dy && dfilm, REPO_E_BADARG);
+  REPO_REQUIRE(conv_kind >= 0 && conv_kind <= 3, REPO_E_BADARG);
+  FilmExact ex{};
+  ex.kind = conv_kind;
+  if (conv_kind) {
+    REPO_REQUIRE(geo && x && w, REPO_E_BADARG);
+    ex.x = x; ex.x_u8 = x_is_u8 ? 1 : 0; ex.w = w; ex.bias = bias;
+    if (conv_kind == 3) {
+      REPO_REQUIRE(geo[0] > 0 && geo[0] < (1 << 20) && !x_is_u8, REPO_E_SHAPE);
+      ex.K = (int)geo[0];
+    } else {
+      const int64_t CB = geo[0], CS = geo[1], HB = geo[2], KS = geo[3];
+      REPO_REQUIRE(CB > 0 && CS > 0 && KS > 0 && HB >= KS && CB < 4096 && CS < 4096 && HB < 4096, REPO_E_SHAPE);
+      const int64_t HS = (HB - KS) / 2 + 1;
+      ex.CB = (int)CB; ex.CS = (int)CS; ex.HB = (int)HB; ex.HS = (int)HS; ex.KS = (int)KS;
+      // the plane the FiLM acts on is the layer's OUTPUT: a small channel for the convolution, a big one for its transpose
+      REPO_REQUIRE(conv_kind == 1 ? (C == CS && P == HS * HS) : (C == CB && P == HB * HB && !x_is_u8), REPO_E_SHAPE);
+    }
+  }
   const long planes = nimg * C;
   long blocks = (planes + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(film_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, h,
-                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm);
+                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm, ex);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }

@@ -72,10 +72,11 @@ def cond_encoder_bwd(p, obs, cond, saved, dembeds, g, accumulate=False, side=Non
     #            d y_l while this stream moves on, and a block freed here is handed to this stream's NEXT allocation
     #            (the caching allocator orders reuse on the allocating stream only)
     for l in (3, 2, 1, 0):
-        dy = (ops.film_bwd_h(dh, hs[l], film, *_ENC_OFF[l], dfilm) if ys is None
+        below = hs[l - 1] if l > 0 else obs
+        dy = (ops.film_bwd_h(dh, hs[l], film, *_ENC_OFF[l], dfilm,
+                             exact=(ops.FILM_CONV_DOWN, _ENC_L[l], below, p[2 * l], p[2 * l + 1])) if ys is None
               else ops.film_bwd(dh, ys[l], film, *_ENC_OFF[l], dfilm))
         dys.append(dy)
-        below = hs[l - 1] if l > 0 else obs
         fk.run(lambda l=l, dy=dy, below=below: ops.conv_wgrad(_ENC_L[l], dy, below, dw=g[2 * l], db=g[2 * l + 1],
                                                              accumulate=accumulate))
         if l > 0:
@@ -134,7 +135,10 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
 
     def fbwd(dh, l):   # the FiLM backward of decoder layer l (0 .. 2): from y_l if it was saved, else from h_l
         if ys is None:
-            return ops.film_bwd_h(dh, (h1, h2, h3)[l], film, *_DEC_OFF[l], dfilm)
+            # (a plane whose 1 + gamma is nearly 0 recomputes y from the layer itself: ops.film_bwd_h)
+            exact = ((ops.FILM_DENSE, h0.shape[1], h0, p[2].view(p[2].shape[0], -1), p[3]) if l == 0 else
+                     (ops.FILM_CONV_UP, (ops.DEC2, ops.DEC3)[l - 1], (h1, h2)[l - 1], p[2 + 2 * l], p[3 + 2 * l]))
+            return ops.film_bwd_h(dh, (h1, h2, h3)[l], film, *_DEC_OFF[l], dfilm, exact=exact)
         return ops.film_bwd(dh, ys[l], film, *_DEC_OFF[l], dfilm)
 
     fk = _Fork(side)

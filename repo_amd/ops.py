@@ -143,7 +143,7 @@ def gemm(A, B, transa=False, transb=False, bias=None, bias_div=1, out=None, epi=
     M, K = (A.shape[1], A.shape[0]) if transa else (A.shape[0], A.shape[1])
     N = B.shape[0] if transb else B.shape[1]
     assert (B.shape[1] if transb else B.shape[0]) == K, (A.shape, B.shape, transa, transb)
-    if not transa and not transb and min(M, N, K) >= _NT_MIN and _nt_forms():
+    if not transa and not transb and _nt_pays(M, N, K, A, B):
         B, transb = transpose(B), True     # (K, N) -> (N, K): both operands k-contiguous
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
@@ -174,6 +174,46 @@ def transpose(src, out=None):
 _NT_MIN = 512
 
 
+def _aligned(t):
+    return t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def _nt_pays(M, N, K, *operands):
+    """The transposing copy is made only for a product the bf16x6 engine will take in its NT form (the same predicate as
+    the library's dispatch: repo_gemm_nt_pays -- sizes, enough tiles to fill the chip, this thread's repo_debug_bgemm)
+    and only from operands repo_transpose and the engine accept; anything else -- N = 513, a misaligned view, a
+    data-parallel shard whose 637 rows make 125 tiles -- stays on the untransposed fp32-MFMA forms."""
+    return (min(M, N, K) >= _NT_MIN and _nt_forms() and all(_aligned(t) for t in operands)
+            and bool(lib().repo_gemm_nt_pays(M, N, K)))
+
+
+# ----------------------------------------------------------------------------- test-aid switches (thread-local in the library)
+_DEBUG_SWITCHES = ("repo_debug_scan_spin_limit", "repo_debug_bgemm", "repo_debug_bconv", "repo_debug_rowtile32")
+
+
+def debug_snapshot():
+    """The calling thread's four repo_debug_* settings (each setter returns the previous value: set, then restore)."""
+    out = []
+    for name in _DEBUG_SWITCHES:
+        fn = getattr(lib(), name)
+        prev = fn(1)
+        fn(prev)
+        out.append(prev)
+    return tuple(out)
+
+
+@contextlib.contextmanager
+def debug_scope(state):
+    """Apply a debug_snapshot() on THIS thread for the block (the autograd wrappers' backward runs on torch's device
+    thread, which would otherwise see the library's defaults)."""
+    prev = [getattr(lib(), name)(v) for name, v in zip(_DEBUG_SWITCHES, state)]
+    try:
+        yield
+    finally:
+        for name, v in zip(_DEBUG_SWITCHES, prev):
+            getattr(lib(), name)(v)
+
+
 def linear(x, w, b=None, epi=EPI_NONE, out=None):
     """F.linear(x, w, b) with a fused activation."""
     return gemm(x, w, transb=True, bias=b, epi=epi, out=out)
@@ -186,7 +226,7 @@ def gemm_wgrad(dY, X, dW=None, db=None, accumulate=False, want_bias=True):
     assert X.shape[0] == M
     if dW is None:
         dW = torch.empty(N, K, dtype=torch.float32, device=dY.device)
-    if db is None and not want_bias and min(M, N, K) >= _NT_MIN and _nt_forms():
+    if db is None and not want_bias and _nt_pays(N, K, M, dY, X):
         # dW = dY^T X as ONE product over k = rows with both operands k-contiguous
         return gemm(transpose(dY), transpose(X), transb=True, out=dW, accumulate=accumulate), None
     if db is None and want_bias:
@@ -549,7 +589,9 @@ def mlp_fwd(params, x, out=None, hid=None):
     return out, hid
 
 
-def mlp_bwd(params, x, hid, dout, dparams=None, accumulate_w=False, dx=None, accumulate_dx=False):
+def mlp_bwd(params, x, hid, dout, dparams=None, accumulate_w=False, dx=None, accumulate_dx=False, dout_w=None):
+    """dout_w (rows_w <= rows, 1): a scalar head differentiated for TWO losses in one reverse chain -- dx from `dout`
+    over all rows, dparams from `dout_w` over the first rows_w rows (include/repo_hip.h, repo_mlp_bwd)."""
     L = len(params) // 2
     rows, in_dim = x.shape
     hidden = params[0].shape[0] if L > 1 else 1
@@ -558,10 +600,14 @@ def mlp_bwd(params, x, hid, dout, dparams=None, accumulate_w=False, dx=None, acc
     ws = workspace(nb, x.device)
     pa, ha = ptr_array(params), ptr_array(hid)
     ga = ptr_array(dparams) if dparams is not None else None
+    rows_w = 0
+    if dout_w is not None:
+        rows_w = dout_w.shape[0]
+        assert dout_w.is_contiguous() and dout_w.numel() == rows_w and dout.shape[1] == 1
     check(
         lib().repo_mlp_bwd(rows, in_dim, hidden, out_dim, L, _ptr(x), _ld(x), pa, ha, _ptr(dout), _ld(dout), ga,
                            int(accumulate_w), _ptr(dx), _ld(dx) if dx is not None else 0, int(accumulate_dx),
-                           _ptr(ws), ws.numel(), _stream()),
+                           _ptr(dout_w), rows_w, _ptr(ws), ws.numel(), _stream()),
         "repo_mlp_bwd",
     )
 
@@ -860,14 +906,25 @@ def film_tables(film, channels):
     return out
 
 
-def film_bwd_h(dh, h, film, gamma_off, beta_off, dfilm, dy=None):
-    """film_bwd for a layer that ran with EPI_FILM_RELU: only its output h exists, y is recovered from it."""
+FILM_CONV_DOWN, FILM_CONV_UP, FILM_DENSE = 1, 2, 3
+
+
+def film_bwd_h(dh, h, film, gamma_off, beta_off, dfilm, dy=None, exact=None):
+    """film_bwd for a layer that ran with EPI_FILM_RELU: only its output h exists, y is recovered from it -- except on
+    planes with |1 + gamma| < 1/16, which recompute y exactly from the layer itself: exact = (FILM_CONV_DOWN | FILM_CONV_UP,
+    layer id, x, w, bias) or (FILM_DENSE, K, x (n, K), w (K, C * P), bias (C))."""
     n, C = h.shape[:2]
     P = h.numel() // (n * C)
     if dy is None:
         dy = torch.empty_like(h)
+    kind, geo, x, w, bias = 0, None, None, None, None
+    if exact is not None:
+        kind, which, x, w, bias = exact
+        geo = (ctypes.c_int64 * 4)(*(CONV_GEO[which] if kind != FILM_DENSE else (int(which), 0, 0, 0)))
+        assert x.is_contiguous() and w.is_contiguous() and x.dtype in (torch.float32, torch.uint8)
     check(lib().repo_film_bwd_h(n, C, P, _ptr(dh), _ptr(h), _ptr(film), film.shape[1], gamma_off, beta_off, _ptr(dy),
-                                _ptr(dfilm), _stream()), "repo_film_bwd_h")
+                                _ptr(dfilm), kind, geo, _ptr(x), int(x is not None and x.dtype == torch.uint8),
+                                _ptr(_f32c(w)) if w is not None else None, _ptr(bias), _stream()), "repo_film_bwd_h")
     return dy
 
 

@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import fixtures as fx
 from oracle import repo_oracle as ro
@@ -129,6 +130,88 @@ def test_film_epilogue_equals_conv_then_film():
         got = ops.conv_up(layer, x, w, bias, epi=ops.EPI_FILM_RELU, aux=tabs[l])
         assert relerr(got, want) < 2e-6, (layer, float(relerr(got, want)))
         x = want
+
+
+def test_film_backward_from_h_is_exact_on_gated_off_channels():
+    """A FiLM layer can gate a channel off for a task: 1 + gamma -> 0.  The fused form keeps only h = relu((1 + gamma) y
+    + beta); recovering y = (h - beta) / (1 + gamma) there loses it (error ~ eps |beta| / |(1 + gamma) y|; nothing at
+    all at exactly 0, where the reference still has d gamma = sum dh * y != 0 whenever beta > 0).  repo_film_bwd_h
+    recomputes y from the layer itself on planes with |1 + gamma| < 1/16: every modulated layer of both stacks, with planes
+    at gamma = -1, -1 +- 1e-4, -1 +- 0.05 and just outside the threshold, against fp64 torch autograd of the layer."""
+    from repo_amd import ops
+    from repo_amd.algorithms.repo.models.conditional import DEC_CHANNELS, ENC_CHANNELS, film_offsets
+
+    rs = np.random.RandomState(23)
+    f = lambda *s_, sc=1.0: torch.from_numpy((rs.standard_normal(s_) * sc).astype(np.float32)).cuda()  # noqa: E731
+    adversarial = np.array([-1.0, -1.0 + 1e-4, -1.0 - 1e-4, -0.95, -1.05, -0.9374, -1.0626, -0.93], dtype=np.float32)
+
+    def spiked_film(n, channels):
+        film = (rs.standard_normal((n, 2 * sum(channels))) * 0.5).astype(np.float32)
+        tot = sum(channels)
+        film[:, tot:] = np.abs(film[:, tot:]) + 0.2          # beta > 0: a gated-off plane is ACTIVE (h = beta > 0)
+        o = 0
+        for C in channels:        # every layer of the stack gets the adversarial planes, in every image
+            for i in range(n):
+                film[i, o + rs.choice(C, size=len(adversarial), replace=False)] = adversarial
+            o += C
+        return torch.from_numpy(film).cuda()
+
+    def check(name, y_fn, x, w, bias, film, off, exact):
+        """y_fn(x64, w64, b64) -> the layer's conv output in fp64 (autograd); FiLM + ReLU + a random cotangent on top."""
+        g_off, b_off = off
+        xc, fc = x.cpu(), film.cpu()
+        xs = xc.double() if xc.dtype != torch.uint8 else ((xc.double() / 255) * 2 - 1)
+        gam = fc[:, g_off:].double().clone().requires_grad_(True)
+        bet = fc[:, b_off:].double().clone().requires_grad_(True)
+        y = y_fn(xs, w.cpu().double(), bias.cpu().double())           # fp64 on the host
+        C = y.shape[1]
+        sh = (y.shape[0], C) + (1,) * (y.dim() - 2)
+        hh = torch.relu((1 + gam[:, :C].reshape(sh)) * y + bet[:, :C].reshape(sh))
+        cot = f(*y.shape).cpu().double()
+        (hh * cot).sum().backward()
+        h32 = hh.detach().float().contiguous().cuda()
+        dh = ops.relu_mask(cot.float().contiguous().cuda(), h32)
+        dfilm = torch.zeros_like(film)
+        dy = ops.film_bwd_h(dh, h32, film, g_off, b_off, dfilm, exact=exact)
+        want_g, want_b = gam.grad[:, :C].cuda(), bet.grad[:, :C].cuda()
+        got_g, got_b = dfilm[:, g_off : g_off + C].double(), dfilm[:, b_off : b_off + C].double()
+        eg = float((got_g - want_g).abs().max() / want_g.abs().max())
+        eb = float((got_b - want_b).abs().max() / want_b.abs().max())
+        scale = (1 + film[:, g_off : g_off + C]).reshape(sh)
+        edy = float((dy - dh * scale).abs().max())
+        gated = (1 + film[:, g_off : g_off + C]).abs() < 1e-3
+        assert bool(gated.any()) and float(want_g[gated].abs().max()) > 1e-2 * float(want_g.abs().max())  # they matter
+        log(f"[film gated-off] {name}: d gamma {eg:.2e} d beta {eb:.2e}")
+        assert eg < 1e-5 and eb < 1e-5 and edy == 0.0, (name, eg, eb, edy)
+        # without the layer's description the exactly-gated planes lose their gamma gradient (documented, kind 0)
+        dfilm0 = torch.zeros_like(film)
+        ops.film_bwd_h(dh, h32, film, g_off, b_off, dfilm0)
+        zero = (1 + film[:, g_off : g_off + C]) == 0
+        assert bool(zero.any()) and float(dfilm0[:, g_off : g_off + C][zero].abs().max()) == 0.0
+
+    n = 5
+    film = spiked_film(n, ENC_CHANNELS)
+    offs = film_offsets(ENC_CHANNELS)
+    x8 = torch.from_numpy(rs.randint(0, 256, (n, 3, 64, 64)).astype(np.uint8)).cuda()
+    conv = lambda xs, w, b: F.conv2d(xs, w, b, stride=2)     # noqa: E731
+    for l, layer in enumerate((ops.ENC1, ops.ENC2, ops.ENC3, ops.ENC4)):
+        (cb, hb, _), (cs, hs_, _) = ops.conv_shapes(layer)
+        w, bias = f(cs, cb, 4, 4, sc=0.1), f(cs)
+        inputs = (x8, ((x8.float() / 255) * 2 - 1).contiguous()) if l == 0 else (f(n, cb, hb, hb).abs().contiguous(),)
+        for x in inputs:
+            check(f"enc{l + 1} {x.dtype}", conv, x, w, bias, film, offs[l], (ops.FILM_CONV_DOWN, layer, x, w, bias))
+    rows = 11
+    film = spiked_film(rows, DEC_CHANNELS)
+    offs = film_offsets(DEC_CHANNELS)
+    h0, w1, b1 = f(rows, 1024, sc=0.3), f(1024, 3200, sc=0.05), f(128)
+    dense = lambda xs, w, b: (xs @ w).view(rows, 128, 25) + b.view(1, 128, 1)   # noqa: E731
+    check("dec1 (dense)", dense, h0, w1, b1, film, offs[0], (ops.FILM_DENSE, 1024, h0, w1, b1))
+    for l, layer in ((1, ops.DEC2), (2, ops.DEC3)):
+        (cb, hb, _), (cs, hs_, _) = ops.conv_shapes(layer)
+        ks = ops.CONV_GEO[layer][3]
+        w, bias, x = f(cs, cb, ks, ks, sc=0.1), f(cb), f(rows, cs, hs_, hs_).abs().contiguous()
+        tconv = lambda xs, w_, b: F.conv_transpose2d(xs, w_, b, stride=2)   # noqa: E731
+        check(f"dec{l + 1}", tconv, x, w, bias, film, offs[l], (ops.FILM_CONV_UP, layer, x, w, bias))
 
 
 @pytest.mark.parametrize("rows,C", [(1, 1), (37, 3), (2450, 3), (500, 13)])

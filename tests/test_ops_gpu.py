@@ -165,6 +165,81 @@ def test_gemm_wgrad(ops, M, N, K):
     assert float((wide[:, :20] - 2).abs().max()) == 0
 
 
+def test_gemm_nt_transposition_is_gated_like_the_engine(ops, monkeypatch):
+    """ops.gemm / ops.gemm_wgrad make their transposing copy (the bf16x6 engine's NT form) only for products that engine
+    takes and from operands repo_transpose accepts: N = 513 (ldb % 4 != 0), a misaligned view and a data-parallel
+    shard's 637 rows (125 tiles < 150) stay on the untransposed forms -- and all of them still compute the product."""
+    calls = []
+    real = ops.transpose
+    monkeypatch.setattr(ops, "transpose", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    rs = np.random.RandomState(11)
+
+    def product(M, N, K, view=False):
+        A, B = rnd(rs, M, K), rnd(rs, K, N + (1 if view else 0))
+        Bd = dev(B)[:, 1:] if view else dev(B)      # view: same ld, data pointer 4 bytes off a 16-byte boundary
+        Bh = B[:, 1:] if view else B
+        got = ops.gemm(dev(A), Bd)
+        assert relerr(got, A.double() @ Bh.double()) < TOL, (M, N, K, view)
+
+    n0 = len(calls)
+    product(2450, 3200, 1024)                  # the decoder's first layer: transposed
+    assert len(calls) == n0 + 1
+    for M, N, K, view in [(640, 513, 512, False), (2560, 1027, 512, True), (637, 3200, 1024, False), (600, 600, 100, False)]:
+        n0 = len(calls)
+        product(M, N, K, view)
+        assert len(calls) == n0, (M, N, K, view, calls[n0:])
+    # the switched-off engine: no copy either
+    prev = ops.lib().repo_debug_bgemm(0)
+    try:
+        n0 = len(calls)
+        product(2450, 3200, 1024)
+        assert len(calls) == n0
+    finally:
+        ops.lib().repo_debug_bgemm(prev)
+    # weight gradient without a bias column: both operands transposed, or none
+    for M, N, K, want in [(2450, 1024, 3200, 2), (637, 1024, 3200, 2), (2450, 513, 640, 0)]:
+        dY, X = rnd(rs, M, N), rnd(rs, M, K)
+        n0 = len(calls)
+        dW, _ = ops.gemm_wgrad(dev(dY), dev(X), want_bias=False)
+        assert relerr(dW, dY.double().t() @ X.double()) < TOL, (M, N, K)
+        assert len(calls) - n0 == want, (M, N, K, calls[n0:])
+
+
+def test_debug_switches_follow_an_autograd_function_into_its_backward_thread(ops):
+    """The repo_debug_* switches are thread-local; torch.autograd runs a Function's backward on its device thread.  The nn
+    wrappers record the forward thread's settings and re-apply them around their backward (ops.debug_scope)."""
+    import threading
+
+    from repo_amd import functional as Fn
+    from repo_amd.algorithms.repo.models.encoder import VisualEncoder
+
+    torch.manual_seed(0)
+    enc = VisualEncoder(1024).cuda()
+    seen = {}
+    real = Fn.encoder_bwd
+
+    def spy(*a, **k):
+        seen["thread"], seen["state"] = threading.get_ident(), ops.debug_snapshot()
+        return real(*a, **k)
+
+    prev = (ops.lib().repo_debug_scan_spin_limit(12345), ops.lib().repo_debug_bconv(0))
+    try:
+        Fn.encoder_bwd = spy
+        want = ops.debug_snapshot()
+        assert want[0] == 12345 and want[2] == 0
+        out = enc(torch.rand(3, 3, 64, 64, device="cuda") - 0.5)
+        out.sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        Fn.encoder_bwd = real
+        ops.lib().repo_debug_scan_spin_limit(prev[0])
+        ops.lib().repo_debug_bconv(prev[1])
+    assert seen["state"] == want, (seen, want)
+    assert ops.debug_snapshot()[0] == prev[0]
+    if seen["thread"] != threading.get_ident():      # the backward thread is back on ITS defaults afterwards
+        assert all(torch.isfinite(p.grad).all() for p in enc.parameters())
+
+
 def _layer_tensors(ops, layer, nimg, seed):
     rs = np.random.RandomState(seed)
     (cb, hb, _), (cs, hs, _) = ops.conv_shapes(layer)

@@ -118,6 +118,44 @@ def test_mlp_fwd_bwd(ops, mod, L, rows):
         assert l2err(g, v.grad) < GTOL, k
 
 
+@pytest.mark.parametrize("rows,rows_w", [(34300, 31850), (700, 650), (4100, 4100), (17, 3), (20011, 1)])
+def test_scalar_head_two_upstream_gradients_through_one_chain(ops, rows, rows_w):
+    """ops.mlp_bwd(dout_w=...): the value head differentiated for the actor's loss (input gradient, all rows) and the
+    critic's loss (weight gradients, the first rows_w rows) in ONE reverse chain -- against autograd of the two losses, and
+    against the two separate passes it replaces (dreamer.py:343-373 of the reference)."""
+    rs = np.random.RandomState(rows + rows_w)
+    p = tparams("value_model", 6)
+    feat = rnd(rs, rows, 230).requires_grad_(True)
+    want = ro.mlp_head(p, feat[:, :200], feat[:, 200:], 4)
+    up_x, up_w = rnd(rs, rows, 1, scale=1e-3), rnd(rs, rows_w, 1, scale=1e-4)
+    up_x[::7] = 0.0                                   # rows whose actor-loss gradient is exactly zero keep their critic share
+    gx, = torch.autograd.grad((want * up_x).sum(), feat, retain_graph=True)
+    gw = torch.autograd.grad((want[:rows_w] * up_w).sum(), list(p.values()))
+    fd = feat.detach().cuda()
+    _, hid = ops.mlp_fwd(cu(p), fd)
+    dparams = [torch.full_like(v, 7.0).cuda() for v in p.values()]
+    dx = torch.full((rows, 230), 3.0).cuda()
+    ops.mlp_bwd(cu(p), fd, hid, up_x.cuda(), dparams=dparams, dx=dx, dout_w=up_w.cuda())
+    for (k, v), g, w in zip(p.items(), dparams, gw):
+        e = l2err(g, w)
+        log(f"mlp one chain {rows}/{rows_w} d{k}: {e:.2e}")
+        assert e < GTOL, (k, e)
+    assert l2err(dx, gx) < GTOL
+    # the two passes: same numbers up to rounding
+    dp2 = [torch.zeros_like(v).cuda() for v in p.values()]
+    dx2 = torch.empty(rows, 230).cuda()
+    ops.mlp_bwd(cu(p), fd, hid, up_x.cuda(), dparams=None, dx=dx2)
+    ops.mlp_bwd(cu(p), fd[:rows_w], [h[:rows_w] for h in hid], up_w.cuda(), dparams=dp2, dx=None)
+    assert l2err(dx, dx2) < 1e-6
+    for g, g2 in zip(dparams, dp2):
+        assert l2err(g, g2) < 2e-6
+    # accumulate_dx adds the scaled chain
+    dx3 = torch.full((rows, 230), 3.0).cuda()
+    ops.mlp_bwd(cu(p), fd, hid, up_x.cuda(), dparams=[torch.zeros_like(v).cuda() for v in p.values()], dx=dx3,
+                accumulate_dx=True, dout_w=up_w.cuda())
+    assert l2err(dx3, gx + 3.0) < GTOL
+
+
 @pytest.mark.parametrize("mod,L,rows", [("value_model", 4, 20011), ("actor_model", 5, 9000)])
 def test_head_weight_gradients_on_the_bf16_pipe_match_fp64_and_the_fp32_engine(ops, mod, L, rows):
     """The dense heads' weight gradients at update-like row counts (csrc/wgrad_tr.h: both operands staged as they lie, split

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import fixtures as fx
+from oracle import repo_oracle as ro
 from oracle.repo_oracle import OracleTIA
 from tests.test_update_gpu import Env, Logger, dev_batch
 from tests.util import log
@@ -108,6 +109,48 @@ def test_tia_update_matches_reference_goldens(golden_dir, fname):
         assert abs(have[n][0] - s_) <= 1e-3 * abs(a_) + 1e-6, (n, have[n][0], s_)
 
 
+_TIE_BAND = 1e-5   # |pre-activation| below which two fp32 convolutions (max abs error 3-4e-6 EACH on these layers) cannot fix a ReLU's sign
+
+
+def _encoder_relu_decisions(agent, obs):
+    """(h_l > 0) of the HIP encoder's four layers on frames 1 .. L-1 of the batch, at the agent's current parameters."""
+    from repo_amd import functional as Fn
+
+    frames = obs[1:].reshape(-1, *obs.shape[2:]).contiguous()
+    _, saved = Fn.encoder_fwd([p.detach() for p in agent.encoder.plist()], frames)
+    torch.cuda.synchronize()
+    return [(h > 0).cpu() for h in saved[:4]]
+
+
+class _knife_edge_relu_from:
+    """Inside the block the oracle's encoder takes the kernels' ReLU decision wherever its own pre-activation lies within
+    _TIE_BAND of zero (oracle/repo_oracle.py, RELU_TIE_BREAK) -- one flipped decision of conv3 at a pre-activation 5e-7
+    from zero moves the encoder's gradient by 5e-3 (profiles/r05_tconv_down.txt, v11), and neither sign is wrong."""
+
+    def __init__(self, decisions, B):
+        self.dec, self.B, self.stat = decisions, B, {"in_band": 0, "overridden": 0}
+
+    def __enter__(self):
+        def tie_break(i, pre, h):
+            d = self.dec[i - 1]
+            if pre.shape[0] != d.shape[0] + self.B:     # (not the world-model batch: L*B frames, the kernels skip frame 0)
+                return h
+            band = pre[self.B :].detach().abs() < _TIE_BAND
+            take = band & (d != (pre[self.B :].detach() > 0))
+            self.stat["in_band"] += int(band.sum())
+            self.stat["overridden"] += int(take.sum())
+            if not bool(take.any()):
+                return h
+            keep = torch.cat([pre[: self.B].detach() > 0, torch.where(band, d, pre[self.B :].detach() > 0)])
+            return pre * keep
+        ro.RELU_TIE_BREAK = tie_break
+        return self.stat
+
+    def __exit__(self, *exc):
+        ro.RELU_TIE_BREAK = None
+        return False
+
+
 def test_tia_update_matches_oracle_grads():
     L, B, H, A = 9, 5, 5, 6
     over = dict(tia_obs_coef=0.7, tia_adv_coef=1.3, tia_reward_train_steps=2, free_nats=0.1)  # KL gradients active
@@ -124,10 +167,15 @@ def test_tia_update_matches_oracle_grads():
             orig()
 
         agent._model_step = hooked
+        decisions = _encoder_relu_decisions(agent, batch[0])     # of the parameters BEFORE this update
         beliefs, post = agent.train_dynamics(batch[0], batch[1], batch[2], 1.0 - batch[3])
         agent._model_step = orig
         agent.train_actor_critic(beliefs.flatten(0, 1), post.flatten(0, 1))
-        ob, op_, oscal = oracle.update(*host, nz)
+        with _knife_edge_relu_from(decisions, B) as ties:
+            ob, op_, oscal = oracle.update(*host, nz)
+        log(f"[oracle tia] update {u}: encoder ReLU decisions inside the +-{_TIE_BAND:g} band: {ties['in_band']}, "
+            f"taken from the kernels against the oracle's own sign: {ties['overridden']}")
+        assert ties["in_band"] < 2000 and ties["overridden"] <= 32, ties    # a handful of knife edges, not a way out
         tol = 1e-4 if u == 0 else 2e-3
         np.testing.assert_allclose(beliefs.cpu().numpy(), ob.numpy(), rtol=1e-3, atol=tol)
         for k, w in oscal.items():

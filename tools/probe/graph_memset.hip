@@ -1,7 +1,7 @@
 // Does a memset node of a captured HIP graph take effect before the kernel node that follows it on the same stream?
 // The column-split scans armed their exchange buffer with hipMemsetAsync(0xff) right before the scan kernel; under a
 // HIP-graph replay of the acting path the posterior came out as garbage on some replays (round 6, tools/act_graph_debug.py).
-// Each replay: [kernel A touches other memory] -> memset(buf, 0xff) -> memset(flags, 0) -> kernel B counts the cells of
+// Each replay: [kernel A touches other memory AND scribbles buf / flags] -> memset(flags, 0) -> memset(buf, 0xff) -> kernel B counts the cells of
 // buf that are NOT 0xFFFFFFFF / flags that are not 0, then overwrites both with data.
 //   hipcc --offload-arch=gfx950 -O2 -o tools/probe/bin/graph_memset tools/probe/graph_memset.hip
 #include <hip/hip_runtime.h>
@@ -9,8 +9,12 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-__global__ void touch(float* p, int n) {
+// kernel A also SCRIBBLES over buf / flags (as the encoder's weight packs do in the shared scratch before the scan's
+// arming): a memset that runs anywhere BEFORE kernel A in the replay -- not only one that runs too late -- is caught
+__global__ void touch(float* p, int n, unsigned* buf, int nb, unsigned* flags, int nf) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = p[i] * 0.5f + 1.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) buf[i] = 0x40000000u + i;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) flags[i] = 5u;
 }
 __global__ void check_and_scribble(unsigned* buf, int n, unsigned* flags, int nf, unsigned* bad) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -34,7 +38,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(bad, 0, 8)); CK(hipMemset(buf, 0, n * 4)); CK(hipMemset(flags, 0xff, nf * 4));
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
     auto body = [&]() {
-      hipLaunchKernelGGL(touch, dim3(256), dim3(256), 0, s, other, nt);
+      hipLaunchKernelGGL(touch, dim3(256), dim3(256), 0, s, other, nt, buf, n, flags, nf);
       CK(hipMemsetAsync(flags, 0, nf * 4, s));
       CK(hipMemsetAsync(buf, 0xff, n * 4, s));
       hipLaunchKernelGGL(check_and_scribble, dim3(13), dim3(256), 0, s, buf, n, flags, nf, bad);
