@@ -413,7 +413,14 @@ int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t H
 
 /* ------------------------------------------------------------------ losses and regularisers
  * All reductions use repo_reduce_workspace_bytes() of scratch and write device scalars
- * (no host synchronisation; the caller batches its .item() reads). */
+ * (no host synchronisation; the caller batches its .item() reads).
+ * ABI v8 -- a reduction whose grid has at most 64 blocks (the KL up to 2560 rows, the scalar heads' NLL up to 65536
+ * elements, the lambda-returns up to 16384 rows) is ONE launch: its last block sums the per-block partials in the fixed
+ * order of the follow-up launch, which larger grids still get (tickets are same-address atomics: 1000 of them cost more
+ * than the launch they would save -- measured).  The scratch of these calls (and of repo_tia_blend_nll,
+ * repo_grad_sqnorm) therefore begins with a 256-byte HEADER that must be ZERO on entry and is left zero on return (the
+ * blocks' ticket word): allocate the buffer zeroed, keep it for these calls only, one per stream (two reductions in
+ * flight on two streams must not share it).  repo_amd.ops.reduce_ws does exactly that. */
 size_t repo_reduce_workspace_bytes(void);
 
 /* KL(q||p) of diagonal Gaussians over rows x S.
@@ -548,7 +555,8 @@ int repo_gemm_nt_pays(int64_t M, int64_t N, int64_t K);
 
 /* ------------------------------------------------------------------ optimiser
  * *sqnorm = sum g^2 over a flat, 16-byte aligned buffer (global norm of
- * nn.utils.clip_grad_norm_, repo.py:89).  Fixed-order two-level sum. */
+ * nn.utils.clip_grad_norm_, repo.py:89).  Fixed-order two-level sum (two launches); ws: a reduction workspace (its
+ * header is left untouched: see "losses and regularisers"). */
 size_t repo_grad_sqnorm_workspace_bytes(void);
 int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* ws, size_t ws_bytes,
                      hipStream_t stream);

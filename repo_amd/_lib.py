@@ -34,7 +34,7 @@ def parse_header(path=HEADER):
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"//[^\n]*", "", txt)
     protos = {}
-    for m in re.finditer(r"\b(int|size_t|const char\s*\*)\s+(repo_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"\b(int|size_t|uint64_t|const char\s*\*)\s+(repo_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
         params = []
         if args and args != "void":
@@ -82,7 +82,8 @@ def lib():
     for name, (ret, params) in _protos.items():
         fn = getattr(L, name)
         fn.argtypes = [_ctype(t) for t, _ in params]
-        fn.restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "constchar*": ctypes.c_char_p}[ret]
+        fn.restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64,
+                      "constchar*": ctypes.c_char_p}[ret]
     if L.repo_abi_version() != 8:
         raise RepoHipError("librepo_hip.so ABI version mismatch")
     _lib = L

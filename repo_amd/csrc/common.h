@@ -81,6 +81,39 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats 
   return r;
 }
 
+// "The last block finishes": the tail of a SMALL-GRID reduction kernel whose blocks have each written their partials
+// parts[v][blk] (v < nvals, row pitch n = gridDim.x).  Every block calls it once, at its end, with all threads; the block
+// that takes the last ticket sums the partials in a FIXED order -- the same order and arithmetic as the one-block follow-up
+// launch (final_sum_kernel), so the result is bitwise what the two-launch form gives -- writes out[v] and puts the ticket
+// word back to 0.  `ticket` must be 0 when the kernel starts: it lives in the zeroed header of the reduction workspace
+// (repo_reduce_workspace_bytes; the Python side allocates that buffer zeroed, per stream, and nothing else writes it).
+// ticket == nullptr: nothing happens (the caller launches the follow-up kernel).
+// Only for grids of at most kLastBlockMaxGrid blocks: the tickets are same-address atomics and serialise in L2 at ~30-75 ns
+// each -- with 1000 blocks the "saved" launch cost 40-75 us (measured, round 6: sqnorm 6 -> 38 us, normal_entropy 5 -> 80,
+// kl 6 -> 51), with <= 64 it costs ~2 us against a ~5 us dependent launch.  blockDim.x == 256.
+constexpr int kRedHeaderBytes = 256;
+constexpr int kLastBlockMaxGrid = 64;
+__device__ __forceinline__ void last_block_finishes(const float* parts, int nvals, float* out, unsigned* ticket, float* smem) {
+  if (!ticket) return;   // (kernel argument: uniform)
+  __shared__ int s_last;
+  __threadfence();          // this block's partials are visible device-wide before its ticket is
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int n = gridDim.x;
+  for (int v = 0; v < nvals; ++v) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+      s += __hip_atomic_load(parts + v * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past this CU's L1
+    s = block_sum(s, smem);
+    if (threadIdx.x == 0) out[v] = s;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------------- noise

@@ -2,7 +2,8 @@
 // Gaussian NLL of the scalar heads, Monte-Carlo tanh-Normal entropy, Normal entropy,
 // lambda-returns.  All are HBM-bound streaming kernels: coalesced loads, wave64 shuffle
 // reductions, one partial per workgroup and a fixed-order final sum (bitwise reproducible;
-// no float atomics).
+// no float atomics) taken by the launch's LAST block (common.h, last_block_finishes: one launch
+// per reduction since round 6, same bits as the follow-up launch it replaces).
 #include "common.h"
 
 namespace repo {
@@ -20,12 +21,6 @@ __global__ void final_sum_kernel(const float* __restrict__ parts, int n, int nva
   }
 }
 
-static int final_sum(const float* parts, int n, int nvals, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, parts, n, nvals, out);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? REPO_OK : (int)e;
-}
-
 // ------------------------------------------------------------------ KL(q || p) of diagonal Gaussians
 // mode 0 (RePo, repo.py:64-83): out = sum_rows KL_row; gradients of
 //   beta * (alpha * KL(sg q || p) + (1-alpha) * KL(q || sg p)) * scale
@@ -38,7 +33,8 @@ __global__ __launch_bounds__(256) void kl_kernel(int rows, int S, const float* _
                                                  const float* __restrict__ log_beta, float free_nats, float scale,
                                                  float* __restrict__ dpm, float* __restrict__ dps,
                                                  float* __restrict__ dqm, float* __restrict__ dqs,
-                                                 float* __restrict__ parts) {
+                                                 float* __restrict__ parts, float* __restrict__ red_out,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const float beta = (mode == 0 && log_beta) ? expf(*log_beta) : 1.f;
@@ -77,6 +73,7 @@ __global__ __launch_bounds__(256) void kl_kernel(int rows, int S, const float* _
   }
   const float s = block_sum(acc, red);
   if (threadIdx.x == 0) parts[blockIdx.x] = s;
+  last_block_finishes(parts, 1, red_out, ticket, red);
 }
 
 // ------------------------------------------------------------------ dual variable (repo.py:83,93-105)
@@ -111,7 +108,8 @@ __global__ void dual_step_kernel(float* __restrict__ log_beta, float* __restrict
 __global__ __launch_bounds__(256) void scalar_nll_kernel(int n, const float* __restrict__ pred,
                                                          const float* __restrict__ target,
                                                          const float* __restrict__ mask, float scale,
-                                                         float* __restrict__ dpred, float* __restrict__ parts) {
+                                                         float* __restrict__ dpred, float* __restrict__ parts, float* __restrict__ red_out,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[16];
   float a = 0.f, msum = 0.f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -127,6 +125,7 @@ __global__ __launch_bounds__(256) void scalar_nll_kernel(int n, const float* __r
     parts[blockIdx.x] = s0;
     parts[gridDim.x + blockIdx.x] = s1;
   }
+  last_block_finishes(parts, 2, red_out, ticket, red);
 }
 
 // ------------------------------------------------------------------ Monte-Carlo entropy of tanh(Normal)
@@ -142,7 +141,8 @@ __global__ __launch_bounds__(256) void tanh_normal_entropy_kernel(int n, int NS,
                                                                   const float* __restrict__ eps, uint64_t nseed,
                                                                   uint64_t noffset, float gscale,
                                                                   float* __restrict__ dmean, float* __restrict__ dstd,
-                                                                  float* __restrict__ parts) {
+                                                                  float* __restrict__ parts, float* __restrict__ red_out,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[16];
   const float kClamp = 0.99999994f;
   const float kLog2 = 0.69314718055994531f;
@@ -195,11 +195,13 @@ __global__ __launch_bounds__(256) void tanh_normal_entropy_kernel(int n, int NS,
   }
   const float s = block_sum(acc, red);
   if (threadIdx.x == 0) parts[blockIdx.x] = s;
+  last_block_finishes(parts, 1, red_out, ticket, red);
 }
 
 // sum over elements of (0.5 + 0.5 log 2pi + log std); dstd = gscale / std   (dreamer.py:327-328)
 __global__ __launch_bounds__(256) void normal_entropy_kernel(int n, const float* __restrict__ stdv, float gscale,
-                                                             float* __restrict__ dstd, float* __restrict__ parts) {
+                                                             float* __restrict__ dstd, float* __restrict__ parts, float* __restrict__ red_out,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[16];
   float acc = 0.f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(256) void normal_entropy_kernel(int n, const float*
   }
   const float s = block_sum(acc, red);
   if (threadIdx.x == 0) parts[blockIdx.x] = s;
+  last_block_finishes(parts, 1, red_out, ticket, red);
 }
 
 // ------------------------------------------------------------------ lambda-returns (common/utils.py:61-71)
@@ -220,7 +223,8 @@ __global__ __launch_bounds__(256) void lambda_return_kernel(int Hm, int N, const
                                                             const float* __restrict__ v, float gamma, float lam,
                                                             float gret, float* __restrict__ returns,
                                                             float* __restrict__ dr, float* __restrict__ dv,
-                                                            float* __restrict__ parts) {
+                                                            float* __restrict__ parts, float* __restrict__ red_out,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[16];
   float acc = 0.f;
   const int L = Hm - 1;
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(256) void lambda_return_kernel(int Hm, int N, const
   }
   const float s = block_sum(acc, red);
   if (threadIdx.x == 0) parts[blockIdx.x] = s;
+  last_block_finishes(parts, 1, red_out, ticket, red);
 }
 
 
@@ -311,7 +316,8 @@ __global__ __launch_bounds__(256) void tia_blend_nll_kernel(int n4, int pix4, co
                                                             const float* t_out, const float* d_out,
                                                             const TgtT* __restrict__ target, float gscale, float* dt_out,
                                                             float* dd_out, float* __restrict__ recon_out,
-                                                            float* __restrict__ parts) {
+                                                            float* __restrict__ parts, float* __restrict__ red_out,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[16];
   float w[6];
 #pragma unroll
@@ -381,6 +387,7 @@ __global__ __launch_bounds__(256) void tia_blend_nll_kernel(int n4, int pix4, co
     const float sv = block_sum(acc[v], red);
     if (threadIdx.x == 0) parts[v * gridDim.x + blockIdx.x] = sv;
   }
+  last_block_finishes(parts, 8, red_out, ticket, red);
 }
 
 static inline int red_blocks(long n, int per_block) {
@@ -394,7 +401,17 @@ static inline int red_blocks(long n, int per_block) {
 
 using namespace repo;
 
-extern "C" size_t repo_reduce_workspace_bytes(void) { return 2 * kRedBlocks * sizeof(float); }
+// reduction workspace: [zeroed header: the ticket word of last_block_finishes | partials].  A grid of at most
+// kLastBlockMaxGrid blocks finishes its own sum (ticket given); a larger one gets the follow-up launch (ticket null).
+static inline float* red_parts(void* ws) { return (float*)((char*)ws + kRedHeaderBytes); }
+static inline unsigned* red_ticket(void* ws, int blocks) { return blocks <= kLastBlockMaxGrid ? (unsigned*)ws : nullptr; }
+static int red_finish(void* ws, int blocks, int nvals, float* out, hipStream_t s) {
+  if (blocks <= kLastBlockMaxGrid) return REPO_OK;   // the launch's last block has written `out`
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, red_parts(ws), blocks, nvals, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? REPO_OK : (int)e;
+}
+extern "C" size_t repo_reduce_workspace_bytes(void) { return kRedHeaderBytes + 2 * kRedBlocks * sizeof(float); }
 
 extern "C" int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const float* ps, const float* qm,
                                const float* qs, int mode, float alpha, const float* log_beta, float free_nats,
@@ -404,11 +421,11 @@ extern "C" int repo_kl_balance(int64_t rows, int64_t S, const float* pm, const f
   REPO_REQUIRE(rows > 0 && S > 0 && S <= 64 && rows * S < kMaxIdx, REPO_E_SHAPE);
   REPO_REQUIRE(pm && ps && qm && qs && kl_sum && (mode == 0 || mode == 1), REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
-  const int blocks = red_blocks(rows, 4);
+  const int blocks = red_blocks(rows, 40);   // <= 64 blocks up to 2560 rows: the launch finishes its own sum (common.h)
   hipLaunchKernelGGL(kl_kernel, dim3(blocks), dim3(256), 0, stream, (int)rows, (int)S, pm, ps, qm, qs, mode, alpha,
-                     log_beta, free_nats, scale, dpm, dps, dqm, dqs, (float*)ws);
+                     log_beta, free_nats, scale, dpm, dps, dqm, dqs, red_parts(ws), kl_sum, red_ticket(ws, blocks));
   REPO_CHECK_LAUNCH();
-  return final_sum((const float*)ws, blocks, 1, kl_sum, stream);
+  return red_finish(ws, blocks, 1, kl_sum, stream);
 }
 
 extern "C" int repo_dual_step(float* log_beta, float* exp_avg, float* exp_avg_sq, const float* kl_sum, int64_t rows,
@@ -433,12 +450,12 @@ extern "C" int repo_scalar_nll(int64_t n, const float* pred, const float* target
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
   const int blocks = red_blocks(n, 1024);
   hipLaunchKernelGGL(scalar_nll_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, pred, target, mask, scale, dpred,
-                     (float*)ws);
+                     red_parts(ws), sums2, red_ticket(ws, blocks));
   REPO_CHECK_LAUNCH();
-  return final_sum((const float*)ws, blocks, 2, sums2, stream);
+  return red_finish(ws, blocks, 2, sums2, stream);
 }
 
-extern "C" size_t repo_tia_blend_nll_workspace_bytes(void) { return 8 * kRedBlocks * sizeof(float); }
+extern "C" size_t repo_tia_blend_nll_workspace_bytes(void) { return kRedHeaderBytes + 8 * kRedBlocks * sizeof(float); }
 
 extern "C" int repo_tia_blend_nll(int64_t nimg, int64_t pixels, const float* t_out, const float* d_out,
                                   const float* mask_wb, const void* target, int target_is_u8, float grad_scale,
@@ -453,12 +470,13 @@ extern "C" int repo_tia_blend_nll(int64_t nimg, int64_t pixels, const float* t_o
   const int blocks = red_blocks(n4, 512);
   if (target_is_u8)
     hipLaunchKernelGGL(tia_blend_nll_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, (int)n4, (int)(pixels / 4),
-                       mask_wb, t_out, d_out, (const uint8_t*)target, grad_scale, dt_out, dd_out, recon, (float*)ws);
+                       mask_wb, t_out, d_out, (const uint8_t*)target, grad_scale, dt_out, dd_out, recon, red_parts(ws), sums8,
+                       red_ticket(ws, blocks));
   else
     hipLaunchKernelGGL(tia_blend_nll_kernel<float>, dim3(blocks), dim3(256), 0, stream, (int)n4, (int)(pixels / 4),
-                       mask_wb, t_out, d_out, (const float*)target, grad_scale, dt_out, dd_out, recon, (float*)ws);
+                       mask_wb, t_out, d_out, (const float*)target, grad_scale, dt_out, dd_out, recon, red_parts(ws), sums8, red_ticket(ws, blocks));
   REPO_CHECK_LAUNCH();
-  return final_sum((const float*)ws, blocks, 8, sums8, stream);
+  return red_finish(ws, blocks, 8, sums8, stream);
 }
 
 extern "C" int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,
@@ -472,9 +490,9 @@ extern "C" int repo_tanh_normal_entropy(int64_t rows, int64_t A, int64_t samples
   const long n = rows * A;
   const int blocks = red_blocks(n, 256);
   hipLaunchKernelGGL(tanh_normal_entropy_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, (int)samples, mean, std,
-                     eps, noise_seed, noise_offset, gscale, dmean, dstd, (float*)ws);
+                     eps, noise_seed, noise_offset, gscale, dmean, dstd, red_parts(ws), ent_sum, red_ticket(ws, blocks));
   REPO_CHECK_LAUNCH();
-  return final_sum((const float*)ws, blocks, 1, ent_sum, stream);
+  return red_finish(ws, blocks, 1, ent_sum, stream);
 }
 
 extern "C" int repo_normal_entropy(int64_t n, const float* std, float gscale, float* dstd, float* ent_sum, void* ws,
@@ -484,9 +502,9 @@ extern "C" int repo_normal_entropy(int64_t n, const float* std, float gscale, fl
   REPO_REQUIRE(std && ent_sum, REPO_E_BADARG);
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
   const int blocks = red_blocks(n, 1024);
-  hipLaunchKernelGGL(normal_entropy_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, std, gscale, dstd, (float*)ws);
+  hipLaunchKernelGGL(normal_entropy_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, std, gscale, dstd, red_parts(ws), ent_sum, red_ticket(ws, blocks));
   REPO_CHECK_LAUNCH();
-  return final_sum((const float*)ws, blocks, 1, ent_sum, stream);
+  return red_finish(ws, blocks, 1, ent_sum, stream);
 }
 
 extern "C" int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, const float* values, float gamma,
@@ -499,9 +517,9 @@ extern "C" int repo_lambda_return(int64_t Hm, int64_t N, const float* rewards, c
   REPO_REQUIRE(ws && ws_bytes >= repo_reduce_workspace_bytes(), REPO_E_WS_TOO_SMALL);
   const int blocks = red_blocks(N, 256);
   hipLaunchKernelGGL(lambda_return_kernel, dim3(blocks), dim3(256), 0, stream, (int)Hm, (int)N, rewards, values, gamma,
-                     lambda_, gret, returns, drewards, dvalues, (float*)ws);
+                     lambda_, gret, returns, drewards, dvalues, red_parts(ws), ret_sum, red_ticket(ws, blocks));
   REPO_CHECK_LAUNCH();
-  return final_sum((const float*)ws, blocks, 1, ret_sum, stream);
+  return red_finish(ws, blocks, 1, ret_sum, stream);
 }
 
 extern "C" int repo_tanh_normal_mode(int64_t rows, int64_t A, int64_t samples, const float* mean, const float* std,

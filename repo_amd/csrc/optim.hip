@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(int64_t n, float* __rest
 
 using namespace repo;
 
-extern "C" size_t repo_grad_sqnorm_workspace_bytes(void) { return 1024 * sizeof(float); }
+// a reduction workspace (include/repo_hip.h, "losses and regularisers"): its 256-byte header belongs to the single-launch
+// reductions' ticket and stays untouched (zero) here -- this grid (up to 1024 blocks) keeps its follow-up launch
+extern "C" size_t repo_grad_sqnorm_workspace_bytes(void) { return kRedHeaderBytes + 1024 * sizeof(float); }
 
 extern "C" int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* ws, size_t ws_bytes,
                                 hipStream_t stream) {
@@ -68,9 +70,10 @@ extern "C" int repo_grad_sqnorm(int64_t n, const float* g, float* sqnorm, void* 
   REPO_REQUIRE(ws && ws_bytes >= repo_grad_sqnorm_workspace_bytes(), REPO_E_WS_TOO_SMALL);
   long blocks = (n + 4095) / 4096;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, g, (float*)ws);
+  float* parts = (float*)((char*)ws + kRedHeaderBytes);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, g, parts);
   REPO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)blocks, sqnorm);
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)parts, (int)blocks, sqnorm);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }

@@ -394,9 +394,23 @@ def ptr_array(tensors):
     return arr
 
 
-def reduce_ws(device):
-    nb = lib().repo_reduce_workspace_bytes()
-    return workspace(nb, device)
+_REDUCE_WS_BYTES = 64 << 10   # >= every reduction's request (repo_reduce / _tia_blend_nll / _grad_sqnorm _workspace_bytes)
+
+
+def reduce_ws(device, nbytes=0):
+    """The reduction workspace of the current stream: allocated ZEROED, used by the single-launch reductions only (their
+    last block leaves the 256-byte ticket header zero again: include/repo_hip.h, "losses and regularisers").  Per
+    (device, stream) like workspace(), and owned by the innermost scratch_scope() if there is one."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = ("reduce", idx, _raw_stream(idx))
+    pool = getattr(_scope, "pool", None)
+    if pool is None:
+        pool = _ws
+    buf = pool.get(key)
+    if buf is None:
+        assert nbytes <= _REDUCE_WS_BYTES
+        buf = pool[key] = torch.zeros(_REDUCE_WS_BYTES, dtype=torch.uint8, device=device)
+    return buf
 
 
 # ----------------------------------------------------------------------------- RSSM observe
@@ -778,7 +792,7 @@ def tia_blend_nll(t_out, d_out, mask_wb, target, grad_scale, want_grads=True, wa
     dd = (d_out if inplace else torch.empty_like(d_out)) if want_grads else None
     recon = torch.empty(n, 3, *t_out.shape[2:], dtype=torch.float32, device=dev) if want_recon else None
     sums = torch.empty(8, dtype=torch.float32, device=dev)
-    ws = workspace(lib().repo_tia_blend_nll_workspace_bytes(), dev)
+    ws = reduce_ws(dev, lib().repo_tia_blend_nll_workspace_bytes())
     check(
         lib().repo_tia_blend_nll(n, pixels, _ptr(_f32c(t_out)), _ptr(_f32c(d_out)), _ptr(_f32c(mask_wb)), _ptr(target),
                                  int(target.dtype == torch.uint8), float(grad_scale), _ptr(dt), _ptr(dd), _ptr(recon),
@@ -853,8 +867,7 @@ def lambda_return(rewards, values, gamma, lambda_, gret=0.0, want_grads=True):
 def grad_sqnorm(g, out=None):
     if out is None:
         out = torch.empty(1, dtype=torch.float32, device=g.device)
-    nb = lib().repo_grad_sqnorm_workspace_bytes()
-    ws = workspace(nb, g.device)
+    ws = reduce_ws(g.device, lib().repo_grad_sqnorm_workspace_bytes())
     check(lib().repo_grad_sqnorm(g.numel(), _ptr(_f32c(g)), _ptr(out), _ptr(ws), ws.numel(), _stream()),
           "repo_grad_sqnorm")
     return out

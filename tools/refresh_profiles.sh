@@ -30,12 +30,12 @@ python3 bench.py --config mt 2>/dev/null | grep '^{' > $O/${RND}_bench_mt.json
 tools/probe/bin/bgemm_probe > $O/${RND}_bgemm_probe.txt 2>&1
 python3 tools/rowtile32_ab.py > $O/${RND}_rollout_engines.txt 2>&1
 python3 tools/layers_isolated.py gemm > $O/${RND}_gemm_isolated.txt 2>&1
-# the round's gain on ONE box: the round-4 tree (git archive c56098e -> .r4tree, built in place) against this tree, alternating
-if [ -f .r4tree/bench.py ]; then
+# the round's gain on ONE box: the round-5 tree (git archive 6f1b639 -> .r5tree, built in place) against this tree, alternating
+if [ -f .r5tree/bench.py ]; then
   (for i in 1 2 3; do
-     echo -n "r4 tree : "; (cd .r4tree && python3 bench.py --no-cpu-baseline --steps 60 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'updates/s', d['ms_per_step'], 'ms', 'resident', d['resident_batch_ms'])")
+     echo -n "r5 tree : "; (cd .r5tree && python3 bench.py --no-cpu-baseline --steps 60 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'updates/s', d['ms_per_step'], 'ms', 'resident', d['resident_batch_ms'])")
      echo -n "this tree: "; python3 bench.py --no-cpu-baseline --steps 60 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'updates/s', d['ms_per_step'], 'ms', 'resident', d['resident_batch_ms'])"
-   done) > $O/${RND}_ab_vs_round4.txt 2>&1
+   done) > $O/${RND}_ab_vs_round5.txt 2>&1
 fi
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke" > $O/${RND}_smoke.txt
 python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed" > $O/${RND}_gpu_tests.txt
