@@ -295,7 +295,23 @@ class AllReduceTimer:
     def __init__(self, dp):
         self.dp, self.pairs = dp, []
         self._orig = (dp.all_reduce, dp.all_reduce_begin, dp.all_reduce_end)
+        self._orig_small = (dp.all_reduce_status, dp.all_reduce_prefix)
         t = self
+
+        def small(which, label):
+            # the 4-byte MAX all-reduce of the update's status word and the logged scalars' prefix sum: latency-only
+            # collectives, one each per update, in line on the update's streams
+            def call(*a, **k):
+                s = torch.cuda.current_stream()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                out = t._orig_small[which](*a, **k)
+                e1.record(s)
+                t.pairs.append((label, e0, e1))
+                return out
+            return call
+
+        dp.all_reduce_status, dp.all_reduce_prefix = small(0, "status_word_max_4B"), small(1, "logged_scalars_prefix")
 
         def all_reduce(x):
             s = torch.cuda.current_stream()
@@ -323,14 +339,16 @@ class AllReduceTimer:
 
     def stop(self):
         self.dp.all_reduce, self.dp.all_reduce_begin, self.dp.all_reduce_end = self._orig
+        self.dp.all_reduce_status, self.dp.all_reduce_prefix = self._orig_small
 
     def summary(self, steps):
         torch.cuda.synchronize()
         by = {}
         for nbytes, e0, e1 in self.pairs:
             by.setdefault(nbytes, []).append(e0.elapsed_time(e1))
-        return {"rank": 0, "per_update_by_bucket_bytes": {str(k): round(sum(v) / steps, 4) for k, v in sorted(by.items())},
-                "note": "rank 0; span from issue to the consumer stream's join, summed per update"}
+        return {"rank": 0, "per_update_by_bucket_bytes": {str(k): round(sum(v) / steps, 4) for k, v in sorted(by.items(), key=lambda kv: str(kv[0]))},
+                "note": "rank 0; span from issue to the consumer stream's join, summed per update; gradient buckets by "
+                        "their bytes, the two latency-only collectives (status word MAX, logged-scalar sums) by name"}
 
 
 def under_profiler():
