@@ -418,8 +418,8 @@ int repo_rssm_imagine_bwd(int64_t Hm, int64_t N, int64_t A, int64_t D, int64_t H
  * elements, the lambda-returns up to 16384 rows) is ONE launch: its last block sums the per-block partials in the fixed
  * order of the follow-up launch, which larger grids still get (tickets are same-address atomics: 1000 of them cost more
  * than the launch they would save -- measured).  The scratch of these calls (and of repo_tia_blend_nll,
- * repo_grad_sqnorm) therefore begins with a 256-byte HEADER that must be ZERO on entry and is left zero on return (the
- * blocks' ticket word): allocate the buffer zeroed, keep it for these calls only, one per stream (two reductions in
+ * repo_grad_sqnorm) therefore begins with a 256-byte HEADER whose FIRST WORD must be zero on entry and is left zero on
+ * return (the blocks' ticket; repo_amd keeps repo_film_bwd_h's epoch word at byte 32 of the same header): allocate the buffer zeroed, keep it for these calls only, one per stream (two reductions in
  * flight on two streams must not share it).  repo_amd.ops.reduce_ws does exactly that. */
 size_t repo_reduce_workspace_bytes(void);
 
@@ -505,21 +505,25 @@ int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh, const flo
 int repo_film_tables(int64_t nimg, int nlayers, const int* channels, const float* film, int64_t ldfilm, float* tables,
                      hipStream_t stream);
 /* repo_film_bwd when the layer ran with REPO_EPI_FILM_RELU and only its OUTPUT h = relu((1 + gamma) y + beta) exists:
- * y = (h - beta) / (1 + gamma) wherever dh != 0 (there h > 0) -- for planes with |1 + gamma| >= 1/16 (the recovered y
- * then carries at most (1 + 32 |beta| / |y|) roundings).  A plane below that -- a channel the FiLM layer has (nearly)
- * gated off for that image's task, where the recovery loses y -- RECOMPUTES its y exactly from the layer's own input,
- * weights and bias (ABI v8), described by
+ * y = (h - beta) / (1 + gamma) wherever dh != 0 (there h > 0) -- for planes with |1 + gamma| >= 1e-3 (the recovered y
+ * then carries a relative error of about eps |beta| / |(1 + gamma) y|: at most ~6e-5 for |beta| ~ |y|).  A plane below
+ * that -- a channel the FiLM layer has gated off for that image's task, where the recovery loses y -- RECOMPUTES its y
+ * exactly from the layer's own input, weights and bias (ABI v8), described by
  *   conv_kind 1: the stride-2 convolution of repo_conv_down, geo = {CB, CS, HB, KS}, x = its `big` input (uint8 frames if
  *                x_is_u8, normalised like repo_conv_down does), w (CS, CB, KS, KS), bias (CS); planes = small channels;
  *   conv_kind 2: its transpose (repo_conv_up), x = the `small` input, same w, bias (CB); planes = big channels;
  *   conv_kind 3: dense (the decoder's 1 x 1 -> 5 x 5 first layer), geo = {K}: y[n][c*P + p] = bias[c] + sum_k x[n][k] w[k][c*P + p];
+ *   gated_epoch / epoch (nullable / non-zero): one device word, zero-initialised once, and a number that grows from call
+ *                to call -- the streaming pass stamps the word with this call's epoch when it meets a gated-off plane,
+ *                and the exact pass (a second launch) returns at once unless the word carries it: a layer without
+ *                gated-off planes pays a few microseconds.  NULL: the exact pass always walks every plane's scale.
  *   conv_kind 0: no description (geo / x / w / bias unused): every plane is recovered, and one whose 1 + gamma is
  *                exactly 0 contributes no gamma gradient -- the round-5 behaviour, kept for callers without the inputs.
  * The reference differentiates the saved conv output itself (models/encoder.py:84-87, models/decoder.py:117-122). */
 int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* h, const float* film,
                     int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm, int conv_kind,
                     const int64_t* geo, const void* x, int x_is_u8, const float* w, const float* bias,
-                    hipStream_t stream);
+                    unsigned* gated_epoch, unsigned epoch, hipStream_t stream);
 /* MultitaskRePo's KL balance (repo_mt.py:75-93): the Lagrange multiplier is PER ROW, beta_row = exp(lb_row) with
  * lb_row = tasks[row] . log_beta (tasks (rows, C) one-hot, log_beta (C), C <= 13).  Gradients (nullable) of
  *   scale * sum_rows beta_row * (alpha*KL(sg q||p) + (1-alpha)*KL(q||sg p)),

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("REPO_HIP_LIB") or os.path.join(HERE, "librepo_hip.so"
 
 _CT = {
     "int": ctypes.c_int,
+    "unsigned": ctypes.c_uint,
     "int64_t": ctypes.c_int64,
     "uint64_t": ctypes.c_uint64,
     "size_t": ctypes.c_size_t,

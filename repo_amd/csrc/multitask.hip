@@ -47,63 +47,18 @@ __global__ __launch_bounds__(256) void film_fwd_kernel(long planes, int C, int P
 // dh is the gradient at the ReLU's INPUT (the producer -- a data-gradient kernel with the MUL_DRELU epilogue, or
 // repo_relu_mask -- has applied the mask): dy = dh * (1 + gamma); d gamma[n][c] = sum_p dh * y; d beta[n][c] = sum_p dh.
 // One wave per plane, fixed summation order.  dfilm rows are written (each (n, c) slot is owned by one plane).
-// FROM_H: `y` is the layer's OUTPUT h (the conv ran with REPO_EPI_FILM_RELU): y = (h - beta) / (1 + gamma) where dh != 0
-// -- for WELL-CONDITIONED planes.  The recovered y carries an error of eps * (|h| + |beta|) / |1 + gamma|, and a plane
-// whose 1 + gamma is 0 has lost y altogether (the reference keeps the exact y: models/encoder.py:84-87), so a plane with
-// |1 + gamma| < kFilmExactBelow RECOMPUTES its y from the layer's own input, weights and bias (FilmExact: a plain
-// fp32 dot product per output element, one lane per pixel) -- a channel a task has gated off costs its planes a slow
-// exact convolution instead of a wrong gamma gradient.  With 1 / 16 the recovery's amplification stays below
-// 1 + 32 |beta| / |y| roundings.
-constexpr float kFilmExactBelow = 0.0625f;
-struct FilmExact {
-  int kind;   // 0: none (recover everywhere; a plane with 1 + gamma == 0 contributes no gamma gradient),
-              // 1: stride-2 convolution big (CB,HB,HB) -> small (CS,HS,HS), the plane is a SMALL channel (encoder layers),
-              // 2: its transpose small -> big, the plane is a BIG channel (decoder conv2 / conv3),
-              // 3: dense, y[n][c * P + p] = bias[c] + sum_k x[n][k] w[k][c * P + p] (decoder conv1: 1 x 1 -> 5 x 5)
-  int CB, CS, HB, HS, KS, K;
-  const void* x;       // the layer's input activation (kind 1: big, uint8 frames if x_u8; kind 2: small; kind 3: (nimg, K))
-  int x_u8;
-  const float* w;      // (CS, CB, KS, KS) as repo_conv_down / repo_conv_up take it; kind 3: (K, C * P)
-  const float* bias;   // per output channel (nullable)
-};
-__device__ float film_exact_y(const FilmExact& e, long n, int c, int p, int C, int P) {
-  float acc = e.bias ? e.bias[c] : 0.f;
-  if (e.kind == 1) {
-    const int oy = p / e.HS, ox = p % e.HS;
-    for (int ci = 0; ci < e.CB; ++ci)
-      for (int ky = 0; ky < e.KS; ++ky)
-        for (int kx = 0; kx < e.KS; ++kx) {
-          const size_t xi = (((size_t)n * e.CB + ci) * e.HB + 2 * oy + ky) * e.HB + 2 * ox + kx;
-          const float xv = e.x_u8 ? pix_norm(((const uint8_t*)e.x)[xi]) : ((const float*)e.x)[xi];
-          acc = fmaf(e.w[(((size_t)c * e.CB + ci) * e.KS + ky) * e.KS + kx], xv, acc);
-        }
-  } else if (e.kind == 2) {
-    const int Y = p / e.HB, X = p % e.HB;
-    const float* xs = (const float*)e.x;
-    for (int cs = 0; cs < e.CS; ++cs)
-      for (int ky = Y & 1; ky < e.KS; ky += 2) {
-        const int iy = (Y - ky) >> 1;
-        if (Y - ky < 0 || iy >= e.HS) continue;
-        for (int kx = X & 1; kx < e.KS; kx += 2) {
-          const int ix = (X - kx) >> 1;
-          if (X - kx < 0 || ix >= e.HS) continue;
-          acc = fmaf(xs[(((size_t)n * e.CS + cs) * e.HS + iy) * e.HS + ix],
-                     e.w[(((size_t)cs * e.CB + c) * e.KS + ky) * e.KS + kx], acc);
-        }
-      }
-  } else {
-    const float* xs = (const float*)e.x + (size_t)n * e.K;
-    const size_t N = (size_t)C * P, j = (size_t)c * P + p;
-    for (int k = 0; k < e.K; ++k) acc = fmaf(xs[k], e.w[(size_t)k * N + j], acc);
-  }
-  return acc;
-}
-
+// FROM_H: `y` is the layer's OUTPUT h (the conv ran with REPO_EPI_FILM_RELU): y = (h - beta) / (1 + gamma) where dh != 0.
+// h = fl((1 + gamma) y + beta) resolves y to eps |h| / |1 + gamma|, so the recovered y carries a relative error of about
+// eps |beta| / |(1 + gamma) y| (measured: d gamma within 5e-6 at |1 + gamma| = 2e-3), and a plane whose 1 + gamma is 0
+// has lost y altogether (the reference keeps the exact y: models/encoder.py:84-87): the (nearly) GATED-OFF planes,
+// |1 + gamma| < kFilmExactBelow, get their gamma gradient from film_exact_kernel below instead.
+constexpr float kFilmExactBelow = 1e-3f;
 template <bool FROM_H>
 __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P, const float* __restrict__ dh,
                                                        const float* __restrict__ y, const float* __restrict__ film,
                                                        int ld, int goff, int boff, float* __restrict__ dy,
-                                                       float* __restrict__ dfilm, FilmExact ex) {
+                                                       float* __restrict__ dfilm, unsigned* __restrict__ gated_epoch,
+                                                       unsigned epoch) {
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   for (long pl = wave; pl < planes; pl += nwaves) {
@@ -112,17 +67,17 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P
     const float g = 1.f + film[n * ld + goff + c];
     const float bt = FROM_H ? film[n * ld + boff + c] : 0.f;
     const float rg = (FROM_H && g != 0.f) ? 1.f / g : 0.f;
-    const bool exact = FROM_H && ex.kind != 0 && fabsf(g) < kFilmExactBelow;   // (wave-uniform)
+    // a gated-off plane: tell film_exact_kernel (the launch behind this one) that it has work -- the word holds the epoch of
+    // the last call that met one (a monotonic host counter: nothing to reset)
+    if (FROM_H && gated_epoch && lane == 0 && fabsf(g) < kFilmExactBelow)
+      __hip_atomic_store(gated_epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float* d = dh + pl * P;
     const float* src = y + pl * P;
     float* dst = dy + pl * P;
     float sg = 0.f, sb = 0.f;
     for (int p = lane; p < P; p += 64) {
       const float v = d[p];
-      float yy;
-      if (!FROM_H) yy = src[p];
-      else if (v == 0.f) yy = 0.f;
-      else yy = exact ? film_exact_y(ex, n, c, p, C, P) : (src[p] - bt) * rg;
+      const float yy = FROM_H ? (v != 0.f ? (src[p] - bt) * rg : 0.f) : src[p];
       sg = fmaf(v, yy, sg);
       sb += v;
       dst[p] = v * g;
@@ -133,6 +88,124 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(long planes, int C, int P
       dfilm[n * ld + goff + c] = sg;
       dfilm[n * ld + boff + c] = sb;
     }
+  }
+}
+
+// The gamma gradient of the GATED-OFF planes, exactly: y recomputed from the layer's own input, weights and bias (a plain
+// fp32 dot product per output element), d gamma = sum_p dh * y written over what film_bwd_kernel<true> left there.  One
+// launch per modulated layer behind film_bwd_kernel; a workgroup walks its share of the planes, skips every plane with
+// |1 + gamma| >= kFilmExactBelow after ONE load (a launch without gated-off planes is a few microseconds), and puts all
+// 256 threads on a gated-off one: thread = (pixel, k-slice), the slices of a pixel meet in LDS in a fixed order.  This is
+// a slow path by design -- a gated-off (task, channel) pair costs its planes a scalar convolution -- kept off the
+// streaming kernel above so that kernel's registers and time are what they were (an in-line version made every launch
+// of it slower and a gated-off pair of decoder conv3 cost 4-5 ms: round 6).
+struct FilmExact {
+  int kind;   // 1: stride-2 convolution big (CB,HB,HB) -> small (CS,HS,HS), the plane is a SMALL channel (encoder layers),
+              // 2: its transpose small -> big, the plane is a BIG channel (decoder conv2 / conv3),
+              // 3: dense, y[n][c * P + p] = bias[c] + sum_k x[n][k] w[k][c * P + p] (decoder conv1: 1 x 1 -> 5 x 5)
+  int CB, CS, HB, HS, KS, K;
+  const void* x;       // the layer's input activation (kind 1: big, uint8 frames if x_u8; kind 2: small; kind 3: (nimg, K))
+  int x_u8;
+  const float* w;      // (CS, CB, KS, KS) as repo_conv_down / repo_conv_up take it; kind 3: (K, C * P)
+  const float* bias;   // per output channel (nullable)
+};
+// the share of one (pixel, slice) of one output element: the outer reduction index (input channel / k) strided by S.  The
+// pixel's taps are listed once (offsets into an input plane and into a weight slab), then every outer step issues all of
+// them into four independent sums -- the loads of a step are in flight together (nested tap loops with one dependent load
+// pair per step ran at ~450 ns per tap: 4 ms for one gated-off pair of decoder conv3).
+__device__ float film_exact_part(const FilmExact& e, long n, int c, int p, int C, int P, int sl, int S) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e.kind == 3) {
+    const float* xs = (const float*)e.x + (size_t)n * e.K;
+    const size_t N = (size_t)C * P, j = (size_t)c * P + p;
+    int k = sl;
+    for (; k + 3 * S < e.K; k += 4 * S) {
+      a0 = fmaf(xs[k], e.w[(size_t)k * N + j], a0);
+      a1 = fmaf(xs[k + S], e.w[(size_t)(k + S) * N + j], a1);
+      a2 = fmaf(xs[k + 2 * S], e.w[(size_t)(k + 2 * S) * N + j], a2);
+      a3 = fmaf(xs[k + 3 * S], e.w[(size_t)(k + 3 * S) * N + j], a3);
+    }
+    for (; k < e.K; k += S) a0 = fmaf(xs[k], e.w[(size_t)k * N + j], a0);
+    return (a0 + a1) + (a2 + a3);
+  }
+  // the pixel's taps as a rectangle (a, b) in [a0, a1) x [b0, b1): input element (xr0 + xrs a, xc0 + xcs b) of a plane of
+  // width XW, weight element (wr0 + wrs a, wc0 + wcs b) of a KS x KS slab -- no per-tap branches, no indexed arrays (a
+  // dynamically indexed private array lives in scratch memory: the version with tap lists ran at 6.8 ms per gated-off pair)
+  int a0_, a1_, b0_, b1_, xr0, xrs, xc0, xcs, wr0, wrs, wc0, wcs, XW, outer;
+  size_t xplane, wslab, xbase, wbase;
+  if (e.kind == 1) {
+    const int oy = p / e.HS, ox = p % e.HS;
+    a0_ = 0, a1_ = e.KS, b0_ = 0, b1_ = e.KS;
+    xr0 = 2 * oy, xrs = 1, xc0 = 2 * ox, xcs = 1, wr0 = 0, wrs = 1, wc0 = 0, wcs = 1, XW = e.HB;
+    outer = e.CB, xplane = (size_t)e.HB * e.HB, wslab = (size_t)e.KS * e.KS;
+    xbase = (size_t)n * e.CB * xplane, wbase = (size_t)c * e.CB * wslab;
+  } else {
+    // ky = py + 2 a reads input row iyb - a (iyb = (Y - py) / 2): valid for 0 <= iyb - a < HS and ky < KS
+    const int Y = p / e.HB, X = p % e.HB, py = Y & 1, px = X & 1, iyb = (Y - py) >> 1, ixb = (X - px) >> 1;
+    a0_ = max(0, iyb - e.HS + 1), a1_ = min((e.KS - py + 1) >> 1, iyb + 1);
+    b0_ = max(0, ixb - e.HS + 1), b1_ = min((e.KS - px + 1) >> 1, ixb + 1);
+    xr0 = iyb, xrs = -1, xc0 = ixb, xcs = -1, wr0 = py, wrs = 2, wc0 = px, wcs = 2, XW = e.HS;
+    outer = e.CS, xplane = (size_t)e.HS * e.HS, wslab = (size_t)e.CB * e.KS * e.KS;   // w[cs][cb][ky][kx]
+    xbase = (size_t)n * e.CS * xplane, wbase = (size_t)c * e.KS * e.KS;
+  }
+  auto xat = [&](size_t i) __attribute__((always_inline)) {
+    return e.x_u8 ? pix_norm(((const uint8_t*)e.x)[i]) : ((const float*)e.x)[i];
+  };
+  int o = sl;
+  for (; o + 3 * S < outer; o += 4 * S) {   // four channels of the slice at once: eight loads in flight per tap
+    const size_t xb = xbase + (size_t)o * xplane, wb = wbase + (size_t)o * wslab;
+    const size_t dx = (size_t)S * xplane, dw = (size_t)S * wslab;
+    for (int a = a0_; a < a1_; ++a)
+      for (int b = b0_; b < b1_; ++b) {
+        const size_t xi = xb + (size_t)((xr0 + xrs * a) * XW + xc0 + xcs * b), wi = wb + (size_t)((wr0 + wrs * a) * e.KS + wc0 + wcs * b);
+        const float x0 = xat(xi), x1 = xat(xi + dx), x2 = xat(xi + 2 * dx), x3 = xat(xi + 3 * dx);
+        const float w0 = e.w[wi], w1 = e.w[wi + dw], w2 = e.w[wi + 2 * dw], w3 = e.w[wi + 3 * dw];
+        a0 = fmaf(w0, x0, a0), a1 = fmaf(w1, x1, a1), a2 = fmaf(w2, x2, a2), a3 = fmaf(w3, x3, a3);
+      }
+  }
+  for (; o < outer; o += S) {
+    const size_t xb = xbase + (size_t)o * xplane, wb = wbase + (size_t)o * wslab;
+    for (int a = a0_; a < a1_; ++a)
+      for (int b = b0_; b < b1_; ++b)
+        a0 = fmaf(e.w[wb + (size_t)((wr0 + wrs * a) * e.KS + wc0 + wcs * b)], xat(xb + (size_t)((xr0 + xrs * a) * XW + xc0 + xcs * b)), a0);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(256) void film_exact_kernel(long planes, int C, int P, const float* __restrict__ dh,
+                                                         const float* __restrict__ film, int ld, int goff,
+                                                         float* __restrict__ dfilm, FilmExact ex,
+                                                         const unsigned* __restrict__ gated_epoch, unsigned epoch) {
+  // no gated-off plane in this layer (what film_bwd_kernel<true> just found): nothing to do
+  if (gated_epoch && __hip_atomic_load(gated_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) return;
+  __shared__ float part[256];
+  __shared__ float red[16];
+  // k-slices per pixel: a power of two, as many as 256 threads give (1 for planes of 256 pixels or more)
+  int S = 1;
+  while (2 * S * P <= 256) S *= 2;
+  const int outer = ex.kind == 1 ? ex.CB : ex.kind == 2 ? ex.CS : ex.K;
+  if (S > outer) S = outer;
+  for (long pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+    const long n = pl / C;
+    const int c = (int)(pl % C);
+    const float g = 1.f + film[n * ld + goff + c];
+    if (!(fabsf(g) < kFilmExactBelow)) continue;   // (uniform over the workgroup)
+    float sg = 0.f;
+    for (int p0 = 0; p0 < P; p0 += 256 / S) {       // a batch of 256 / S pixels, S slices each
+      const int pi = threadIdx.x % (256 / S), sl = threadIdx.x / (256 / S), p = p0 + pi;
+      const float v = (p < P && sl < S) ? dh[pl * P + p] : 0.f;
+      // (a masked-out element needs no y: dh == 0 there)
+      part[threadIdx.x] = (v != 0.f) ? film_exact_part(ex, n, c, p, C, P, sl, S) : 0.f;
+      __syncthreads();
+      if (sl == 0 && p < P && v != 0.f) {
+        float y = ex.bias ? ex.bias[c] : 0.f;
+        for (int q = 0; q < S; ++q) y += part[q * (256 / S) + pi];
+        sg = fmaf(v, y, sg);
+      }
+      __syncthreads();
+    }
+    sg = block_sum(sg, red);
+    if (threadIdx.x == 0) dfilm[n * ld + goff + c] = sg;
   }
 }
 
@@ -294,7 +367,7 @@ extern "C" int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh
   long blocks = (planes + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(film_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, y,
-                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm, FilmExact{});
+                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm, (unsigned*)nullptr, 0u);
   REPO_CHECK_LAUNCH();
   return REPO_OK;
 }
@@ -302,11 +375,11 @@ extern "C" int repo_film_bwd(int64_t nimg, int64_t C, int64_t P, const float* dh
 extern "C" int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* dh, const float* h, const float* film,
                                int64_t ldfilm, int64_t gamma_off, int64_t beta_off, float* dy, float* dfilm,
                                int conv_kind, const int64_t* geo, const void* x, int x_is_u8, const float* w,
-                               const float* bias, hipStream_t stream) {
+                               const float* bias, unsigned* gated_epoch, unsigned epoch, hipStream_t stream) {
   REPO_ARCH_GUARD();
   REPO_REQUIRE(film_args_ok(nimg, C, P, ldfilm, gamma_off, beta_off), REPO_E_SHAPE);
   REPO_REQUIRE(dh && h && film && dy && dfilm, REPO_E_BADARG);
-  REPO_REQUIRE(conv_kind >= 0 && conv_kind <= 3, REPO_E_BADARG);
+  REPO_REQUIRE(conv_kind >= 0 && conv_kind <= 3 && (!gated_epoch || epoch != 0), REPO_E_BADARG);
   FilmExact ex{};
   ex.kind = conv_kind;
   if (conv_kind) {
@@ -328,8 +401,14 @@ extern "C" int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* 
   long blocks = (planes + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(film_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, planes, (int)C, (int)P, dh, h,
-                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm, ex);
+                     film, (int)ldfilm, (int)gamma_off, (int)beta_off, dy, dfilm, conv_kind ? gated_epoch : nullptr, epoch);
   REPO_CHECK_LAUNCH();
+  if (conv_kind) {   // the gated-off planes' gamma gradients, exactly (every block returns at once when there are none)
+    long eb = planes < 4096 ? planes : 4096;
+    hipLaunchKernelGGL(film_exact_kernel, dim3((unsigned)eb), dim3(256), 0, stream, planes, (int)C, (int)P, dh, film,
+                       (int)ldfilm, (int)gamma_off, dfilm, ex, gated_epoch, epoch);
+    REPO_CHECK_LAUNCH();
+  }
   return REPO_OK;
 }
 

@@ -924,7 +924,7 @@ FILM_CONV_DOWN, FILM_CONV_UP, FILM_DENSE = 1, 2, 3
 
 def film_bwd_h(dh, h, film, gamma_off, beta_off, dfilm, dy=None, exact=None):
     """film_bwd for a layer that ran with EPI_FILM_RELU: only its output h exists, y is recovered from it -- except on
-    planes with |1 + gamma| < 1/16, which recompute y exactly from the layer itself: exact = (FILM_CONV_DOWN | FILM_CONV_UP,
+    planes with |1 + gamma| < 1e-3, which recompute y exactly from the layer itself: exact = (FILM_CONV_DOWN | FILM_CONV_UP,
     layer id, x, w, bias) or (FILM_DENSE, K, x (n, K), w (K, C * P), bias (C))."""
     n, C = h.shape[:2]
     P = h.numel() // (n * C)
@@ -935,10 +935,18 @@ def film_bwd_h(dh, h, film, gamma_off, beta_off, dfilm, dy=None, exact=None):
         kind, which, x, w, bias = exact
         geo = (ctypes.c_int64 * 4)(*(CONV_GEO[which] if kind != FILM_DENSE else (int(which), 0, 0, 0)))
         assert x.is_contiguous() and w.is_contiguous() and x.dtype in (torch.float32, torch.uint8)
+    # the "a gated-off plane was met" word: word 8 of the stream's zeroed reduction workspace, stamped with a call counter
+    global _film_epoch
+    _film_epoch = _film_epoch % 0xFFFFFFF0 + 1
+    word = reduce_ws(h.device)[32:36]
     check(lib().repo_film_bwd_h(n, C, P, _ptr(dh), _ptr(h), _ptr(film), film.shape[1], gamma_off, beta_off, _ptr(dy),
                                 _ptr(dfilm), kind, geo, _ptr(x), int(x is not None and x.dtype == torch.uint8),
-                                _ptr(_f32c(w)) if w is not None else None, _ptr(bias), _stream()), "repo_film_bwd_h")
+                                _ptr(_f32c(w)) if w is not None else None, _ptr(bias), _ptr(word), _film_epoch,
+                                _stream()), "repo_film_bwd_h")
     return dy
+
+
+_film_epoch = 0
 
 
 def film_bwd(dh, y, film, gamma_off, beta_off, dfilm, dy=None):

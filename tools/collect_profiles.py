@@ -32,7 +32,7 @@ pairs = [
     (f"{RND}_bgemm_probe.txt", f"{RND}_bgemm_probe.txt"),
     (f"{RND}_gemm_isolated.txt", f"{RND}_gemm_isolated.txt"),
     (f"{RND}_rollout_engines.txt", f"{RND}_rollout_engines.txt"),
-    (f"{RND}_ab_vs_round5.txt", f"{RND}_ab_vs_round4.txt"),
+    (f"{RND}_ab_vs_round5.txt", f"{RND}_ab_vs_round5.txt"),
     (f"{RND}_gpu_tests.txt", f"{RND}_gpu_tests.txt"),
     (f"{RND}_smoke.txt", f"{RND}_smoke.txt"),
 ]
