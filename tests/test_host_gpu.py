@@ -571,6 +571,56 @@ def test_pipelined_updates_bitwise_equal_sequential():
     assert float(a.log_beta) == float(b.log_beta)
 
 
+def test_captured_graph_owns_its_scratch_and_survives_workspace_growth():
+    """A HIP graph bakes the pointers of the scratch its kernels were captured with.  ops.capture_graph gives warm-up and
+    capture a scratch dict of their own (kept with the graph), so that (a) nothing the graph holds is ever replaced by a
+    later, larger request for the process-wide per-stream workspace -- round 5 baked that workspace's pointer, and a
+    replaced buffer returns to the allocator while the graph keeps scribbling into it (the scans start by filling their
+    exchange cells with NaN patterns) -- and (b) a request for process-wide scratch under stream capture raises instead of
+    baking it.  The acting path's values after the process-wide workspaces were dropped, regrown and overwritten."""
+    from repo_amd import ops
+
+    agent, cfg = make_agent("repo", 6, 3, 4, 6)
+    rs = np.random.RandomState(3)
+    frame = torch.from_numpy(rs.uniform(-0.5, 0.5, (1, 3, 64, 64)).astype(np.float32)).cuda()
+    lat = (torch.full((1, 200), 0.1, device="cuda"), torch.full((1, 30), 0.5, device="cuda"), torch.full((1, 6), 0.3, device="cuda"))
+    first = agent.update_latent_and_select_action(*lat, frame, False)       # captures
+    graph, sin, sout, scratch = agent._act_graphs[(False, 1, torch.float32)]
+    assert len(scratch) >= 1 and all(isinstance(b, torch.Tensor) for b in scratch.values())
+    held = {b.data_ptr() for b in scratch.values()}
+    assert not held & {b.data_ptr() for b in ops._ws.values()}                  # nothing shared with the process-wide pool
+    # drop and regrow every process-wide workspace, then scribble NaN patterns over whatever the allocator hands out
+    ops._ws.clear()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
+    for nb in (1 << 20, 1 << 24, 1 << 27):
+        ops.workspace(nb, torch.device("cuda", 0)).fill_(0xFF)
+    del junk
+    batch, _ = dev_batch(6, 3, 6, 77)
+    agent.update(batch)                                                         # the update's own (large) scratch requests
+    agent.synchronize()
+    again = agent.update_latent_and_select_action(*lat, frame, False)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = agent._act_eager(*lat, frame, False)
+    assert torch.equal(again[0], ref[0])                                        # belief: no noise in it
+    assert all(bool(torch.isfinite(t).all()) and float(t.abs().max()) < 50 for t in again)
+    assert float(first[1].abs().max()) < 50
+    # scratch requested under capture outside a scope: refused (the capture state is faked: a failed real capture would
+    # leave the process' capture machinery in an error state for the tests behind this one)
+    ops._ws.clear()
+    real = torch.cuda.is_current_stream_capturing
+    torch.cuda.is_current_stream_capturing = lambda: True
+    try:
+        with pytest.raises(RuntimeError, match="scratch_scope"):
+            ops.workspace(1 << 20, torch.device("cuda", 0))
+        with ops.scratch_scope() as own:                                        # ... and served inside one
+            ops.workspace(1 << 20, torch.device("cuda", 0))
+            assert len(own) == 1 and not ops._ws
+    finally:
+        torch.cuda.is_current_stream_capturing = real
+
+
 # ----------------------------------------------------------------------------- BASELINE configs at full size
 def _full_size_vs_oracle(tag, algo, L, B, H, A, n_updates=1, image=64):
     agent, cfg = make_agent(algo, L, B, H, A, image=image)
