@@ -244,6 +244,8 @@ class MultitaskDreamer(Dreamer):
         task = to_torch(np.asarray(env.task_one_hot, dtype=np.float32)[None], device=self.device)
         latent = self.update_latent_and_select_action(*latent, frame, task, explore)
         action = to_np(latent[2])[0]
+        if not np.isfinite(action).all():   # fail loudly (rollout.EpisodeDriver.advance)
+            raise FloatingPointError(f"the acting path returned a non-finite action {action!r} at environment step {self.step}")
         following, reward, done, info = env.step(action)
         return latent, action, following, reward, done, info
 

@@ -8,6 +8,8 @@ HIP-graph replay of the acting path plus the action's device->host copy.
 """
 from collections import namedtuple
 
+import numpy as np
+
 from ...common.utils import preprocess, to_np, to_torch
 
 Transition = namedtuple("Transition", "obs action reward done")
@@ -34,6 +36,11 @@ class EpisodeDriver:
         frame = to_torch(preprocess(seen[None]), device=self.agent.device)
         self.latent = self.agent.update_latent_and_select_action(*self.latent, frame, self.explore)
         action = to_np(self.latent[2])[0]
+        if not np.isfinite(action).all():
+            # fail loudly: a non-finite action can only come from a broken acting path (round 5's driver-box garbage,
+            # DESIGN section 5a), and pushed into the ring it would poison every later batch
+            raise FloatingPointError(f"the acting path returned a non-finite action {action!r} at environment step "
+                                     f"{getattr(self.agent, 'step', '?')}")
         self.obs, reward, done, info = self.env.step(action)
         self.episode_return += reward
         self.episode_success += info.get("success", 0)

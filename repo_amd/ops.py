@@ -398,9 +398,10 @@ _REDUCE_WS_BYTES = 64 << 10   # >= every reduction's request (repo_reduce / _tia
 
 
 def reduce_ws(device, nbytes=0):
-    """The reduction workspace of the current stream: allocated ZEROED, used by the single-launch reductions only (their
-    last block leaves the 256-byte ticket header zero again: include/repo_hip.h, "losses and regularisers").  Per
-    (device, stream) like workspace(), and owned by the innermost scratch_scope() if there is one."""
+    """The reduction workspace of the current stream: allocated ZEROED, used only by the reductions (the small-grid ones
+    finish in their own launch: their last block takes the ticket in word 0 of the 256-byte header and leaves it zero
+    again: include/repo_hip.h, "losses and regularisers") and by film_bwd_h, which keeps its epoch word at byte 32 of the
+    header.  Per (device, stream) like workspace(), and owned by the innermost scratch_scope() if there is one."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = ("reduce", idx, _raw_stream(idx))
     pool = getattr(_scope, "pool", None)
