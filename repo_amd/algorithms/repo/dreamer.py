@@ -279,6 +279,10 @@ class Dreamer:
         embeds, st["enc_saved"] = Fn.encoder_fwd(pe, frames)
         pr, _ = self._pg(self.transition_model)
         b0, s0 = self._zero_state(B)
+        pd, _ = self._pg(self.obs_model)
+        # the decoder's composed first layers (functional.dec_head_compose) depend on the parameters only: made here, under
+        # the latency-bound scan, off the decoder's chain
+        head = Fn.dec_head_compose(pd) if Fn._dec_compose(rows) else None
         sv = ops.rssm_observe_fwd(
             pr, b0, s0, actions[:-1].contiguous(), nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1),
             self._noise("obs_prior", (T, B, S)), self._noise("obs_post", (T, B, S)), self.transition_model.min_std_dev,
@@ -290,8 +294,7 @@ class Dreamer:
         feat = sv.featx[1:].reshape(rows, D + S)
         st["feat"] = feat
         # decoder + pixel NLL (mean over (T,B) of the per-frame sums)
-        pd, _ = self._pg(self.obs_model)
-        st["nll_sum"], st["dec_saved"] = Fn.decoder_fwd_nll(pd, feat, frames, 1.0 / grow)
+        st["nll_sum"], st["dec_saved"] = Fn.decoder_fwd_nll(pd, feat, frames, 1.0 / grow, head=head)
         # reward head; predicted from the next state, masked by nonterminal (repo.py:58-61)
         pw, _ = self._pg(self.reward_model)
         r_pred, st["rew_hid"] = ops.mlp_fwd(pw, feat)

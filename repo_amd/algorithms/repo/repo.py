@@ -70,6 +70,9 @@ class RePo(Dreamer):
         pe, ge = self._pg(self.encoder)
         embeds, enc_saved = Fn.encoder_fwd(pe, frames)
         pr, gr = self._pg(self.transition_model)
+        pd, gd = self._pg(self.obs_model)
+        # the decoder's composed first layers depend on the parameters only: made here, under the latency-bound scan
+        head = Fn.dec_head_compose(pd) if Fn._dec_compose(rows) else None
         sv = ops.rssm_observe_fwd(
             pr, *self._zero_state(B), actions[:-1].contiguous(),
             nonterms[:-1].reshape(T, B).contiguous(), embeds.view(T, B, -1), self._noise("obs_prior", (T, B, S)),
@@ -93,8 +96,7 @@ class RePo(Dreamer):
             ops.rssm_observe_bwd(pr, sv, gr, dfeat=dfeat, dpm=klg[0], dps=klg[1], dqm=klg[2], dqs=klg[3], dembeds=dembeds,
                                  min_std=self.transition_model.min_std_dev)
             Fn.encoder_bwd(pe, frames, enc_saved, dembeds, ge, side=None)
-        pd, gd = self._pg(self.obs_model)
-        nll_sum, dec_saved = Fn.decoder_fwd_nll(pd, feat, frames, 1.0 / grow)
+        nll_sum, dec_saved = Fn.decoder_fwd_nll(pd, feat, frames, 1.0 / grow, head=head)
         Fn.decoder_bwd(pd, feat, dec_saved, gd, side=self._wgrad_side(B))
         if self.dp is not None and self._dp_two_buckets:
             main.wait_event(ev_rew)

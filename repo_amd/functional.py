@@ -4,6 +4,8 @@ expressed over repo_amd.ops (the C ABI).  Parameter lists are in the reference m
 state_dict order; gradients are written in place into caller-provided tensors (views of the
 flat gradient buffer), so no autograd graph and no extra accumulation pass are involved.
 """
+import os
+
 import torch
 
 from . import ops
@@ -99,23 +101,73 @@ def encoder_bwd(p, obs, saved, dembeds, g, accumulate=False, side=None):
 
 
 # ----------------------------------------------------------------------------- decoder
-def decoder_trunk_fwd(p, feat):
+# The decoder's first two layers are LINEAR in sequence: `hidden = self.fc1(cat)  # No nonlinearity here`, then
+# `act(conv1(hidden.view(-1, E, 1, 1)))` (models/decoder.py:41-44) -- a (230 -> 1024) Linear followed by a
+# (1024 -> 128 x 5 x 5) transposed conv on a 1 x 1 input, which is a (1024 -> 3200) Linear.  Their composition is one
+# (230 -> 3200) Linear, W01 = W1^T W0 (3200 x 230), b01 = W1^T b0 + b1: the 1024-wide hidden never has to exist, and
+# neither do the three largest GEMMs of the update (forward 2450 x 3200 x 1024, input gradient 2450 x 1024 x 3200, weight
+# gradient 1024 x 3200 over 2450 rows: 16 GFLOP each).  With G = d1^T feat (3200 x 230) and s = column sums of d1:
+#     h1   = relu(feat W01^T + b01)
+#     d W1 = W0 G^T + b0 s^T,   d W0 = W1 G,   d b0 = W1 s,   d b1 = channel sums of d1,   d feat = d1 W01
+# -- 5 / 7-10 GFLOP forward / backward instead of 17 / 34, exact in real arithmetic (fp32 rounding differs at the 1e-6
+# level, as between any two summation orders).  The bias terms ride as a 231st column (W0 | b0), (G | s): the vector
+# products b0^T W1 and W1 s alone are one-row GEMMs that cost 90-155 us on the tile engines (measured:
+# tools/probe_py/dec_head_compose.py); W1 G is a reduction over 3200 "rows" of W1^T and goes to the row-split weight-gradient
+# engine.  From _DEC_COMPOSE_MIN_ROWS rows up (composing costs 1.5 GFLOP whatever the batch: the acting path's single row
+# keeps the two layers); REPO_DEC_COMPOSE=0 restores the two-layer form everywhere.
+_DEC_COMPOSE_MIN_ROWS = 512
+_DEC_PAD = 232   # 230 inputs + the bias column, padded to a multiple of 4
+
+
+def _dec_compose(rows):
+    return rows >= _DEC_COMPOSE_MIN_ROWS and os.environ.get("REPO_DEC_COMPOSE", "1") == "1"
+
+
+class DecHead:
+    """The composed first two decoder layers of one parameter state: w0aug (1024, 232) = [W0 | b0 | 0], w1t (3200, 1024)
+    = W1^T, w01aug (3200, 232) = W1^T w0aug = [W01 | W1^T b0 | 0], b01 (3200,)."""
+    __slots__ = ("w0aug", "w1t", "w01aug", "b01")
+
+
+def dec_head_compose(p):
+    """Depends on the parameters only: the agents issue it ahead of the scan, off the decoder's chain."""
+    w0, b0 = p[0], p[1]
+    w1 = p[2].view(p[2].shape[0], -1)                        # (1024, 3200)
+    F_ = w0.shape[1]
+    dh = DecHead()
+    dh.w0aug = torch.zeros(w0.shape[0], _DEC_PAD, dtype=torch.float32, device=w0.device)
+    dh.w0aug[:, :F_].copy_(w0)
+    dh.w0aug[:, F_].copy_(b0)
+    dh.w1t = ops.transpose(w1)                                # (3200, 1024)
+    dh.w01aug = ops.gemm(dh.w1t, dh.w0aug)                    # (3200, 232)
+    dh.b01 = dh.w01aug[:, F_] + p[3].repeat_interleave(w1.shape[1] // p[3].shape[0])
+    return dh
+
+
+def decoder_trunk_fwd(p, feat, head=None):
     """fc1 + the first three transposed convolutions (models/decoder.py:41-46).
-    feat (rows, 230) = [belief|state]; p = [fc1.w, fc1.b, conv1.w, conv1.b, ..., conv4.w, conv4.b]."""
+    feat (rows, 230) = [belief|state]; p = [fc1.w, fc1.b, conv1.w, conv1.b, ..., conv4.w, conv4.b].
+    Returns (h0, h1, h2, h3): h0 is the DecHead when the first two layers ran composed (see above; `head`: one made
+    ahead of time by dec_head_compose)."""
     rows = feat.shape[0]
     pk2, pk3 = ops.conv_up_pack(ops.DEC2, p[4]), ops.conv_up_pack(ops.DEC3, p[6])
-    h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
-    w1 = p[2].view(p[2].shape[0], -1)  # (1024, 128*25): 1x1 -> 5x5 transposed conv is a GEMM
-    h1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_RELU).view(rows, 128, 5, 5)
+    if _dec_compose(rows):
+        h0 = head if head is not None else dec_head_compose(p)
+        F_ = feat.shape[1]
+        h1 = ops.gemm(feat, h0.w01aug[:, :F_], transb=True, bias=h0.b01, epi=ops.EPI_RELU).view(rows, 128, 5, 5)
+    else:
+        h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
+        w1 = p[2].view(p[2].shape[0], -1)  # (1024, 128*25): 1x1 -> 5x5 transposed conv is a GEMM
+        h1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_RELU).view(rows, 128, 5, 5)
     h2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_RELU, pack=pk2)
     h3 = ops.conv_up(ops.DEC3, h2, p[6], p[7], epi=ops.EPI_RELU, pack=pk3)
     return h0, h1, h2, h3
 
 
-def decoder_fwd(p, feat):
+def decoder_fwd(p, feat, head=None):
     """VisualObservationModel.forward -> (recon (rows,3,64,64), saved).  Twelve tensors in p = the 128 x 128 stack
     (conv4 32 -> 16 with ReLU, conv5 16 -> 3): recon (rows,3,128,128), saved gains h4."""
-    h0, h1, h2, h3 = decoder_trunk_fwd(p, feat)
+    h0, h1, h2, h3 = decoder_trunk_fwd(p, feat, head)
     if len(p) > 10:
         h4 = ops.conv_up(ops.X_DEC4, h3, p[8], p[9], epi=ops.EPI_RELU)
         recon = ops.conv_up(ops.X_DEC5, h4, p[10], p[11], epi=ops.EPI_NONE)
@@ -125,10 +177,10 @@ def decoder_fwd(p, feat):
     return recon, (h0, h1, h2, h3)
 
 
-def decoder_fwd_nll(p, feat, target, grad_scale):
+def decoder_fwd_nll(p, feat, target, grad_scale, head=None):
     """Decoder forward fused with the unit-variance pixel NLL (repo.py:46-53).
     Returns (sum 0.5*(recon-target)^2 (1,), saved incl. d loss/d recon * grad_scale)."""
-    h0, h1, h2, h3 = decoder_trunk_fwd(p, feat)
+    h0, h1, h2, h3 = decoder_trunk_fwd(p, feat, head)
     if len(p) > 10:  # 128 x 128 stack: the output layer + NLL on the gather engine (ops.conv_up_nll)
         h4 = ops.conv_up(ops.X_DEC4, h3, p[8], p[9], epi=ops.EPI_RELU)
         loss_sum, dpre5, _ = ops.conv_up_nll(ops.X_DEC5, h4, p[10], p[11], target, grad_scale)
@@ -223,6 +275,31 @@ def _decoder_bwd_tail(p, feat, h0, h1, h2, d3, g, dfeat, accumulate_dfeat, accum
     d1 = ops.conv_down(ops.DEC2, d2, p[4], None, epi=ops.EPI_MUL_DRELU, aux=h1)
     d1f = d1.view(rows, 128 * 25)
     w1 = p[2].view(p[2].shape[0], -1)
+    if isinstance(h0, DecHead):
+        # the first two layers ran composed (decoder_trunk_fwd): every gradient of the pair through (G | s) = d1^T (feat | 1)
+        F_ = feat.shape[1]
+        gaug = torch.zeros(d1f.shape[1], _DEC_PAD, dtype=torch.float32, device=d1f.device)     # (3200, 232) = [G | s | 0]
+        _, s_ = ops.gemm_wgrad(d1f, feat, dW=gaug[:, :F_])
+        gaug[:, F_].copy_(s_)
+
+        def wpair():
+            ops.gemm(h0.w0aug, gaug, transb=True, out=g[2].view(w1.shape), accumulate=accumulate)   # d W1 = W0 G^T + b0 s^T
+            ops.channel_sum(d1.view(rows, 128, 25), out=g[3], accumulate=accumulate)
+            d0aug, _ = ops.gemm_wgrad(h0.w1t, gaug, want_bias=False)                                # (1024, 232) = [W1 G | W1 s | 0]
+            if accumulate:
+                g[0].add_(d0aug[:, :F_])
+                g[1].add_(d0aug[:, F_])
+            else:
+                g[0].copy_(d0aug[:, :F_])
+                g[1].copy_(d0aug[:, F_])
+
+        fk.run(wpair)
+        if dfeat is not None:
+            # d feat = d1 W01, as an NT product over W01^T (a 3 MB transposing copy: 94 -> ~55 us at 2450 rows)
+            w01t = ops.transpose(h0.w01aug)                                                         # (232, 3200)
+            ops.gemm(d1f, w01t[:F_], transb=True, out=dfeat, accumulate=accumulate_dfeat)
+        fk.join()
+        return
 
     def w1f():
         ops.gemm_wgrad(h0, d1f, dW=g[2].view(w1.shape), db=None, accumulate=accumulate, want_bias=False)
@@ -234,4 +311,3 @@ def _decoder_bwd_tail(p, feat, h0, h1, h2, d3, g, dfeat, accumulate_dfeat, accum
     if dfeat is not None:
         ops.gemm(dh0, p[0], out=dfeat, accumulate=accumulate_dfeat)
     fk.join()
-
