@@ -126,7 +126,11 @@ int repo_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, hi
  * models/actor_critic.py:21-25,77-82 (transa=0, transb=1), their input gradients
  * (transb=0), and the 1x1 -> 5x5 first transposed convolution of the decoder
  * (models/decoder.py:44), which is a plain GEMM against the (1024, 128*25) weight.
- * bias may be NULL; aux (ld = ldaux) is read only by the MUL_* epilogues. */
+ * bias may be NULL; aux (ld = ldaux) is read only by the MUL_* / FILM epilogues.
+ * bias_div < 0 (ABI v8, REPO_EPI_FILM_RELU only): the bias is per output column (as bias_div = 1) while the FiLM table's
+ * channel of column n is n / -bias_div -- the decoder's COMPOSED first layers (repo_amd/functional.py, dec_head_compose:
+ * fc1 and the 1 x 1 -> 5 x 5 transposed conv are linear in sequence, models/decoder.py:41-44) carry one bias per
+ * output element and one FiLM pair per 25 of them. */
 int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
               const float* B, int64_t ldb, const float* bias, int64_t bias_div, float* C, int64_t ldc,
               int epi, const float* aux, int64_t ldaux, int accumulate, hipStream_t stream);
@@ -512,7 +516,8 @@ int repo_film_tables(int64_t nimg, int nlayers, const int* channels, const float
  *   conv_kind 1: the stride-2 convolution of repo_conv_down, geo = {CB, CS, HB, KS}, x = its `big` input (uint8 frames if
  *                x_is_u8, normalised like repo_conv_down does), w (CS, CB, KS, KS), bias (CS); planes = small channels;
  *   conv_kind 2: its transpose (repo_conv_up), x = the `small` input, same w, bias (CB); planes = big channels;
- *   conv_kind 3: dense (the decoder's 1 x 1 -> 5 x 5 first layer), geo = {K}: y[n][c*P + p] = bias[c] + sum_k x[n][k] w[k][c*P + p];
+ *   conv_kind 3: dense (the decoder's 1 x 1 -> 5 x 5 first layer), geo = {K, per_element_bias}: y[n][c*P + p] = bias[c] (or
+ *                bias[c*P + p] if per_element_bias) + sum_k x[n][k] w[k][c*P + p];
  *   gated_epoch / epoch (nullable / non-zero): one device word, zero-initialised once, and a number that grows from call
  *                to call -- the streaming pass stamps the word with this call's epoch when it meets a gated-off plane,
  *                and the exact pass (a second launch) returns at once unless the word carries it: a layer without

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512) void bgemm_kernel(BgArgs p) {
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + (wn * TN + j) * 32 + li;
       if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[p.bias_div == 1 ? n : n / p.bias_div] : 0.f;
+      const float bv = p.bias ? p.bias[p.bias_div > 1 ? n / p.bias_div : n] : 0.f;   // bias_div < 0: one bias per output column
       const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512) void bgemm_kernel(BgArgs p) {
           else if (p.epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(p.aux[(size_t)m * p.ldaux + n]);
           else if (p.epi == REPO_EPI_MUL_DRELU) v = p.aux[(size_t)m * p.ldaux + n] > 0.f ? v : 0.f;
           else if (p.epi == REPO_EPI_FILM_RELU) {   // row m's FiLM table: [scale (C) | shift (C)], C = ldaux / 2, channel n / bias_div
-            const int ch = p.bias_div == 1 ? n : n / p.bias_div;
+            const int ch = p.bias_div == 1 ? n : n / (p.bias_div < 0 ? -p.bias_div : p.bias_div);
             v = fmaxf(fmaf(p.aux[(size_t)m * p.ldaux + ch], v, p.aux[(size_t)m * p.ldaux + (p.ldaux >> 1) + ch]), 0.f);
           }
           float* c = p.C + (size_t)m * p.ldc + n;

@@ -42,7 +42,7 @@ struct GemmOp {
   __device__ BK b_k(int k) const { return TB ? k : k * ldb; }
   __device__ float b(const BK& k, const BN& n) const { return B[(unsigned)(k + n)]; }
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
-    const float bv = bias ? bias[bias_div == 1 ? n : n / bias_div] : 0.f;
+    const float bv = bias ? bias[bias_div > 1 ? n / bias_div : n] : 0.f;   // bias_div < 0: one bias per output column (FiLM: header)
     float* c = C + mb * ldc + n;
     const float* ax = aux ? aux + mb * ldaux + n : nullptr;
 #pragma unroll
@@ -55,7 +55,7 @@ struct GemmOp {
         else if (epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(ax[dm * ldaux]);
         else if (epi == REPO_EPI_MUL_DRELU) v = ax[dm * ldaux] > 0.f ? v : 0.f;
         else if (epi == REPO_EPI_FILM_RELU) {   // row's FiLM table [scale (C) | shift (C)], C = ldaux / 2 (bgemm.h)
-          const int ch = bias_div == 1 ? n : n / bias_div;
+          const int ch = bias_div == 1 ? n : n / (bias_div < 0 ? -bias_div : bias_div);
           const float* tb = aux + (size_t)(mb + dm) * ldaux;
           v = fmaxf(fmaf(tb[ch], v, tb[(ldaux >> 1) + ch]), 0.f);
         }
@@ -89,7 +89,7 @@ struct VGemmOp {
   template <class V>
   __device__ void fix_b(V&, int) const {}
   __device__ void store_col(int mb, int n, const f32x16& acc, int M) {
-    const float bv = bias ? bias[bias_div == 1 ? n : n / bias_div] : 0.f;
+    const float bv = bias ? bias[bias_div > 1 ? n / bias_div : n] : 0.f;   // bias_div < 0: one bias per output column (FiLM: header)
     float* c = C + mb * ldc + n;
     const float* ax = aux ? aux + mb * ldaux + n : nullptr;
 #pragma unroll
@@ -102,7 +102,7 @@ struct VGemmOp {
         else if (epi == REPO_EPI_MUL_DELU) v *= elu_grad_from_out(ax[dm * ldaux]);
         else if (epi == REPO_EPI_MUL_DRELU) v = ax[dm * ldaux] > 0.f ? v : 0.f;
         else if (epi == REPO_EPI_FILM_RELU) {   // row's FiLM table [scale (C) | shift (C)], C = ldaux / 2 (bgemm.h)
-          const int ch = bias_div == 1 ? n : n / bias_div;
+          const int ch = bias_div == 1 ? n : n / (bias_div < 0 ? -bias_div : bias_div);
           const float* tb = aux + (size_t)(mb + dm) * ldaux;
           v = fmaxf(fmaf(tb[ch], v, tb[(ldaux >> 1) + ch]), 0.f);
         }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(int M, int N, int K, co
     writer = true;
   }
   if (!writer) return;
-  const float bv = bias ? bias[bias_div == 1 ? n : n / bias_div] : 0.f;
+  const float bv = bias ? bias[bias_div > 1 ? n / bias_div : n] : 0.f;   // bias_div < 0: one bias per output column (FiLM: header)
 #pragma unroll
   for (int m = 0; m < MR; ++m)
     if (m < M) {
@@ -465,7 +465,10 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
   REPO_REQUIRE((epi >= REPO_EPI_NONE && epi <= REPO_EPI_MUL_DRELU) || epi == REPO_EPI_FILM_RELU, REPO_E_BADARG);
   REPO_REQUIRE((epi != REPO_EPI_MUL_DELU && epi != REPO_EPI_MUL_DRELU && epi != REPO_EPI_FILM_RELU) || aux, REPO_E_BADARG);
   // FiLM: one table row per output row, [scale | shift] over the N / bias_div channels; not on the <= 8-row vector path
-  REPO_REQUIRE(epi != REPO_EPI_FILM_RELU || (M > 8 && !accumulate && ldaux % 2 == 0 && ldaux / 2 >= (N + (bias_div > 0 ? bias_div : 1) - 1) / (bias_div > 0 ? bias_div : 1)), REPO_E_BADARG);
+  {
+    const int64_t fd = bias_div < 0 ? -bias_div : (bias_div > 0 ? bias_div : 1);   // pixels per FiLM channel
+    REPO_REQUIRE(epi != REPO_EPI_FILM_RELU || (M > 8 && !accumulate && ldaux % 2 == 0 && ldaux / 2 >= (N + fd - 1) / fd), REPO_E_BADARG);
+  }
   REPO_REQUIRE(M < kMaxIdx && N < kMaxIdx && K < kMaxIdx && lda < kMaxIdx && ldb < kMaxIdx && ldc < kMaxIdx,
                REPO_E_SHAPE);
   {  // operand offsets are 32-bit inside the kernel
@@ -473,7 +476,7 @@ extern "C" int repo_gemm(int transa, int transb, int64_t M, int64_t N, int64_t K
     const int64_t eb = transb ? (N - 1) * ldb + K : (K - 1) * ldb + N;
     REPO_REQUIRE(ea < kMaxBufElems && eb < kMaxBufElems && M * ldc < kMaxIdx && M * ldaux < kMaxIdx, REPO_E_SHAPE);
   }
-  if (bias_div <= 0) bias_div = 1;
+  if (bias_div == 0 || (bias_div < 0 && epi != REPO_EPI_FILM_RELU)) bias_div = 1;   // (< 0 only means something to FiLM: header)
   // K == 1 (outer products, e.g. the gradient through a scalar output layer): a contiguous M x 1 / N x 1
   // operand is its own transpose, which turns its k-vectors (K % 2 != 0: gather engine) into m/n-vectors
   if (K == 1 && !transa && lda == 1) { transa = 1; lda = M; }

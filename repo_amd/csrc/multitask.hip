@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void film_exact_kernel(long planes, int C, int
       part[threadIdx.x] = (v != 0.f) ? film_exact_part(ex, n, c, p, C, P, sl, S) : 0.f;
       __syncthreads();
       if (sl == 0 && p < P && v != 0.f) {
-        float y = ex.bias ? ex.bias[c] : 0.f;
+        float y = ex.bias ? ex.bias[(ex.kind == 3 && ex.KS) ? c * P + p : c] : 0.f;
         for (int q = 0; q < S; ++q) y += part[q * (256 / S) + pi];
         sg = fmaf(v, y, sg);
       }
@@ -388,6 +388,7 @@ extern "C" int repo_film_bwd_h(int64_t nimg, int64_t C, int64_t P, const float* 
     if (conv_kind == 3) {
       REPO_REQUIRE(geo[0] > 0 && geo[0] < (1 << 20) && !x_is_u8, REPO_E_SHAPE);
       ex.K = (int)geo[0];
+      ex.KS = geo[1] ? 1 : 0;   // (kind 3 only: the bias is per output element, not per channel)
     } else {
       const int64_t CB = geo[0], CS = geo[1], HB = geo[2], KS = geo[3];
       REPO_REQUIRE(CB > 0 && CS > 0 && KS > 0 && HB >= KS && CB < 4096 && CS < 4096 && HB < 4096, REPO_E_SHAPE);

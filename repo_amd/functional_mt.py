@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .algorithms.repo.models.conditional import DEC_CHANNELS, ENC_CHANNELS, film_offsets
-from .functional import _Fork
+from .functional import DecHead, _DEC_PAD, _Fork, _dec_compose, dec_head_compose
 
 _ENC_L = (ops.ENC1, ops.ENC2, ops.ENC3, ops.ENC4)
 _ENC_OFF = film_offsets(ENC_CHANNELS)
@@ -87,15 +87,25 @@ def cond_encoder_bwd(p, obs, cond, saved, dembeds, g, accumulate=False, side=Non
 
 
 # ----------------------------------------------------------------------------- decoder
-def _cond_decoder_trunk(p, feat, cond):
+def _cond_decoder_trunk(p, feat, cond, head=None):
     """feat (rows, D + S) = [belief | state]: the pixel decoder concatenates nothing (models/decoder.py:116), the
     condition enters through FiLM on conv1..conv3 only;
     p = [fc1.w, fc1.b, conv1.w, conv1.b, ..., conv4.w, conv4.b, film.w, film.b]."""
     rows = feat.shape[0]
     film = _film(p[10], p[11], cond)
     pk2, pk3 = ops.conv_up_pack(ops.DEC2, p[4]), ops.conv_up_pack(ops.DEC3, p[6])
-    h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
     w1 = p[2].view(p[2].shape[0], -1)
+    if _fused() and _dec_compose(rows):
+        # fc1 and conv1 composed (functional.dec_head_compose: linear in sequence, models/decoder.py:113-116): one bias per
+        # output element, one FiLM pair per 25 of them (bias_div = -25)
+        tabs = ops.film_tables(film, DEC_CHANNELS)
+        h0 = head if head is not None else dec_head_compose(p)
+        h1 = ops.gemm(feat, h0.w01aug[:, : feat.shape[1]], transb=True, bias=h0.b01, bias_div=-25, epi=ops.EPI_FILM_RELU,
+                      aux=tabs[0].view(rows, -1)).view(rows, 128, 5, 5)
+        h2 = ops.conv_up(ops.DEC2, h1, p[4], p[5], epi=ops.EPI_FILM_RELU, aux=tabs[1], pack=pk2)
+        h3 = ops.conv_up(ops.DEC3, h2, p[6], p[7], epi=ops.EPI_FILM_RELU, aux=tabs[2], pack=pk3)
+        return film, h0, None, (h1, h2, h3)
+    h0 = ops.gemm(feat, p[0], transb=True, bias=p[1])
     if _fused() and rows > 8:   # (a handful of rows -- the acting path's reconstruction -- takes the vector path: two kernels)
         tabs = ops.film_tables(film, DEC_CHANNELS)
         h1 = ops.gemm(h0, w1, bias=p[3], bias_div=25, epi=ops.EPI_FILM_RELU, aux=tabs[0].view(rows, -1)).view(rows, 128, 5, 5)
@@ -118,10 +128,10 @@ def cond_decoder_fwd(p, feat, cond):
     return recon, (film, h0, ys, hs)
 
 
-def cond_decoder_fwd_nll(p, feat, cond, target, grad_scale):
+def cond_decoder_fwd_nll(p, feat, cond, target, grad_scale, head=None):
     """Decoder forward fused with the unit-variance pixel NLL (dreamer_mt.py:189-195).
     Returns (sum 0.5*(recon-target)^2 (1,), saved incl. d loss / d recon * grad_scale)."""
-    film, h0, ys, hs = _cond_decoder_trunk(p, feat, cond)
+    film, h0, ys, hs = _cond_decoder_trunk(p, feat, cond, head)
     db4 = torch.empty(3, dtype=torch.float32, device=feat.device)   # the output bias gradient, out of the same kernel
     loss_sum, dpre4, _, mask3 = ops.decoder_out_nll(hs[2], p[8], p[9], target, grad_scale, want_mask=True, dbias=db4)
     return loss_sum, (film, h0, ys, hs, dpre4, mask3, db4)
@@ -136,11 +146,17 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
     def fbwd(dh, l):   # the FiLM backward of decoder layer l (0 .. 2): from y_l if it was saved, else from h_l
         if ys is None:
             # (a plane whose 1 + gamma is nearly 0 recomputes y from the layer itself: ops.film_bwd_h)
-            exact = ((ops.FILM_DENSE, h0.shape[1], h0, p[2].view(p[2].shape[0], -1), p[3]) if l == 0 else
-                     (ops.FILM_CONV_UP, (ops.DEC2, ops.DEC3)[l - 1], (h1, h2)[l - 1], p[2 + 2 * l], p[3 + 2 * l]))
+            if l == 0 and composed:   # y1 = feat W01^T + b01: dense over K = 230 with one bias per output element
+                exact = (ops.FILM_DENSE, (feat.shape[1], True), feat, w01t[: feat.shape[1]], h0.b01)
+            elif l == 0:
+                exact = (ops.FILM_DENSE, h0.shape[1], h0, p[2].view(p[2].shape[0], -1), p[3])
+            else:
+                exact = (ops.FILM_CONV_UP, (ops.DEC2, ops.DEC3)[l - 1], (h1, h2)[l - 1], p[2 + 2 * l], p[3 + 2 * l])
             return ops.film_bwd_h(dh, (h1, h2, h3)[l], film, *_DEC_OFF[l], dfilm, exact=exact)
         return ops.film_bwd(dh, ys[l], film, *_DEC_OFF[l], dfilm)
 
+    composed = isinstance(h0, DecHead)
+    w01t = ops.transpose(h0.w01aug) if composed else None   # (232, 3200): W01^T, for the exact FiLM pass and d feat
     fk = _Fork(side)
     dfilm = torch.empty_like(film)
 
@@ -171,6 +187,29 @@ def cond_decoder_bwd(p, feat, cond, saved, g, dfeat=None, accumulate_dfeat=False
     dy1 = fbwd(dh1, 0)
     d1f = dy1.view(rows, 128 * 25)
     w1 = p[2].view(p[2].shape[0], -1)
+    if composed:   # functional._decoder_bwd_tail's composed branch: every gradient of the pair through (G | s) = d y1^T (feat | 1)
+        F_ = feat.shape[1]
+        gaug = torch.zeros(d1f.shape[1], _DEC_PAD, dtype=torch.float32, device=d1f.device)
+        _, s_ = ops.gemm_wgrad(d1f, feat, dW=gaug[:, :F_])
+        gaug[:, F_].copy_(s_)
+
+        def wpair():
+            ops.gemm(h0.w0aug, gaug, transb=True, out=g[2].view(w1.shape), accumulate=accumulate)
+            ops.channel_sum(dy1.view(rows, 128, 25), out=g[3], accumulate=accumulate)
+            d0aug, _ = ops.gemm_wgrad(h0.w1t, gaug, want_bias=False)
+            if accumulate:
+                g[0].add_(d0aug[:, :F_])
+                g[1].add_(d0aug[:, F_])
+            else:
+                g[0].copy_(d0aug[:, :F_])
+                g[1].copy_(d0aug[:, F_])
+
+        fk.run(wpair)
+        if dfeat is not None:
+            ops.gemm(d1f, w01t[:F_], transb=True, out=dfeat, accumulate=accumulate_dfeat)
+        _film_grads(dfilm, cond, g[10], g[11], accumulate)
+        fk.join()
+        return
 
     def w1f():
         ops.gemm_wgrad(h0, d1f, dW=g[2].view(w1.shape), db=None, accumulate=accumulate, want_bias=False)

@@ -934,7 +934,9 @@ def film_bwd_h(dh, h, film, gamma_off, beta_off, dfilm, dy=None, exact=None):
     kind, geo, x, w, bias = 0, None, None, None, None
     if exact is not None:
         kind, which, x, w, bias = exact
-        geo = (ctypes.c_int64 * 4)(*(CONV_GEO[which] if kind != FILM_DENSE else (int(which), 0, 0, 0)))
+        # FILM_DENSE: which = K, or (K, True) when `bias` holds one value per output element (the composed decoder head)
+        dense = which if isinstance(which, tuple) else (which, False)
+        geo = (ctypes.c_int64 * 4)(*(CONV_GEO[which] if kind != FILM_DENSE else (int(dense[0]), int(bool(dense[1])), 0, 0)))
         assert x.is_contiguous() and w.is_contiguous() and x.dtype in (torch.float32, torch.uint8)
     # the "a gated-off plane was met" word: word 8 of the stream's zeroed reduction workspace, stamped with a call counter
     global _film_epoch

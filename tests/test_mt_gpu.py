@@ -209,6 +209,9 @@ def test_film_backward_from_h_is_exact_on_gated_off_channels():
     h0, w1, b1 = f(rows, 1024, sc=0.3), f(1024, 3200, sc=0.05), f(128)
     dense = lambda xs, w, b: (xs @ w).view(rows, 128, 25) + b.view(1, 128, 1)   # noqa: E731
     check("dec1 (dense)", dense, h0, w1, b1, film, offs[0], (ops.FILM_DENSE, 1024, h0, w1, b1))
+    # ... and with one bias per output element, as the composed decoder head describes the layer (functional.dec_head_compose)
+    check("dec1 (dense, per-element bias)", dense, h0, w1, b1, film, offs[0],
+          (ops.FILM_DENSE, (1024, True), h0, w1, b1.repeat_interleave(25).contiguous()))
     for l, layer in ((1, ops.DEC2), (2, ops.DEC3)):
         (cb, hb, _), (cs, hs_, _) = ops.conv_shapes(layer)
         ks = ops.CONV_GEO[layer][3]
