@@ -142,9 +142,9 @@ def gemm(M, Nn, K, tb=True, epi=ops.EPI_NONE):
 
 
 for (M, Nn, K, tb, what) in [
-    (N, 1024, 230, True, "decoder fc1 fwd"),
-    (N, 3200, 1024, False, "decoder conv1 (1x1->5x5) fwd"),
-    (N, 1024, 3200, True, "decoder conv1 dgrad"),
+    (N, 1024, 230, True, "decoder fc1 fwd (two-layer form: small batches / REPO_DEC_COMPOSE=0)"),
+    (N, 3200, 1024, False, "decoder conv1 (1x1->5x5) fwd (two-layer form)"),
+    (N, 1024, 3200, True, "decoder conv1 dgrad (two-layer form)"),
     (N, 200, 1224, True, "posterior embed (hoisted) fwd"),
     (N, 1024, 9216, True, "encoder fc@128 fwd"),
     (N, 9216, 1024, False, "encoder fc@128 dgrad"),
@@ -171,11 +171,42 @@ def _wgfc():
     return lambda: ops.gemm_wgrad(dY, X, dW=dW, db=db)
 
 
-@case("gemm_wgrad 2450 rows 1024x3200 (decoder conv1 weight gradient)", flop=2.0 * N * 3200 * 1024)
+@case("gemm_wgrad 2450 rows 1024x3200 (decoder conv1 weight gradient, two-layer form)", flop=2.0 * N * 3200 * 1024)
 def _wg2():
     dY, X = r(N, 1024), r(N, 3200)
     dW = torch.empty(1024, 3200, device=dev)
     return lambda: ops.gemm_wgrad(dY, X, dW=dW, db=None, want_bias=False)
+
+
+# the decoder's first two layers composed (repo_amd/functional.py, dec_head_compose): what the update runs since round 6
+@case("dec head: W01aug = W1^T [W0|b0]  3200x232x1024 nn (+ the 1024x3200 transposing copy)", flop=2.0 * 3200 * 232 * 1024)
+def _dh_compose():
+    w1, w0aug = r(1024, 3200), r(1024, 232)
+    return lambda: ops.gemm(ops.transpose(w1), w0aug)
+
+
+@case("dec head: h1 = relu(feat W01^T + b01)  2450x3200x230 nt", flop=2.0 * N * 3200 * 230)
+def _dh_fwd():
+    feat, w01aug, b01 = r(N, 230), r(3200, 232), r(3200)
+    return lambda: ops.gemm(feat, w01aug[:, :230], transb=True, bias=b01, epi=ops.EPI_RELU)
+
+
+@case("dec head: (G|s) = d1^T feat  3200x230 over 2450 rows", flop=2.0 * N * 3200 * 230)
+def _dh_g():
+    d1, feat, gaug = r(N, 3200), r(N, 230), torch.zeros(3200, 232, device=dev)
+    return lambda: ops.gemm_wgrad(d1, feat, dW=gaug[:, :230])
+
+
+@case("dec head: d W1 = [W0|b0] (G|s)^T  1024x3200x232 nt", flop=2.0 * 1024 * 3200 * 232)
+def _dh_dw1():
+    w0aug, gaug, out = r(1024, 232), r(3200, 232), torch.empty(1024, 3200, device=dev)
+    return lambda: ops.gemm(w0aug, gaug, transb=True, out=out)
+
+
+@case("dec head: [d W0|d b0] = W1 (G|s)  1024x232 over the 3200 rows of W1^T", flop=2.0 * 1024 * 3200 * 232)
+def _dh_dw0():
+    w1t, gaug = r(3200, 1024), r(3200, 232)
+    return lambda: ops.gemm_wgrad(w1t, gaug, want_bias=False)
 
 
 P = fx.make_params(A, 7)
