@@ -93,6 +93,9 @@ class MultitaskDreamer(Dreamer):
         pe, _ = self._pg(self.encoder)
         embeds, st["enc_saved"] = Fm.cond_encoder_fwd(pe, frames, cond)
         pr, _ = self._pg(self.transition_model)
+        pd, _ = self._pg(self.obs_model)
+        # the decoder's composed first layers (functional.dec_head_compose): parameters only, made under the scan
+        head = Fm.dec_head_compose(pd) if (Fm._fused() and Fm._dec_compose(rows)) else None
         pseudo = torch.cat((actions[:-1], tasks[:-1]), dim=2).contiguous()
         sv = ops.rssm_observe_fwd(
             pr, *self._zero_state(B), pseudo,
@@ -105,10 +108,9 @@ class MultitaskDreamer(Dreamer):
         featc[:, :F_] = sv.featx[1:].reshape(rows, F_)
         featc[:, F_:] = cond
         st["featc"] = featc
-        pd, _ = self._pg(self.obs_model)
         feat = sv.featx[1:].reshape(rows, F_)
         st["feat"] = feat
-        st["nll_sum"], st["dec_saved"] = Fm.cond_decoder_fwd_nll(pd, feat, cond, frames, 1.0 / grow)
+        st["nll_sum"], st["dec_saved"] = Fm.cond_decoder_fwd_nll(pd, feat, cond, frames, 1.0 / grow, head=head)
         pw, _ = self._pg(self.reward_model)
         r_pred, st["rew_hid"] = ops.mlp_fwd(pw, featc)
         st["rew_sums"], st["drew"] = ops.scalar_nll(
