@@ -255,7 +255,14 @@ __global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, int spli
 // one slab, four loads in flight per thread -- and the 16 partial sums of an output meet in LDS in a fixed order
 // (bit-reproducible).  (Round 4's one-wave-per-output form read 64 different slabs per load instruction, one cache line
 // each: 70-80 us inside the update for 3.8 MB of slabs.)
-__global__ __launch_bounds__(1024) void conv_slab_reduce_wave_kernel(const float* __restrict__ slab, int splits, int Mrows,
+// SLAB_REDUCE_WAVES waves per workgroup walk the 16 slab groups (16: the round-4 form, one group per wave; 4: each wave takes
+// four groups in turn -- the same 16 partial sums in the same order, bit for bit, from a 256-thread workgroup that finds a
+// place on a busy chip; a 1024-thread workgroup needs a CU with 16 free wave slots, and inside the update these launches
+// waited for one: 78-135 us each in the trace against ~15 us alone).
+#ifndef SLAB_REDUCE_WAVES
+#define SLAB_REDUCE_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * SLAB_REDUCE_WAVES) void conv_slab_reduce_wave_kernel(const float* __restrict__ slab, int splits, int Mrows,
                                                                      int Ncols, float* __restrict__ dw,
                                                                      float* __restrict__ db, int accumulate, int tkk,
                                                                      int tcb, float* __restrict__ dbig) {
@@ -263,21 +270,24 @@ __global__ __launch_bounds__(1024) void conv_slab_reduce_wave_kernel(const float
   // and, behind them, the two row-parity halves of the channel sums of `big` (2 x tcb: one aligned block of 64 outputs)
   __shared__ float red[16][64];
   const int total = Mrows * (Ncols + 1) + (tkk > 0 ? 2 * tcb : 0);
-  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int o = threadIdx.x & 63, gw = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < total) {
-    int z = g;
-    for (; z + 48 < splits; z += 64) {
-      s0 += slab[(size_t)z * total + i];
-      s1 += slab[(size_t)(z + 16) * total + i];
-      s2 += slab[(size_t)(z + 32) * total + i];
-      s3 += slab[(size_t)(z + 48) * total + i];
+  for (int g = gw; g < 16; g += SLAB_REDUCE_WAVES) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+      int z = g;
+      for (; z + 48 < splits; z += 64) {
+        s0 += slab[(size_t)z * total + i];
+        s1 += slab[(size_t)(z + 16) * total + i];
+        s2 += slab[(size_t)(z + 32) * total + i];
+        s3 += slab[(size_t)(z + 48) * total + i];
+      }
+      for (; z < splits; z += 16) s0 += slab[(size_t)z * total + i];
     }
-    for (; z < splits; z += 16) s0 += slab[(size_t)z * total + i];
+    red[g][o] = (s0 + s1) + (s2 + s3);
   }
-  red[g][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
+  const int g = gw;
   if (g == 0 && i < total) {
     float s = 0.f;
 #pragma unroll
@@ -674,7 +684,7 @@ static void launch_conv_slab_reduce(const float* ws, int splits, int cs, int nw,
                                     hipStream_t s) {
   const int total = cs * (nw + 1);
   if (splits >= 64 && total <= 65536) {
-    hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(total, 64)), dim3(1024), 0, s, ws, splits, cs, nw, dw, db,
+    hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(total, 64)), dim3(64 * SLAB_REDUCE_WAVES), 0, s, ws, splits, cs, nw, dw, db,
                        accumulate, 0, 0, (float*)nullptr);
   } else {
     const int blocks = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
@@ -769,7 +779,7 @@ static int conv_wgrad_t(int64_t nimg, const float* small, const BigT* big, float
       a.want_dbig = covers && dbig != nullptr;
       rc = launch_tconv_wgrad<G, kTWgradNBK<G>, kTWgradNPW<G>>(a, tsplits, s);
       if (rc) return rc;
-      hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(TG::SLAB, 64)), dim3(1024), 0, s, (const float*)ws, tsplits,
+      hipLaunchKernelGGL(conv_slab_reduce_wave_kernel, dim3(cdiv(TG::SLAB, 64)), dim3(64 * SLAB_REDUCE_WAVES), 0, s, (const float*)ws, tsplits,
                          G::CS, G::CB * G::KK, dw, db, accumulate, G::KK, G::CB, covers ? dbig : nullptr);
       REPO_CHECK_LAUNCH();
       if (!covers && dbig)
