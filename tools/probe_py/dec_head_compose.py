@@ -56,3 +56,9 @@ t("G, s = d1^T feat   3200 x 230 over 2450 rows (+db)", lambda: ops.gemm_wgrad(d
 t("d W1 = [W0|b0] [G|s]^T  1024 x 3200 x 232 nt", lambda: ops.gemm(w0aug, gaug, transb=True, out=gw1), 2 * 1024 * 3200 * 232)
 t("[d W0|d b0] = W1 [G|s]  1024 x 232 over 3200 rows", lambda: ops.gemm_wgrad(w1t, gaug, want_bias=False), 2 * 1024 * 3200 * 232)
 t("d feat = d1 W01    2450 x 230 x 3200  nn (Dreamer)", lambda: ops.gemm(d1, w01aug[:, :230]), 2 * rows * 3200 * 230)
+print("# with the feature rows at a pitch of 232 ([feat | 1 | 0]): both K = 232 products on aligned operands")
+featp = torch.cat([feat, torch.ones(rows, 1, device=dev), torch.zeros(rows, 1, device=dev)], 1).contiguous()
+w01b = torch.randn(3200, 232, device=dev)
+t("[feat | 1 | 0]     torch.cat copy 2450 x 232", lambda: torch.cat([feat, torch.ones(rows, 1, device=dev), torch.zeros(rows, 1, device=dev)], 1), 0)
+t("h1 = relu([feat|1] [W01|b01]^T)  2450 x 3200 x 232 nt", lambda: ops.gemm(featp, w01b, transb=True, epi=ops.EPI_RELU), 2 * rows * 3200 * 232)
+t("(G|s) = d1^T [feat|1]  3200 x 232 over 2450 rows (no db)", lambda: ops.gemm_wgrad(d1, featp, want_bias=False), 2 * rows * 3200 * 232)
