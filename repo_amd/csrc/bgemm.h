@@ -332,10 +332,13 @@ typedef BgTile<128, 128, 32> BgMid;
 
 // Shapes this engine takes (everything else stays on the fp32-MFMA tile engines): big products whose tiles fill the
 // chip, 16-byte aligned operands with leading dimensions that keep every staged vector aligned.
+#ifndef BG_MIN_TILES
+#define BG_MIN_TILES 150   // (A/B builds: tools/build_variant.sh; 100 -- the 128 x 128 stack's fc at 1568 rows makes 104 tiles -- measured neutral: 12.94-12.99 against 12.90-13.02 ms per update, round 6)
+#endif
 inline bool bgemm_ok(int64_t M, int64_t N, int64_t K, bool a_kc, int64_t lda, bool b_kc, int64_t ldb, const void* A,
                      const void* B) {
   if (M < 512 || N < 512 || K < 128) return false;
-  if (((M + 127) / 128) * ((N + 127) / 128) < 150) return false;
+  if (((M + 127) / 128) * ((N + 127) / 128) < BG_MIN_TILES) return false;
   if (lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return false;
   if (!a_kc && M % 4) return false;  // row quads must not straddle the end of a row of A[k][m]
   if (!b_kc && N % 4) return false;
